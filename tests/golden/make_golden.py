@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference's own modules (runs ONLY in the build
+container, where /root/reference is mounted; the GPU box never sees the reference).
+
+    python tests/golden/make_golden.py [--full]      # writes tests/golden/*.npz
+
+The reference modules are imported unmodified from /root/reference on CPU (recipe:
+SURVEY.md Appendix D -- two in-memory no-op stubs for ``torchvision.utils`` and
+``omegaconf.listconfig`` that the arithmetic never touches).  They are filled with the
+deterministic synthetic state-dict of ``adaprompt_amd.synth`` (a function of tensor name,
+shape and seed), fed seeded inputs, and their outputs are stored.  A fixture holds only
+data: config, seeds, inputs too small to regenerate from a seed, and expected outputs.
+
+``--full`` additionally captures the full-size SD-1.5 UNet (859.5 M parameters) and VAE
+encoder at 512x512; takes ~1 min and ~10 GB of RAM.
+"""
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from adaprompt_amd import synth
+
+REF = "/root/reference"
+
+
+def import_reference():
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = lambda *a, **k: None
+    tvu.draw_bounding_boxes = lambda *a, **k: None
+    tv.utils = tvu
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.utils"] = tvu
+    oc = types.ModuleType("omegaconf")
+    ocl = types.ModuleType("omegaconf.listconfig")
+
+    class ListConfig(list):
+        pass
+    ocl.ListConfig = ListConfig
+    oc.listconfig = ocl
+    sys.modules["omegaconf"] = oc
+    sys.modules["omegaconf.listconfig"] = ocl
+    sys.path.insert(0, REF)
+    from ldm.modules.diffusionmodules import openaimodel, model, util
+    from ldm.modules import attention
+    from ldm.modules.distributions import distributions
+    return openaimodel, model, util, attention, distributions
+
+
+def fill(module, prefix, seed):
+    """load the synthetic state dict (by name) into a reference module."""
+    sd = {k: synth.synthetic_tensor(prefix + k, v.shape, seed) for k, v in module.state_dict().items()}
+    module.load_state_dict(sd, strict=True)
+    return module.eval()
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KB")
+
+
+def ellipse_mask(B, H, W):
+    """centred ellipse ~35 % area as float [B,1,H,W]."""
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    m = ((xx / 0.62) ** 2 + (yy / 0.72) ** 2 <= 1.0).float()
+    return m[None, None].repeat(B, 1, 1, 1)
+
+
+def border_mask(B, H, W, border):
+    m = torch.zeros(B, 1, H, W)
+    m[:, :, border:H - border, border:W - border] = 1
+    return m
+
+
+def subsample_act(key, ten):
+    """strided subsample of a captured activation (shared with tests/test_oracle_golden.py)."""
+    if key == "outfeat":                       # [B, C, H, W]
+        return ten[:, ::8, ::4, ::4] if ten.shape[-1] > 8 else ten[:, ::8]
+    n = ten.shape[2]                           # attn/attnscore [B,h,N,M], q [B,h,N,d]
+    return ten[:, ::4, ::max(1, n // 32)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    openaimodel, model, util, attention, distributions = import_reference()
+    seed = 0
+
+    # ---------------- per-op: timestep embedding, GroupNorm32+SiLU ----------------------
+    t = torch.tensor([0, 1, 500, 999])
+    save("op_timestep_embedding", t=t, out=util.timestep_embedding(t, 320))
+
+    for tag, (C, H, eps) in {"c320": (320, 16, 1e-5), "c1920": (1920, 8, 1e-5),
+                             "c640e6": (640, 8, 1e-6)}.items():
+        gn = util.GroupNorm32(32, C, eps=eps)
+        fill(gn, f"gn.{tag}.", seed)
+        x = synth.synthetic_input(f"gn.{tag}", (2, C, H, H), seed) * 1.5 + 0.3
+        y = gn(x)
+        y = y * torch.sigmoid(y)
+        save(f"op_groupnorm_silu_{tag}", C=C, H=H, eps=eps, out=y)
+
+    # ---------------- per-op: CrossAttention ---------------------------------------------
+    # (C, N, M ctx tokens or 0 for self, split K/V, mask)
+    cases = {
+        "self_c320_n256": (320, 256, 0, False, False),
+        "self_c320_n256_mask": (320, 256, 0, False, True),
+        "self_c640_n64": (640, 64, 0, False, False),
+        "self_c1280_n64": (1280, 64, 0, False, False),
+        "cross_c320_n256_m77": (320, 256, 77, False, False),
+        "cross_c1280_n64_m77_split": (1280, 64, 77, True, False),
+    }
+    for tag, (C, N, M, split, use_mask) in cases.items():
+        ca = attention.CrossAttention(query_dim=C, context_dim=768 if M else None, heads=8,
+                                      dim_head=C // 8)
+        fill(ca, f"ca.{tag}.", seed)
+        ca.save_attn_vars = True
+        x = synth.synthetic_input(f"ca.{tag}.x", (2, N, C), seed)
+        ctx = None
+        if M:
+            if split:
+                c = synth.synthetic_input(f"ca.{tag}.ctx", (2, 2 * M, 768), seed)
+                v, k = c.chunk(2, dim=1)
+                ctx = (v, k)
+            else:
+                ctx = synth.synthetic_input(f"ca.{tag}.ctx", (2, M, 768), seed)
+        mask = None
+        if use_mask:
+            hw = int(N ** 0.5)
+            mask = border_mask(2, hw, hw, 2)
+            mask[1] = ellipse_mask(1, hw, hw)[0]
+        out = ca(x, context=ctx, mask=mask)
+        acts = ca.cached_activations
+        save(f"op_cross_attention_{tag}", C=C, N=N, M=M, split=split, use_mask=use_mask, out=out,
+             q=acts["q"][:, :, ::4], attn=acts["attn"][:, :, ::16],
+             attnscore=acts["attnscore"][:, :, ::16],
+             mask=mask if mask is not None else np.zeros(0))
+
+    # ---------------- per-op: ResBlock / Down / Up / SpatialTransformer -------------------
+    for tag, (ci, co, H) in {"c320_320": (320, 320, 16), "c640_320_skip": (640, 320, 8),
+                             "c1920_640_skip": (1920, 640, 4)}.items():
+        rb = openaimodel.ResBlock(ci, 1280, 0, out_channels=co, dims=2, use_checkpoint=True)
+        fill(rb, f"res.{tag}.", seed)
+        x = synth.synthetic_input(f"res.{tag}.x", (2, ci, H, H), seed)
+        emb = synth.synthetic_input(f"res.{tag}.emb", (2, 1280), seed)
+        save(f"op_resblock_{tag}", ci=ci, co=co, H=H, out=rb(x, emb))
+
+    dn = openaimodel.Downsample(320, True, dims=2, out_channels=320)
+    fill(dn, "down.", seed)
+    x = synth.synthetic_input("down.x", (2, 320, 16, 16), seed)
+    save("op_downsample_c320", out=dn(x))
+    up = openaimodel.Upsample(320, True, dims=2, out_channels=320)
+    fill(up, "up.", seed)
+    x = synth.synthetic_input("up.x", (2, 320, 8, 8), seed)
+    save("op_upsample_c320", out=up(x))
+
+    for tag, (C, H, use_mask) in {"c320_h16": (320, 16, False), "c320_h16_mask": (320, 16, True),
+                                  "c640_h8": (640, 8, False)}.items():
+        st = attention.SpatialTransformer(C, 8, C // 8, depth=1, context_dim=768)
+        fill(st, f"st.{tag}.", seed)
+        x = synth.synthetic_input(f"st.{tag}.x", (2, C, H, H), seed)
+        ctx = synth.synthetic_input(f"st.{tag}.ctx", (2, 77, 768), seed)
+        mask = border_mask(2, 64, 64, 9) if use_mask else None
+        out = st(x, context=lambda: ((ctx, ctx), None), mask=mask)
+        save(f"op_spatial_transformer_{tag}", C=C, H=H, use_mask=use_mask, out=out)
+
+    # ---------------- per-op: VAE blocks ---------------------------------------------------
+    for tag, (ci, co, H) in {"c128_128": (128, 128, 16), "c128_256_nin": (128, 256, 16)}.items():
+        rb = model.ResnetBlock(in_channels=ci, out_channels=co, temb_channels=0, dropout=0.0)
+        fill(rb, f"vres.{tag}.", seed)
+        x = synth.synthetic_input(f"vres.{tag}.x", (2, ci, H, H), seed)
+        save(f"op_vae_resnet_{tag}", ci=ci, co=co, H=H, out=rb(x, None))
+    dn = model.Downsample(128, True)
+    fill(dn, "vdown.", seed)
+    x = synth.synthetic_input("vdown.x", (2, 128, 16, 16), seed)
+    save("op_vae_downsample_c128", out=dn(x))
+    for tag, use_mask in {"nomask": False, "mask": True}.items():
+        ab = model.AttnBlock(128)
+        fill(ab, "vattn.", seed)
+        x = synth.synthetic_input("vattn.x", (2, 128, 16, 16), seed)
+        mask = None
+        if use_mask:
+            mask = {"fg_mask": ellipse_mask(2, 128, 128), "aug_mask": border_mask(2, 128, 128, 17)}
+        save(f"op_vae_attnblock_{tag}", out=ab(x, mask))
+
+    # ---------------- whole model: narrow UNet (mc=32, ctx 64), bs=2 -----------------------
+    def run_unet(cfg, B, M, tag, iter_type="normal_recon", capture=True, use_mask=False,
+                 with_grad=False, subsample=False):
+        kw = dict(cfg)
+        kw["attention_resolutions"] = list(kw["attention_resolutions"])
+        kw["channel_mult"] = list(kw["channel_mult"])
+        unet = openaimodel.UNetModel(**kw)
+        fill(unet, "model.diffusion_model.", seed)
+        x = synth.synthetic_input(f"unet.{tag}.x", (B, 4, 64, 64), seed)
+        tt = torch.tensor([500, 37, 999, 3][:B])
+        ntok = 2 * M if iter_type == "mix_hijk" else M
+        ctx = synth.synthetic_input(f"unet.{tag}.ctx", (16 * B, ntok, cfg["context_dim"]), seed)
+        img_mask = border_mask(B, 64, 64, 6) if use_mask else None
+        extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1,
+                 "iter_type": iter_type, "is_training": True, "capture_distill_attn": capture,
+                 "placeholder2indices": None, "img_mask": img_mask}
+        out = {}
+        if with_grad:
+            with torch.enable_grad():
+                ctx_g = ctx.clone().requires_grad_(True)
+                eps = unet(x, tt, context=ctx_g, context_in=None, extra_info=extra)
+                w = synth.synthetic_input(f"unet.{tag}.gw", eps.shape, seed)
+                (eps * w).sum().backward()
+                g = ctx_g.grad
+                out["grad_context_norm"] = g.norm()
+                out["grad_context"] = g[:, ::4, ::8] if subsample else g
+                eps = eps.detach()
+        else:
+            eps = unet(x, tt, context=ctx, context_in=None, extra_info=extra)
+        out["eps"] = eps
+        acts = extra["ca_layers_activations"]
+        for key in ("outfeat", "attn", "attnscore", "q"):
+            for li, ten in acts[key].items():
+                ten = ten.detach()
+                # strided subsamples keep the fixtures small; the test applies the same slices
+                ten = subsample_act(key, ten)
+                out[f"{key}_{li}"] = ten
+        save(f"unet_{tag}", B=B, M=M, iter_type=iter_type, capture=capture, use_mask=use_mask,
+             t=tt, **out)
+        del unet
+
+    narrow = dict(synth.SD15_UNET, model_channels=32, context_dim=64)
+    run_unet(narrow, 2, 77, "narrow_recon", with_grad=True)
+    run_unet(narrow, 2, 77, "narrow_mask", use_mask=True, capture=False)
+    run_unet(narrow, 2, 77, "narrow_mixhijk", iter_type="mix_hijk")
+
+    # ---------------- whole model: narrow VAE encoder (ch=32, 64x64 input) -----------------
+    def run_vae(dd, B, res, tag, use_mask):
+        enc = model.Encoder(**{**dd, "ch_mult": list(dd["ch_mult"]), "attn_resolutions": []})
+        fill(enc, "first_stage_model.encoder.", seed)
+        qc = torch.nn.Conv2d(2 * dd["z_channels"], 2 * 4, 1)
+        fill(qc, "first_stage_model.quant_conv.", seed)
+        x = synth.synthetic_input(f"vae.{tag}.x", (B, 3, res, res), seed, 0.5).clamp(-1, 1)
+        mask = None
+        if use_mask:
+            mask = {"fg_mask": ellipse_mask(B, res, res), "aug_mask": border_mask(B, res, res, res // 16)}
+        h = enc(x, mask)
+        moments = qc(h)
+        post = distributions.DiagonalGaussianDistribution(moments)
+        save(f"vae_{tag}", B=B, res=res, use_mask=use_mask, moments=moments,
+             mean=post.mean, std=post.std)
+
+    vnarrow = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    run_vae(vnarrow, 2, 64, "narrow_nomask", False)
+    run_vae(vnarrow, 2, 64, "narrow_mask", True)
+
+    if args.full:
+        run_unet(dict(synth.SD15_UNET), 1, 77, "sd15_recon", with_grad=True, subsample=True)
+        run_vae(dict(synth.SD15_VAE_DD), 1, 512, "sd15_mask", True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,302 @@
+"""The oracle (oracle/ldm_oracle.py) against the golden vectors captured from the
+reference's own modules (tests/golden/make_golden.py), plus closed-form known-answer
+checks for the ddpm.py pieces that cannot be imported.  CPU only."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adaprompt_amd import synth
+from oracle import ldm_oracle as O
+from conftest import load_golden, rel_err, ellipse_mask, border_mask, subsample_act
+
+TOL = 2e-5     # CPU restatement vs reference modules, relative L2 (<=1e-5..)
+
+
+def sd_for(shapes, prefix, seed=0):
+    return synth.synthetic_like(shapes, seed, prefix)
+
+
+def test_timestep_embedding():
+    g = load_golden("op_timestep_embedding")
+    assert rel_err(O.timestep_embedding(g["t"], 320), g["out"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["c320", "c1920", "c640e6"])
+def test_groupnorm_silu(tag):
+    g = load_golden("op_groupnorm_silu_" + tag)
+    C, H, eps = g["C"], g["H"], g["eps"]
+    w = synth.synthetic_tensor(f"gn.{tag}.weight", (C,))
+    b = synth.synthetic_tensor(f"gn.{tag}.bias", (C,))
+    x = synth.synthetic_input(f"gn.{tag}", (2, C, H, H)) * 1.5 + 0.3
+    assert rel_err(O.silu(O.group_norm32(x, w, b, eps)), g["out"]) < TOL
+
+
+def ca_sd(tag, C, M):
+    p = f"ca.{tag}."
+    cd = 768 if M else C
+    return {p + "to_q.weight": synth.synthetic_tensor(p + "to_q.weight", (C, C)),
+            p + "to_k.weight": synth.synthetic_tensor(p + "to_k.weight", (C, cd)),
+            p + "to_v.weight": synth.synthetic_tensor(p + "to_v.weight", (C, cd)),
+            p + "to_out.0.weight": synth.synthetic_tensor(p + "to_out.0.weight", (C, C)),
+            p + "to_out.0.bias": synth.synthetic_tensor(p + "to_out.0.bias", (C,))}
+
+
+@pytest.mark.parametrize("tag", ["self_c320_n256", "self_c320_n256_mask", "self_c640_n64",
+                                 "self_c1280_n64", "cross_c320_n256_m77",
+                                 "cross_c1280_n64_m77_split"])
+def test_cross_attention(tag):
+    g = load_golden("op_cross_attention_" + tag)
+    C, N, M = g["C"], g["N"], g["M"]
+    sd = ca_sd(tag, C, M)
+    x = synth.synthetic_input(f"ca.{tag}.x", (2, N, C))
+    ctx = None
+    if M:
+        if g["split"]:
+            v, k = synth.synthetic_input(f"ca.{tag}.ctx", (2, 2 * M, 768)).chunk(2, dim=1)
+            ctx = (v, k)
+        else:
+            ctx = synth.synthetic_input(f"ca.{tag}.ctx", (2, M, 768))
+    mask = g["mask"] if g["use_mask"] else None
+    save = {}
+    out = O.cross_attention(sd, f"ca.{tag}", x, ctx, mask, 8, save)
+    assert rel_err(out, g["out"]) < TOL
+    assert rel_err(save["q"][:, :, ::4], g["q"]) < TOL
+    assert rel_err(save["attn"][:, :, ::16], g["attn"]) < TOL
+    if not g["use_mask"]:    # masked scores hold -finfo.max; compare the finite ones only
+        assert rel_err(save["attnscore"][:, :, ::16], g["attnscore"]) < TOL
+
+
+@pytest.mark.parametrize("tag,ci,co,H", [("c320_320", 320, 320, 16), ("c640_320_skip", 640, 320, 8),
+                                         ("c1920_640_skip", 1920, 640, 4)])
+def test_resblock(tag, ci, co, H):
+    g = load_golden("op_resblock_" + tag)
+    p = f"res.{tag}"
+    shapes = [("in_layers.0.weight", (ci,)), ("in_layers.0.bias", (ci,)),
+              ("in_layers.2.weight", (co, ci, 3, 3)), ("in_layers.2.bias", (co,)),
+              ("emb_layers.1.weight", (co, 1280)), ("emb_layers.1.bias", (co,)),
+              ("out_layers.0.weight", (co,)), ("out_layers.0.bias", (co,)),
+              ("out_layers.3.weight", (co, co, 3, 3)), ("out_layers.3.bias", (co,))]
+    if ci != co:
+        shapes += [("skip_connection.weight", (co, ci, 1, 1)), ("skip_connection.bias", (co,))]
+    sd = sd_for(shapes, p + ".")
+    x = synth.synthetic_input(f"res.{tag}.x", (2, ci, H, H))
+    emb = synth.synthetic_input(f"res.{tag}.emb", (2, 1280))
+    assert rel_err(O.res_block(sd, p, x, emb), g["out"]) < TOL
+
+
+def test_down_up_sample():
+    g = load_golden("op_downsample_c320")
+    sd = sd_for([("op.weight", (320, 320, 3, 3)), ("op.bias", (320,))], "down.")
+    x = synth.synthetic_input("down.x", (2, 320, 16, 16))
+    assert rel_err(O._conv(sd, "down.op", x, stride=2, padding=1), g["out"]) < TOL
+    g = load_golden("op_upsample_c320")
+    sd = sd_for([("conv.weight", (320, 320, 3, 3)), ("conv.bias", (320,))], "up.")
+    x = synth.synthetic_input("up.x", (2, 320, 8, 8))
+    y = O._conv(sd, "up.conv", F.interpolate(x, scale_factor=2, mode="nearest"), padding=1)
+    assert rel_err(y, g["out"]) < TOL
+
+
+def st_shapes(C):
+    out = [("norm.weight", (C,)), ("norm.bias", (C,)), ("proj_in.weight", (C, C, 1, 1)),
+           ("proj_in.bias", (C,)), ("proj_out.weight", (C, C, 1, 1)), ("proj_out.bias", (C,))]
+    b = "transformer_blocks.0."
+    for a, cd in (("attn1", C), ("attn2", 768)):
+        out += [(f"{b}{a}.to_q.weight", (C, C)), (f"{b}{a}.to_k.weight", (C, cd)),
+                (f"{b}{a}.to_v.weight", (C, cd)), (f"{b}{a}.to_out.0.weight", (C, C)),
+                (f"{b}{a}.to_out.0.bias", (C,))]
+    out += [(b + "ff.net.0.proj.weight", (8 * C, C)), (b + "ff.net.0.proj.bias", (8 * C,)),
+            (b + "ff.net.2.weight", (C, 4 * C)), (b + "ff.net.2.bias", (C,))]
+    for n in ("norm1", "norm2", "norm3"):
+        out += [(f"{b}{n}.weight", (C,)), (f"{b}{n}.bias", (C,))]
+    return out
+
+
+@pytest.mark.parametrize("tag,C,H,use_mask", [("c320_h16", 320, 16, False),
+                                              ("c320_h16_mask", 320, 16, True),
+                                              ("c640_h8", 640, 8, False)])
+def test_spatial_transformer(tag, C, H, use_mask):
+    g = load_golden("op_spatial_transformer_" + tag)
+    sd = sd_for(st_shapes(C), f"st.{tag}.")
+    x = synth.synthetic_input(f"st.{tag}.x", (2, C, H, H))
+    ctx = synth.synthetic_input(f"st.{tag}.ctx", (2, 77, 768))
+    mask = border_mask(2, 64, 64, 9) if use_mask else None
+    out = O.spatial_transformer(sd, f"st.{tag}", x, (ctx, ctx), mask, 8)
+    assert rel_err(out, g["out"]) < TOL
+
+
+def vres_shapes(ci, co):
+    s = [("norm1.weight", (ci,)), ("norm1.bias", (ci,)), ("conv1.weight", (co, ci, 3, 3)),
+         ("conv1.bias", (co,)), ("norm2.weight", (co,)), ("norm2.bias", (co,)),
+         ("conv2.weight", (co, co, 3, 3)), ("conv2.bias", (co,))]
+    if ci != co:
+        s += [("nin_shortcut.weight", (co, ci, 1, 1)), ("nin_shortcut.bias", (co,))]
+    return s
+
+
+@pytest.mark.parametrize("tag,ci,co", [("c128_128", 128, 128), ("c128_256_nin", 128, 256)])
+def test_vae_resnet(tag, ci, co):
+    g = load_golden("op_vae_resnet_" + tag)
+    sd = sd_for(vres_shapes(ci, co), f"vres.{tag}.")
+    x = synth.synthetic_input(f"vres.{tag}.x", (2, ci, 16, 16))
+    assert rel_err(O.vae_resnet_block(sd, f"vres.{tag}", x), g["out"]) < TOL
+
+
+def test_vae_downsample():
+    g = load_golden("op_vae_downsample_c128")
+    sd = sd_for([("conv.weight", (128, 128, 3, 3)), ("conv.bias", (128,))], "vdown.")
+    x = synth.synthetic_input("vdown.x", (2, 128, 16, 16))
+    assert rel_err(O.vae_downsample(sd, "vdown", x), g["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_vae_attnblock(tag):
+    g = load_golden("op_vae_attnblock_" + tag)
+    shapes = [("norm.weight", (128,)), ("norm.bias", (128,))]
+    for n in ("q", "k", "v", "proj_out"):
+        shapes += [(n + ".weight", (128, 128, 1, 1)), (n + ".bias", (128,))]
+    sd = sd_for(shapes, "vattn.")
+    x = synth.synthetic_input("vattn.x", (2, 128, 16, 16))
+    mask = None
+    if tag == "mask":
+        mask = {"fg_mask": ellipse_mask(2, 128, 128), "aug_mask": border_mask(2, 128, 128, 17)}
+    assert rel_err(O.vae_attn_block(sd, "vattn", x, mask), g["out"]) < TOL
+
+
+def run_unet_case(cfg, tag, g, with_grad):
+    B, M = g["B"], g["M"]
+    sd = synth.synthetic_unet_state_dict(cfg)
+    x = synth.synthetic_input(f"unet.{tag}.x", (B, 4, 64, 64))
+    ntok = 2 * M if g["iter_type"] == "mix_hijk" else M
+    ctx = synth.synthetic_input(f"unet.{tag}.ctx", (16 * B, ntok, cfg["context_dim"]))
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1,
+             "iter_type": g["iter_type"], "is_training": True,
+             "capture_distill_attn": bool(g["capture"]), "placeholder2indices": None,
+             "img_mask": border_mask(B, 64, 64, 6) if g["use_mask"] else None}
+    if with_grad:
+        ctx = ctx.clone().requires_grad_(True)
+    eps = O.unet_forward(sd, cfg, x, g["t"], ctx, extra)
+    assert rel_err(eps, g["eps"]) < TOL
+    acts = extra["ca_layers_activations"]
+    n_checked = 0
+    for key in ("outfeat", "attn", "attnscore", "q"):
+        for li, ten in acts[key].items():
+            assert rel_err(subsample_act(key, ten.detach()), g[f"{key}_{li}"]) < TOL, (key, li)
+            n_checked += 1
+    if g["capture"]:
+        assert n_checked == 4 * 12
+    if with_grad:
+        w = synth.synthetic_input(f"unet.{tag}.gw", eps.shape)
+        (eps * w).sum().backward()
+        return ctx.grad
+
+
+def test_unet_narrow_recon_and_grad():
+    g = load_golden("unet_narrow_recon")
+    cfg = dict(synth.SD15_UNET, model_channels=32, context_dim=64)
+    grad = run_unet_case(cfg, "narrow_recon", g, True)
+    assert rel_err(grad, g["grad_context"]) < 1e-4
+    assert abs(float(grad.norm()) / float(g["grad_context_norm"]) - 1) < 1e-4
+
+
+def test_unet_narrow_mask():
+    g = load_golden("unet_narrow_mask")
+    run_unet_case(dict(synth.SD15_UNET, model_channels=32, context_dim=64), "narrow_mask", g, False)
+
+
+def test_unet_narrow_mixhijk():
+    g = load_golden("unet_narrow_mixhijk")
+    run_unet_case(dict(synth.SD15_UNET, model_channels=32, context_dim=64), "narrow_mixhijk", g, False)
+
+
+@pytest.mark.slow
+def test_unet_sd15_full_size():
+    """the full 859.5 M-parameter UNet, bs=1 (config 1 of BASELINE.json) + grad wrt context."""
+    g = load_golden("unet_sd15_recon")
+    cfg = dict(synth.SD15_UNET)
+    grad = run_unet_case(cfg, "sd15_recon", g, True)
+    assert rel_err(grad[:, ::4, ::8], g["grad_context"]) < 1e-4
+    assert abs(float(grad.norm()) / float(g["grad_context_norm"]) - 1) < 1e-4
+
+
+def run_vae_case(dd, tag, g):
+    B, res = g["B"], g["res"]
+    sd = synth.synthetic_vae_state_dict(dd)
+    x = synth.synthetic_input(f"vae.{tag}.x", (B, 3, res, res), 0, 0.5).clamp(-1, 1)
+    mask = None
+    if g["use_mask"]:
+        mask = {"fg_mask": ellipse_mask(B, res, res), "aug_mask": border_mask(B, res, res, res // 16)}
+    with torch.no_grad():
+        moments = O.autoencoder_encode_moments(sd, dd, x, mask)
+    assert rel_err(moments, g["moments"]) < 1e-4
+    z = O.gaussian_sample(moments, torch.zeros_like(g["mean"]))
+    assert rel_err(z, g["mean"]) < 1e-4
+    z1 = O.gaussian_sample(moments, torch.ones_like(g["mean"]))
+    assert rel_err(z1 - z, g["std"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["narrow_nomask", "narrow_mask"])
+def test_vae_narrow(tag):
+    run_vae_case(dict(synth.SD15_VAE_DD, ch=32, resolution=64), tag, load_golden("vae_" + tag))
+
+
+@pytest.mark.slow
+def test_vae_sd15_full_size():
+    run_vae_case(dict(synth.SD15_VAE_DD), "sd15_mask", load_golden("vae_sd15_mask"))
+
+
+# ---------------------------------------------------------------------------------------------
+# ddpm.py pieces that cannot be imported here: closed-form known answers
+# ---------------------------------------------------------------------------------------------
+
+def test_schedule_closed_form():
+    s = O.make_schedule()
+    b0, bT = 0.00085, 0.012
+    assert abs(float(s["betas"][0]) - b0) < 1e-9 and abs(float(s["betas"][-1]) - bT) < 1e-8
+    # alpha_bar_t = prod (1 - beta_i), independently in python floats
+    ab, acc = [], 1.0
+    for i in range(1000):
+        beta = (math.sqrt(b0) + (math.sqrt(bT) - math.sqrt(b0)) * i / 999) ** 2
+        acc *= 1.0 - beta
+        ab.append(acc)
+    ab = torch.tensor(ab, dtype=torch.float64)
+    assert rel_err(s["alphas_cumprod"], ab) < 1e-6
+    assert rel_err(s["sqrt_alphas_cumprod"] ** 2 + s["sqrt_one_minus_alphas_cumprod"] ** 2,
+                   torch.ones(1000)) < 1e-6
+    # SD-1.5's well-known terminal SNR: alpha_bar_999 ~= 0.00466
+    assert abs(float(s["alphas_cumprod"][-1]) - 0.0046600) < 2e-5
+
+
+def test_q_sample_and_predict_x0_roundtrip():
+    s = O.make_schedule()
+    x0 = synth.synthetic_input("ka.x0", (4, 4, 8, 8))
+    n = synth.synthetic_input("ka.n", (4, 4, 8, 8))
+    t = torch.tensor([0, 10, 500, 999])
+    xt = O.q_sample(s, x0, t, n)
+    a0 = math.sqrt(1 - 0.00085)
+    assert rel_err(xt[0], a0 * x0[0] + math.sqrt(1 - a0 * a0) * n[0]) < 1e-6
+    assert rel_err(O.predict_start_from_noise(s, xt, t, n)[:3], x0[:3]) < 1e-4
+    assert rel_err(xt[3], n[3]) < 0.08          # t=999 is almost pure noise
+
+
+def test_recon_loss_known_answers():
+    a = synth.synthetic_input("ka.a", (2, 4, 8, 8))
+    b = synth.synthetic_input("ka.b", (2, 4, 8, 8))
+    loss, pix = O.calc_recon_loss(a, b)
+    assert abs(float(loss) - float(F.mse_loss(a, b))) < 1e-6      # all-ones masks == mse (denominator +1e-6)
+    # hand case: fg = left half, img_mask all ones, w_bg = 0.1
+    fg = torch.zeros(2, 1, 8, 8)
+    fg[..., :4] = 1
+    loss, pix = O.calc_recon_loss(a, b, torch.ones(2, 1, 8, 8), fg, 1.0, 0.1)
+    num = pix[..., :4].sum() + 0.1 * pix[..., 4:].sum()
+    den = 2 * 8 * 4 * 4 + 0.1 * 2 * 8 * 4 * 4 + 1e-6     # masks expand over the 4 channels
+    assert abs(float(loss) - float(num / den)) < 1e-6
+
+
+def test_gaussian_sample_clamp():
+    m = torch.zeros(1, 8, 2, 2)
+    m[:, 4:] = 100.0        # logvar clamps to 20
+    z = O.gaussian_sample(m, torch.ones(1, 4, 2, 2))
+    assert rel_err(z, torch.full((1, 4, 2, 2), math.exp(10.0))) < 1e-6
+    assert rel_err(O.get_first_stage_encoding(m, torch.ones(1, 4, 2, 2)), 0.18215 * z) < 1e-6
