@@ -1,0 +1,81 @@
+"""ctypes binding of libadaprompt_hip.so -- the only doorway from the Python host code to the
+HIP kernels.  Signatures are read from include/adaprompt_hip.h, so header and binding cannot
+drift.  There is no CPU fallback: if the library is missing and cannot be built, or a call
+returns a non-zero status, a RuntimeError is raised."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "adaprompt_hip.h")
+LIB_PATH = os.path.join(HERE, "libadaprompt_hip.so")
+
+_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes], [argnames])} for every prototype in the header."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    protos = {}
+    for m in re.finditer(r"\b(const char\*|int|long)\s+(adap_\w+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = {"int": ctypes.c_int, "long": ctypes.c_long, "const char*": ctypes.c_char_p}[ret]
+        argtypes, argnames = [], []
+        args = args.strip()
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.+?)\s*(\w+)$", a)
+                typ, an = mm.group(1).strip(), mm.group(2)
+                if "*" in typ:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_SCALARS[typ.replace("const ", "")])
+                argnames.append(an)
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def load(build_if_missing=True):
+    """dlopen the in-tree library (building it with hipcc first if it is absent)."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise RuntimeError(f"{LIB_PATH} not found; run `python -m adaprompt_amd.build`")
+        from . import build as _build
+        _build.build(verbose=False)
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (restype, argtypes, _) in _protos.items():
+        fn = getattr(lib, name)       # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.adap_abi_version() != 1:
+        raise RuntimeError("libadaprompt_hip.so: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise HipError with adap_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HipError(f"{name} failed ({rc}): {lib.adap_last_error().decode()}")
+
+
+def call_long(name, *args):
+    return getattr(load(), name)(*args)

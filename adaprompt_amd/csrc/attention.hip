@@ -1,0 +1,672 @@
+// Fused (flash-style) multi-head attention for the SD-1.5 UNet on CDNA4 matrix cores.
+//
+// Reference semantics: CrossAttention.forward, attention.py:172-257 --
+//   sim = (q k^T) * dim_head^-0.5 ; key mask -> -finfo.max ; softmax over keys ; out = attn v.
+// dim_head is C/8 = 40 / 80 / 160 (not 64); self-attention has N = M up to 4096 tokens, cross
+// attention M = 77 (or two 77-token halves for V and K in 'mix_hijk').  The reference
+// materialises sim ([32,4096,4096] fp32 = 2.1 GB per layer at bs=4); here the score tile never
+// leaves the registers.
+//
+// Tensors are token-major bf16: q [B,N,H*d], k,v [B,M,H*d] (outputs of the to_q/to_k/to_v
+// contractions), out [B,N,H*d] bf16 (operand of to_out), lse [B,H,N] f32 for the backward.
+//
+// Structure (v_mfma_f32_32x32x16_bf16, fp32 softmax/accumulate): a workgroup = 4 waves = 128
+// queries of one (batch, head); a wave owns 32 queries.  Scores are computed TRANSPOSED,
+// S^T = K Q^T, so that the query is on the lane and the keys are in the accumulator registers:
+// row max / row sum are in-lane plus one half-wave exchange, the running rescale is a per-lane
+// scalar, and the accumulator is already the B operand of O^T = V^T P^T (guide section 3, "An
+// accumulator tile as the next MFMA's operand").  K tiles are read by rows (ds_read_b128), V by
+// the hardware-transposing ds_read_b64_tr_b16 from the same row-major [key][d] image, so no
+// transposed copy of V exists anywhere.
+//
+// Backward = two kernels without atomics (bit-reproducible): dQ is query-stationary (same loop
+// as the forward), dK/dV are key-stationary (a wave owns 32 keys and sweeps the queries); P is
+// recomputed from the saved LSE.
+#include "common.h"
+#include <float.h>
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+}
+
+// A-operand fragment of X^T for a [row][col] bf16 LDS image X: element j of lane (c = lane&31, h = lane>>5)
+// is X[row0 + 8*(j>>2) + 4h + (j&3)][col0 + c]  (the k-order of an accumulator used as B operand).
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* img, int stride, int row0, int col0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const char* p = img + (row0 + 4 * (g >> 1) + (i >> 2)) * stride + (col0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+    bf16x4 lo = lds_tr16(p);
+    bf16x4 hi = lds_tr16(p + 8 * stride);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sh) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * sh + j];
+    return r;
+}
+
+struct AttnParams {
+    const uint16_t* q; long ldq;
+    const uint16_t* k; long ldk;
+    const uint16_t* v; long ldv;
+    const uint8_t* kmask;       // [B][M] (1 = keep) or null
+    uint16_t* o; long ldo;      // fwd out (bf16)
+    float* lse;                 // [B][H][N]
+    // backward
+    const uint16_t* dout; long lddo;   // bf16 [B,N,H*d]
+    const float* delta;                // [B][H][N]
+    float* dq32; uint16_t* dq16; long lddq;
+    float* dk32; uint16_t* dk16; long lddk;
+    float* dv32; uint16_t* dv16; long lddv;
+    int B, H, N, M, d;
+    float scale;
+};
+
+template <int KS>
+struct TileGeom {
+    static constexpr int DPK = KS * 16;
+    static constexpr int NCH = DPK / 8;                 // 16-byte chunks per padded row
+    static constexpr int RSTRIDE = ((NCH | 1)) * 16;    // odd chunk count: conflict-free ds_read_b128 by rows
+};
+
+template <int VT>
+struct VGeom {
+    static constexpr int VSTRIDE = (VT % 2 == 1) ? 64 * VT : 64 * VT + 64;   // == 64 (mod 128): conflict-free tr reads
+};
+
+// stage a [rows x d] bf16 tile (row-major in HBM with leading dim ld) into LDS with the given stride, zero padded to
+// nch chunks per row; rows >= nvalid are zero.
+__device__ __forceinline__ void stage_tile(char* dst, int stride, int nch, const uint16_t* src, long ld, int nrows,
+                                           int nvalid, int d, int tid) {
+    for (int idx = tid; idx < nrows * nch; idx += 256) {
+        int row = idx / nch, ch = idx - row * nch;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < nvalid && ch * 8 < d) v = *(const uint4*)(src + (size_t)row * ld + ch * 8);
+        *(uint4*)(dst + row * stride + ch * 16) = v;
+    }
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int KS, int VT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    using G = TileGeom<KS>;
+    constexpr int KSTRIDE = G::RSTRIDE;
+    constexpr int VSTRIDE = VGeom<VT>::VSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                       // [64][KSTRIDE]
+    char* sV = sK + 64 * KSTRIDE;          // [64][VSTRIDE]
+    float* sBias = (float*)(sV + 64 * VSTRIDE);   // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
+    const int q = blockIdx.x * 128 + wave * 32 + c;
+    const int d = p.d;
+    const float cs = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int ch = 2 * s + h;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < p.N && ch * 8 < d) v = *(const uint4*)(p.q + ((size_t)b * p.N + q) * p.ldq + head * d + ch * 8);
+        qf[s] = __builtin_bit_cast(bf16x8, v);
+    }
+
+    f32x16 O[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[vt][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
+    const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
+    const int ntiles = (p.M + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * 64;
+        const int nvalid = min(64, p.M - key0);
+        stage_tile(sK, KSTRIDE, G::NCH, kb + (size_t)key0 * p.ldk, p.ldk, 64, nvalid, d, tid);
+        stage_tile(sV, VSTRIDE, (d + 7) / 8, vb + (size_t)key0 * p.ldv, p.ldv, 64, nvalid, d, tid);
+        if (tid < 64) {
+            int key = key0 + tid;
+            float bias = 0.f;
+            if (key >= p.M) bias = -INFINITY;
+            else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
+            sBias[tid] = bias;
+        }
+        __syncthreads();
+
+        f32x16 S[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[t][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
+                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[t], 0, 0, 0);
+            }
+        }
+        // scale, bias, running max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
+                float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = S[t][4 * g + e] * cs + bb[e];
+                    S[t][4 * g + e] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float alpha = exp2f(m - mnew);
+        m = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = exp2f(S[t][r] - mnew);
+                S[t][r] = pv;
+                psum += pv;
+            }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[vt][r] *= alpha;
+        // O^T += V^T P^T
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                bf16x8 pf = acc_to_frag(S[t], sh);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) {
+                    bf16x8 vf = lds_tr_frag(sV, VSTRIDE, 32 * t + 16 * sh, 32 * vt, lane);
+                    O[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[vt], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+    }
+    const float ltot = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (q < p.N) {
+        uint16_t* orow = p.o + ((size_t)b * p.N + q) * p.ldo + head * d;
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int d0 = 32 * vt + 8 * g + 4 * h;
+                if (d0 < d) {
+                    uint2 w;
+                    w.x = pack_bf16x2(O[vt][4 * g] * inv, O[vt][4 * g + 1] * inv);
+                    w.y = pack_bf16x2(O[vt][4 * g + 2] * inv, O[vt][4 * g + 3] * inv);
+                    *(uint2*)(orow + d0) = w;
+                }
+            }
+        if (h == 0 && p.lse) p.lse[((size_t)b * p.H + head) * p.N + q] = (m + log2f(ltot)) * 0.6931471805599453f;
+    }
+}
+
+// =============================================================================================
+// backward, part 0: delta[b][h][n] = sum_d dO * O      (one wave per token row)
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, long ldo,
+                                                         const uint16_t* __restrict__ dout, long lddo,
+                                                         float* __restrict__ delta, int B, int H, int N, int d) {
+    __shared__ float part[4][160];     // C/8 <= 160 chunks
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + w;
+    const int nch = H * d / 8;
+    const bool live = row < (long)B * N;
+    if (live) {
+        for (int ch = lane; ch < nch; ch += 64) {
+            uint4 a = *(const uint4*)(o + row * ldo + ch * 8);
+            uint4 g = *(const uint4*)(dout + row * lddo + ch * 8);
+            float fa[8], fg[8];
+            unpack_bf16x8(a, fa);
+            unpack_bf16x8(g, fg);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += fa[e] * fg[e];
+            part[w][ch] = s;
+        }
+    }
+    __syncthreads();
+    if (live && lane < H) {
+        int cph = d / 8;
+        float s = 0.f;
+        for (int i = 0; i < cph; ++i) s += part[w][lane * cph + i];
+        long b = row / N, n = row - b * N;
+        delta[(b * H + lane) * N + n] = s;
+    }
+}
+
+// =============================================================================================
+// backward, part 1: dQ (query-stationary)
+// =============================================================================================
+template <int KS, int VT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    using G = TileGeom<KS>;
+    constexpr int KSTRIDE = G::RSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                       // [64][KSTRIDE]   rows + transposed reads
+    char* sV = sK + 64 * KSTRIDE;          // [64][KSTRIDE]   row reads
+    float* sBias = (float*)(sV + 64 * KSTRIDE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
+    const int q = blockIdx.x * 128 + wave * 32 + c;
+    const int d = p.d;
+    const float cs = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int ch = 2 * s + h;
+        uint4 v = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+        if (q < p.N && ch * 8 < d) {
+            v = *(const uint4*)(p.q + ((size_t)b * p.N + q) * p.ldq + head * d + ch * 8);
+            g = *(const uint4*)(p.dout + ((size_t)b * p.N + q) * p.lddo + head * d + ch * 8);
+        }
+        qf[s] = __builtin_bit_cast(bf16x8, v);
+        dof[s] = __builtin_bit_cast(bf16x8, g);
+    }
+    float lse2 = 0.f, dl = 0.f;
+    if (q < p.N) {
+        lse2 = p.lse[((size_t)b * p.H + head) * p.N + q] * 1.4426950408889634f;
+        dl = p.delta[((size_t)b * p.H + head) * p.N + q];
+    }
+    f32x16 dQ[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQ[vt][r] = 0.f;
+
+    const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
+    const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
+    const int ntiles = (p.M + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * 64;
+        const int nvalid = min(64, p.M - key0);
+        stage_tile(sK, KSTRIDE, G::NCH, kb + (size_t)key0 * p.ldk, p.ldk, 64, nvalid, d, tid);
+        stage_tile(sV, KSTRIDE, G::NCH, vb + (size_t)key0 * p.ldv, p.ldv, 64, nvalid, d, tid);
+        if (tid < 64) {
+            int key = key0 + tid;
+            float bias = 0.f;
+            if (key >= p.M) bias = -INFINITY;
+            else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
+            sBias[tid] = bias;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 S, dP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S, 0, 0, 0);
+                bf16x8 vf = *(const bf16x8*)(sV + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dP, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
+                float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pv = exp2f(S[4 * g + e] * cs + bb[e] - lse2);
+                    S[4 * g + e] = pv * (dP[4 * g + e] - dl);      // dS^T
+                }
+            }
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                bf16x8 dsf = acc_to_frag(S, sh);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) {
+                    bf16x8 ktr = lds_tr_frag(sK, KSTRIDE, 32 * t + 16 * sh, 32 * vt, lane);
+                    dQ[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktr, dsf, dQ[vt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q < p.N) {
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int d0 = 32 * vt + 8 * g + 4 * h;
+                if (d0 < d) {
+                    float o0 = dQ[vt][4 * g] * p.scale, o1 = dQ[vt][4 * g + 1] * p.scale;
+                    float o2 = dQ[vt][4 * g + 2] * p.scale, o3 = dQ[vt][4 * g + 3] * p.scale;
+                    size_t off = ((size_t)b * p.N + q) * p.lddq + head * d + d0;
+                    if (p.dq32) *(float4*)(p.dq32 + off) = make_float4(o0, o1, o2, o3);
+                    if (p.dq16) {
+                        uint2 w;
+                        w.x = pack_bf16x2(o0, o1);
+                        w.y = pack_bf16x2(o2, o3);
+                        *(uint2*)(p.dq16 + off) = w;
+                    }
+                }
+            }
+    }
+}
+
+// =============================================================================================
+// backward, part 2: dK, dV (key-stationary: a wave owns 32 keys, the workgroup 128 keys)
+// =============================================================================================
+template <int KS, int VT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+    using G = TileGeom<KS>;
+    constexpr int QSTRIDE = G::RSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;                        // [64][QSTRIDE]
+    char* sDO = sQ + 64 * QSTRIDE;          // [64][QSTRIDE]
+    float* sLse = (float*)(sDO + 64 * QSTRIDE);   // [64] (log2 domain)
+    float* sDl = sLse + 64;                       // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
+    const int key = blockIdx.x * 128 + wave * 32 + c;
+    const int d = p.d;
+    const float cs = p.scale * 1.4426950408889634f;
+
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        int ch = 2 * s + h;
+        uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+        if (key < p.M && ch * 8 < d) {
+            a = *(const uint4*)(p.k + ((size_t)b * p.M + key) * p.ldk + head * d + ch * 8);
+            g = *(const uint4*)(p.v + ((size_t)b * p.M + key) * p.ldv + head * d + ch * 8);
+        }
+        kf[s] = __builtin_bit_cast(bf16x8, a);
+        vf[s] = __builtin_bit_cast(bf16x8, g);
+    }
+    float bias = 0.f;
+    if (key >= p.M) bias = -INFINITY;
+    else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
+
+    f32x16 dK[VT], dV[VT];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dK[vt][r] = 0.f; dV[vt][r] = 0.f; }
+
+    const uint16_t* qb = p.q + (size_t)b * p.N * p.ldq + head * d;
+    const uint16_t* dob = p.dout + (size_t)b * p.N * p.lddo + head * d;
+    const float* lseb = p.lse + ((size_t)b * p.H + head) * p.N;
+    const float* dlb = p.delta + ((size_t)b * p.H + head) * p.N;
+    const int ntiles = (p.N + 63) / 64;
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int q0 = qt * 64;
+        const int nvalid = min(64, p.N - q0);
+        stage_tile(sQ, QSTRIDE, G::NCH, qb + (size_t)q0 * p.ldq, p.ldq, 64, nvalid, d, tid);
+        stage_tile(sDO, QSTRIDE, G::NCH, dob + (size_t)q0 * p.lddo, p.lddo, 64, nvalid, d, tid);
+        if (tid < 64) {
+            bool ok = tid < nvalid;
+            sLse[tid] = ok ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
+            sDl[tid] = ok ? dlb[q0 + tid] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            f32x16 S, dP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 qrow = *(const bf16x8*)(sQ + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow, kf[s], S, 0, 0, 0);
+                bf16x8 drow = *(const bf16x8*)(sDO + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP, 0, 0, 0);
+            }
+            // rows of S / dP are queries 32qi + 8g + 4h + e, the column (lane) is this wave's key
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
+                float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
+                float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pv = exp2f(S[4 * g + e] * cs + bias - ll[e]);
+                    S[4 * g + e] = pv;                                   // P
+                    dP[4 * g + e] = pv * (dP[4 * g + e] - dd[e]);        // dS
+                }
+            }
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                bf16x8 pf = acc_to_frag(S, sh);
+                bf16x8 dsf = acc_to_frag(dP, sh);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) {
+                    bf16x8 dotr = lds_tr_frag(sDO, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
+                    dV[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotr, pf, dV[vt], 0, 0, 0);
+                    bf16x8 qtr = lds_tr_frag(sQ, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
+                    dK[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr, dsf, dK[vt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (key < p.M) {
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int d0 = 32 * vt + 8 * g + 4 * h;
+                if (d0 < d) {
+                    size_t offk = ((size_t)b * p.M + key) * p.lddk + head * d + d0;
+                    size_t offv = ((size_t)b * p.M + key) * p.lddv + head * d + d0;
+                    float k0 = dK[vt][4 * g] * p.scale, k1 = dK[vt][4 * g + 1] * p.scale;
+                    float k2 = dK[vt][4 * g + 2] * p.scale, k3 = dK[vt][4 * g + 3] * p.scale;
+                    if (p.dk32) *(float4*)(p.dk32 + offk) = make_float4(k0, k1, k2, k3);
+                    if (p.dk16) {
+                        uint2 w;
+                        w.x = pack_bf16x2(k0, k1);
+                        w.y = pack_bf16x2(k2, k3);
+                        *(uint2*)(p.dk16 + offk) = w;
+                    }
+                    if (p.dv32)
+                        *(float4*)(p.dv32 + offv) =
+                            make_float4(dV[vt][4 * g], dV[vt][4 * g + 1], dV[vt][4 * g + 2], dV[vt][4 * g + 3]);
+                    if (p.dv16) {
+                        uint2 w;
+                        w.x = pack_bf16x2(dV[vt][4 * g], dV[vt][4 * g + 1]);
+                        w.y = pack_bf16x2(dV[vt][4 * g + 2], dV[vt][4 * g + 3]);
+                        *(uint2*)(p.dv16 + offv) = w;
+                    }
+                }
+            }
+    }
+}
+
+// =============================================================================================
+// host dispatch
+// =============================================================================================
+template <int KS, int VT>
+static int launch_fwd(const AttnParams& p, hipStream_t s) {
+    size_t lds = 64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE + 64 * 4;
+    dim3 grid((p.N + 127) / 128, p.B * p.H);
+    hipLaunchKernelGGL((attn_fwd_kernel<KS, VT>), grid, dim3(256), lds, s, p);
+    return adap_check_launch("attn_fwd");
+}
+
+template <int KS, int VT>
+static int launch_bwd(const AttnParams& p, hipStream_t s) {
+    size_t lds1 = 2 * 64 * TileGeom<KS>::RSTRIDE + 64 * 4;
+    dim3 g1((p.N + 127) / 128, p.B * p.H);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT>), g1, dim3(256), lds1, s, p);
+    size_t lds2 = 2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4;
+    dim3 g2((p.M + 127) / 128, p.B * p.H);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT>), g2, dim3(256), lds2, s, p);
+    return adap_check_launch("attn_bwd");
+}
+
+#define ATTN_DISPATCH(FN, p, s)                                                  \
+    do {                                                                         \
+        int d_ = (p).d;                                                          \
+        if (d_ <= 16) return FN<1, 1>(p, s);                                     \
+        if (d_ <= 32) return FN<2, 1>(p, s);                                     \
+        if (d_ <= 48) return FN<3, 2>(p, s);                                     \
+        if (d_ <= 64) return FN<4, 2>(p, s);                                     \
+        if (d_ <= 80) return FN<5, 3>(p, s);                                     \
+        if (d_ <= 96) return FN<6, 3>(p, s);                                     \
+        if (d_ <= 128) return FN<8, 4>(p, s);                                    \
+        if (d_ <= 160) return FN<10, 5>(p, s);                                   \
+        return adap_set_error(ADAP_ERR_UNSUPPORTED, "attention: dim_head %d > 160", d_); \
+    } while (0)
+
+static int attn_common_checks(const char* who, int B, int H, int N, int M, int d, long ldq, long ldk, long ldv) {
+    ADAP_REQUIRE(B > 0 && H > 0 && N > 0 && M > 0, ADAP_ERR_SHAPE, "%s: empty problem", who);
+    ADAP_REQUIRE(d % 8 == 0 && d >= 8 && d <= 160, ADAP_ERR_UNSUPPORTED, "%s: dim_head %d (need multiple of 8, <= 160)", who, d);
+    ADAP_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0, ADAP_ERR_ALIGN, "%s: leading dims must be multiples of 8", who);
+    ADAP_REQUIRE(ldq >= H * d && ldk >= H * d && ldv >= H * d, ADAP_ERR_SHAPE, "%s: leading dims < H*d", who);
+    return ADAP_OK;
+}
+
+extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                  const uint8_t* key_mask, void* out, long ldo, float* lse,
+                                  int B, int H, int N, int M, int d, float scale, void* stream) {
+    ADAP_REQUIRE(q && k && v && out, ADAP_ERR_SHAPE, "attention_fwd: null pointer");
+    int rc = attn_common_checks("attention_fwd", B, H, N, M, d, ldq, ldk, ldv);
+    if (rc) return rc;
+    ADAP_REQUIRE(ldo % 4 == 0 && ldo >= H * d, ADAP_ERR_ALIGN, "attention_fwd: ldo");
+    AttnParams p = {};
+    p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
+    p.kmask = key_mask; p.o = (uint16_t*)out; p.ldo = ldo; p.lse = lse;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    ATTN_DISPATCH(launch_fwd, p, (hipStream_t)stream);
+}
+
+extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                  const uint8_t* key_mask, const void* out, long ldo, const void* dout, long lddo,
+                                  const float* lse, float* delta_ws,
+                                  float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
+                                  float* dv32, void* dv16, long lddv,
+                                  int B, int H, int N, int M, int d, float scale, void* stream) {
+    ADAP_REQUIRE(q && k && v && out && dout && lse && delta_ws, ADAP_ERR_SHAPE, "attention_bwd: null pointer");
+    ADAP_REQUIRE((dq32 || dq16) && (dk32 || dk16) && (dv32 || dv16), ADAP_ERR_SHAPE, "attention_bwd: missing output");
+    int rc = attn_common_checks("attention_bwd", B, H, N, M, d, ldq, ldk, ldv);
+    if (rc) return rc;
+    ADAP_REQUIRE(ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, ADAP_ERR_ALIGN,
+                 "attention_bwd: leading dims");
+    ADAP_REQUIRE(H * d / 8 <= 160 && H <= 64, ADAP_ERR_UNSUPPORTED, "attention_bwd: H*d too large");
+    hipStream_t s = (hipStream_t)stream;
+    long rows = (long)B * N;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const uint16_t*)out, ldo,
+                       (const uint16_t*)dout, lddo, delta_ws, B, H, N, d);
+    AttnParams p = {};
+    p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
+    p.kmask = key_mask; p.lse = (float*)lse; p.dout = (const uint16_t*)dout; p.lddo = lddo; p.delta = delta_ws;
+    p.dq32 = dq32; p.dq16 = (uint16_t*)dq16; p.lddq = lddq;
+    p.dk32 = dk32; p.dk16 = (uint16_t*)dk16; p.lddk = lddk;
+    p.dv32 = dv32; p.dv16 = (uint16_t*)dv16; p.lddv = lddv;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    ATTN_DISPATCH(launch_bwd, p, s);
+}
+
+// =============================================================================================
+// Cross-attention side outputs for the distillation layers (attention.py:245-255): the pre-softmax
+// scores (already scaled by dim_head^-0.5), the probabilities, and q * dim_head^-0.25.  Only the
+// 12 cross-attention layers {7,8,12,16..24} with M <= 160 text tokens ask for them
+// (openaimodel.py:947-952), so this is a small direct kernel: one wave per query row, lanes over
+// keys, K^T of the (batch, head) in LDS.
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __restrict__ q, long ldq,
+                                                           const uint16_t* __restrict__ k, long ldk,
+                                                           float* __restrict__ score, float* __restrict__ prob,
+                                                           float* __restrict__ qout, int B, int H, int N, int M, int d,
+                                                           float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sKT = (float*)smem;            // [d][Mp]  (Mp = M rounded up to 64, +1 pad)
+    const int Mp = ((M + 63) / 64) * 64 + 1;
+    float* sQ = sKT + d * Mp;             // [4][d]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    for (int idx = tid; idx < M * d; idx += 256) {
+        int key = idx / d, dd = idx - key * d;
+        sKT[dd * Mp + key] = bf16_to_f32(k[((size_t)b * M + key) * ldk + head * d + dd]);
+    }
+    __syncthreads();
+    const float qs = sqrtf(scale);
+    const int rows_per_block = 64;
+    for (int rr = w; rr < rows_per_block; rr += 4) {
+        const int n = blockIdx.x * rows_per_block + rr;
+        if (n >= N) break;            // uniform per wave
+        for (int dd = lane; dd < d; dd += 64) {
+            float qv = bf16_to_f32(q[((size_t)b * N + n) * ldq + head * d + dd]);
+            sQ[w * d + dd] = qv;
+            if (qout) qout[(((size_t)b * H + head) * N + n) * d + dd] = qv * qs;
+        }
+        __builtin_amdgcn_s_waitcnt(0);    // LDS writes of this wave visible to itself (single wave uses sQ[w])
+        __builtin_amdgcn_wave_barrier();
+        float sv[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            int key = lane + 64 * kk;
+            float acc = -INFINITY;
+            if (key < M) {
+                acc = 0.f;
+                for (int dd = 0; dd < d; ++dd) acc += sQ[w * d + dd] * sKT[dd * Mp + key];
+                acc *= scale;
+            }
+            sv[kk] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) sum += (lane + 64 * kk < M) ? __expf(sv[kk] - mx) : 0.f;
+        sum = wave_sum(sum);
+        const size_t base = (((size_t)b * H + head) * N + n) * M;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            int key = lane + 64 * kk;
+            if (key < M) {
+                if (score) score[base + key] = sv[kk];
+                if (prob) prob[base + key] = __expf(sv[kk] - mx) / sum;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
+                                      float* q_scaled, int B, int H, int N, int M, int d, float scale, void* stream) {
+    ADAP_REQUIRE(q && k && (attnscore || attn || q_scaled), ADAP_ERR_SHAPE, "attention_capture: null pointer");
+    ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture: M=%d (cross-attention only, <= 192)", M);
+    ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture: d=%d", d);
+    int Mp = ((M + 63) / 64) * 64 + 1;
+    size_t lds = ((size_t)d * Mp + 4 * d) * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)attn_capture_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    dim3 grid((N + 63) / 64, B * H);
+    hipLaunchKernelGGL(attn_capture_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)q, ldq,
+                       (const uint16_t*)k, ldk, attnscore, attn, q_scaled, B, H, N, M, d, scale);
+    return adap_check_launch("attention_capture");
+}

@@ -1,0 +1,381 @@
+// Implicit-GEMM convolution / linear layer on the CDNA4 matrix cores (gfx950).
+//
+// One kernel family serves every contraction of the SD-1.5 hot path: Linear and 1x1 conv
+// (taps = 1), the ResBlock / VAE 3x3 convs (taps = 9: nine shifted 1x1 contractions over the
+// same pixel tile, zero padding by predicate), stride-2 downsamples (symmetric pad 1 for the
+// UNet, openaimodel.py:138-164; pad (0,1,0,1) for the VAE, model.py:73-77), the nearest-2x
+// upsample fused into the gather (openaimodel.py:95-123), and the data-gradient of each of
+// them (same kernel, transposed/flipped weight pack; zero-insert gather for stride 2).
+//
+// Layout: activations are pixel-major ("NHWC"): x[(b*H + y)*W + x][c], c contiguous, either
+// bf16 or f32 (converted to bf16 on the way into LDS).  Weights are pre-packed bf16
+// [tap][Cout][Cin] (Cin contiguous), so both MFMA operands are K-contiguous.
+//
+// Tile: 128 pixels x BN output channels x 64 input channels per step, 256 threads = 4 waves in
+// a 2 (pixel halves) x 2 (channel halves) arrangement, v_mfma_f32_16x16x32_bf16 with the
+// WEIGHTS as the A operand and the PIXELS as the B operand: an accumulator register quad then
+// holds 4 consecutive output channels of one pixel, i.e. one 16-byte store into the pixel-major
+// output.  LDS tiles are [row][64 bf16] with 128-byte rows, 16-byte chunk index XOR (row & 7)
+// so that ds_read_b128 fragment reads are bank-conflict free (guide T2), register-staged
+// double buffering with one barrier per K-step (guide T14).
+//
+// Epilogue (fused): * alpha, + bias[c], + chan_add[b][c] (the ResBlock time-embedding add,
+// openaimodel.py:271-277), + residual[pixel][c] (skip / transformer residual), written as f32
+// and/or bf16.  Split-K (grid.z) accumulates with f32 atomics into a pre-zeroed f32 output.
+#include "common.h"
+
+struct ConvParams {
+    const void* x;          // activations (bf16 or f32), pixel-major
+    long ldx;               // elements between consecutive pixels
+    const uint16_t* w;      // packed bf16 [taps][Cout][Cin]
+    const float* bias;      // [Cout] or null
+    const float* chan_add;  // [B][ld_ca] or null
+    long ld_ca;
+    const float* residual;  // f32 [M][ldr] or null
+    long ldr;
+    float* y32;             // f32 out or null
+    long ldy32;
+    uint16_t* y16;          // bf16 out or null
+    long ldy16;
+    int B, Hin, Win, Cin, Hout, Wout, Cout;
+    int KH, KW, stride, pad, up;   // up: 0 none, 1 nearest x2, 2 zero-insert x2
+    int ktiles_per_tap;            // ceil(Cin / 64)
+    int ktiles_total;              // taps * ktiles_per_tap
+    int ksplit;                    // grid.z
+    int ntiles_n;                  // ceil(Cout / BN)
+    int ntiles_m;                  // ceil(M / 128)
+    float alpha;
+    long batch_stride_x;    // batched mode (B2 > 1 via grid.y): element strides per batch item
+    long batch_stride_w;
+    long batch_stride_y32;
+    long batch_stride_y16;
+};
+
+#define BM 128
+#define BK 64
+
+template <int BN, bool A_F32>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
+    constexpr int WN = BN / 2;        // output channels per wave
+    constexpr int MT = WN / 16;       // weight (A-operand) tiles per wave
+    constexpr int PT = 4;             // pixel (B-operand) tiles per wave: 64 pixels
+    constexpr int BROWS = BN / 32;    // weight rows staged per thread
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                          // pixels  [2][128][128 B]
+    char* sB = smem + 2 * BM * 128;           // weights [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int nwg = p.ntiles_m * p.ntiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tn = bid % p.ntiles_n;
+    const int tm = bid / p.ntiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int HWo = p.Hout * p.Wout;
+    const int M = p.B * HWo;
+
+    const int bz = blockIdx.y;   // batched-GEMM index (VAE attention); 0 otherwise
+    const char* xbase = (const char*)p.x + (size_t)bz * p.batch_stride_x * (A_F32 ? 4 : 2);
+    const uint16_t* wbase = p.w + (size_t)bz * p.batch_stride_w;
+
+    // split-K range
+    int kt_begin = 0, kt_end = p.ktiles_total;
+    if (p.ksplit > 1) {
+        int per = (p.ktiles_total + p.ksplit - 1) / p.ksplit;
+        kt_begin = blockIdx.z * per;
+        kt_end = min(p.ktiles_total, kt_begin + per);
+        if (kt_begin >= kt_end) return;
+    }
+
+    // ---- per-thread staging geometry -------------------------------------------------------
+    const int chunk = tid & 7;      // 16-byte chunk (8 channels) within the 64-channel K-step
+    const int srow = tid >> 3;      // 0..31
+    int a_iy0[4], a_ix0[4], a_boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + srow + 32 * i;
+        if (m < M) {
+            int b = m / HWo, r = m - b * HWo;
+            int oy = r / p.Wout, ox = r - oy * p.Wout;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_boff[i] = b * p.Hin * p.Win;
+        } else {
+            a_iy0[i] = -(1 << 28);   // never valid
+            a_ix0[i] = 0;
+            a_boff[i] = 0;
+        }
+    }
+    const int Heff = p.up ? 2 * p.Hin : p.Hin;
+    const int Weff = p.up ? 2 * p.Win : p.Win;
+
+    uint4 ra[4], rb[BROWS];
+
+    auto load_tile = [&](int kt) {
+        int tap = kt / p.ktiles_per_tap;
+        int c = (kt - tap * p.ktiles_per_tap) * BK + chunk * 8;
+        int ky = tap / p.KW, kx = tap - ky * p.KW;
+        bool cok = c < p.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            bool ok = cok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;
+            if (p.up == 2) ok = ok && !((iy | ix) & 1);
+            if (p.up) { iy >>= 1; ix >>= 1; }
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                size_t off = (size_t)(a_boff[i] + iy * p.Win + ix) * p.ldx + c;
+                if (A_F32) {
+                    const float4* src = (const float4*)(xbase + off * 4);
+                    float4 f0 = src[0], f1 = src[1];
+                    v.x = pack_bf16x2(f0.x, f0.y);
+                    v.y = pack_bf16x2(f0.z, f0.w);
+                    v.z = pack_bf16x2(f1.x, f1.y);
+                    v.w = pack_bf16x2(f1.z, f1.w);
+                } else {
+                    v = *(const uint4*)(xbase + off * 2);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int n = n0 + srow + 32 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cok && n < p.Cout)
+                v = *(const uint4*)(wbase + ((size_t)tap * p.Cout + n) * p.Cin + c);
+            rb[i] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        char* a = sA + buf * (BM * 128);
+        char* b = sB + buf * (BN * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = srow + 32 * i;
+            *(uint4*)(a + r * 128 + ((chunk ^ (r & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int r = srow + 32 * i;
+            *(uint4*)(b + r * 128 + ((chunk ^ (r & 7)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[MT][PT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+
+    load_tile(kt_begin);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1 < kt_end);
+        if (more) load_tile(kt + 1);
+        const char* a = sA + cur * (BM * 128);
+        const char* b = sB + cur * (BN * 128);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fw[MT], fx[PT];
+            const int cc = 4 * s + fchunk;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int r = wn * WN + i * 16 + frow;
+                fw[i] = *(const bf16x8*)(b + r * 128 + ((cc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                int r = wm * 64 + j * 16 + frow;
+                fx[j] = *(const bf16x8*)(a + r * 128 + ((cc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    // acc[i][j][r] = C[cout = n0 + wn*WN + i*16 + (lane>>4)*4 + r][pixel = m0 + wm*64 + j*16 + (lane&15)]
+    const bool lead = (p.ksplit <= 1) || (blockIdx.z == 0);
+    float* y32 = p.y32 ? p.y32 + (size_t)bz * p.batch_stride_y32 : nullptr;
+    uint16_t* y16 = p.y16 ? p.y16 + (size_t)bz * p.batch_stride_y16 : nullptr;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        if (m >= M) continue;
+        const int b = m / HWo;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
+            if (c0 >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (lead) {
+                if (p.bias) {
+                    float4 t = *(const float4*)(p.bias + c0);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                }
+                if (p.chan_add) {
+                    float4 t = *(const float4*)(p.chan_add + (size_t)b * p.ld_ca + c0);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                }
+                if (p.residual) {
+                    float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                }
+            }
+            if (p.ksplit > 1) {
+                float* dst = y32 + (size_t)m * p.ldy32 + c0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + r, v[r]);
+            } else {
+                if (y32) *(float4*)(y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                if (y16) {
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2*)(y16 + (size_t)m * p.ldy16 + c0) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int BN, bool A_F32>
+static int launch(const ConvParams& p, int nbatch, hipStream_t stream) {
+    size_t lds = 2 * BM * 128 + 2 * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_gemm_kernel<BN, A_F32>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(p.ntiles_m * p.ntiles_n, nbatch, p.ksplit);
+    hipLaunchKernelGGL((conv_gemm_kernel<BN, A_F32>), grid, dim3(256), lds, stream, p);
+    return adap_check_launch("conv_gemm");
+}
+
+extern "C" int adap_conv2d_nhwc(
+    const void* x, int x_dtype, long ldx,
+    const void* w_packed,
+    const float* bias, const float* chan_add, long ld_ca,
+    const float* residual, long ldr,
+    float* y32, long ldy32, void* y16, long ldy16,
+    int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+    int KH, int KW, int stride, int pad, int up,
+    float alpha, int ksplit,
+    int nbatch, long bs_x, long bs_w, long bs_y32, long bs_y16,
+    void* stream) {
+    ADAP_REQUIRE(x && w_packed && (y32 || y16), ADAP_ERR_SHAPE, "conv2d: null pointer");
+    ADAP_REQUIRE(x_dtype == 0 || x_dtype == 1, ADAP_ERR_UNSUPPORTED, "conv2d: x_dtype %d", x_dtype);
+    ADAP_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cin > 0 && Cout > 0,
+                 ADAP_ERR_SHAPE, "conv2d: non-positive dims");
+    ADAP_REQUIRE(Cin % 8 == 0, ADAP_ERR_ALIGN, "conv2d: Cin=%d must be a multiple of 8", Cin);
+    ADAP_REQUIRE(Cout % 4 == 0, ADAP_ERR_ALIGN, "conv2d: Cout=%d must be a multiple of 4", Cout);
+    ADAP_REQUIRE(ldx % 8 == 0 && ldx >= Cin, ADAP_ERR_ALIGN, "conv2d: ldx=%ld (Cin=%d)", ldx, Cin);
+    ADAP_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0, ADAP_ERR_ALIGN,
+                 "conv2d: x / w must be 16-byte aligned");
+    ADAP_REQUIRE(!y32 || (ldy32 % 4 == 0 && ldy32 >= Cout && ((uintptr_t)y32 % 16) == 0),
+                 ADAP_ERR_ALIGN, "conv2d: y32 alignment");
+    ADAP_REQUIRE(!y16 || (ldy16 % 4 == 0 && ldy16 >= Cout && ((uintptr_t)y16 % 8) == 0),
+                 ADAP_ERR_ALIGN, "conv2d: y16 alignment");
+    ADAP_REQUIRE(!chan_add || (ld_ca % 4 == 0 && ((uintptr_t)chan_add % 16) == 0), ADAP_ERR_ALIGN,
+                 "conv2d: chan_add alignment");
+    ADAP_REQUIRE(!bias || ((uintptr_t)bias % 16) == 0, ADAP_ERR_ALIGN, "conv2d: bias alignment");
+    ADAP_REQUIRE(!residual || (ldr % 4 == 0 && ((uintptr_t)residual % 16) == 0), ADAP_ERR_ALIGN,
+                 "conv2d: residual alignment");
+    ADAP_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3), ADAP_ERR_UNSUPPORTED,
+                 "conv2d: kernel %dx%d", KH, KW);
+    ADAP_REQUIRE(stride == 1 || stride == 2, ADAP_ERR_UNSUPPORTED, "conv2d: stride %d", stride);
+    ADAP_REQUIRE(up >= 0 && up <= 2, ADAP_ERR_UNSUPPORTED, "conv2d: up %d", up);
+    ADAP_REQUIRE(ksplit >= 1 && (ksplit == 1 || (y32 && !y16)), ADAP_ERR_UNSUPPORTED,
+                 "conv2d: split-K needs an f32-only output");
+    ADAP_REQUIRE(nbatch >= 1, ADAP_ERR_SHAPE, "conv2d: nbatch");
+    long M = (long)B * Hout * Wout;
+    ADAP_REQUIRE(M < (1L << 31) && (long)B * Hin * Win < (1L << 31), ADAP_ERR_SHAPE, "conv2d: too many pixels");
+
+    ConvParams p;
+    p.x = x; p.ldx = ldx; p.w = (const uint16_t*)w_packed; p.bias = bias; p.chan_add = chan_add; p.ld_ca = ld_ca;
+    p.residual = residual; p.ldr = ldr; p.y32 = y32; p.ldy32 = ldy32; p.y16 = (uint16_t*)y16; p.ldy16 = ldy16;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout; p.Cout = Cout;
+    p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.up = up;
+    p.ktiles_per_tap = (Cin + BK - 1) / BK;
+    p.ktiles_total = KH * KW * p.ktiles_per_tap;
+    p.ksplit = ksplit < p.ktiles_total ? ksplit : p.ktiles_total;
+    p.ntiles_m = (int)((M + BM - 1) / BM);
+    p.alpha = alpha;
+    p.batch_stride_x = bs_x; p.batch_stride_w = bs_w; p.batch_stride_y32 = bs_y32; p.batch_stride_y16 = bs_y16;
+    hipStream_t s = (hipStream_t)stream;
+
+    // channel-tile choice: 160 divides 320/640/960/1280/...; 128 for the VAE's powers of two; 64 for tiny Cout.
+    int bn;
+    if (Cout <= 64) bn = 64;
+    else if (Cout % 160 == 0) bn = 160;
+    else bn = 128;
+    p.ntiles_n = (Cout + bn - 1) / bn;
+    if (x_dtype == 0) {
+        if (bn == 160) return launch<160, true>(p, nbatch, s);
+        if (bn == 128) return launch<128, true>(p, nbatch, s);
+        return launch<64, true>(p, nbatch, s);
+    } else {
+        if (bn == 160) return launch<160, false>(p, nbatch, s);
+        if (bn == 128) return launch<128, false>(p, nbatch, s);
+        return launch<64, false>(p, nbatch, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing: OIHW f32 (the checkpoint layout) -> bf16 [tap][Cout'][Cin'].
+//   mode 0: forward     out[t][o][i]      = w[o][i][ky][kx],  t = ky*KW + kx   (Cin padded to cin_pad with zeros)
+//   mode 1: data-grad   out[t][i][o]      = w[o][i][KH-1-ky][KW-1-kx]          (roles of Cin/Cout swapped, taps flipped)
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int O, int I,
+                                   int KH, int KW, int mode, int rows, int cols) {
+    // out is [taps][rows][cols]
+    long n = (long)KH * KW * rows * cols;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        int c = idx % cols;
+        long t2 = idx / cols;
+        int r = t2 % rows;
+        int t = t2 / rows;
+        int ky = t / KW, kx = t % KW;
+        float v = 0.f;
+        if (mode == 0) {
+            if (r < O && c < I) v = w[(((long)r * I + c) * KH + ky) * KW + kx];
+        } else {
+            if (r < I && c < O) v = w[(((long)c * I + r) * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)];
+        }
+        out[idx] = f32_to_bf16(v);
+    }
+}
+
+extern "C" int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O, int I, int KH, int KW,
+                                     int mode, int rows, int cols, void* stream) {
+    ADAP_REQUIRE(w_oihw && out_bf16, ADAP_ERR_SHAPE, "pack_weight: null pointer");
+    ADAP_REQUIRE(mode == 0 || mode == 1, ADAP_ERR_UNSUPPORTED, "pack_weight: mode %d", mode);
+    ADAP_REQUIRE(mode == 0 ? (rows >= O && cols >= I) : (rows >= I && cols >= O), ADAP_ERR_SHAPE,
+                 "pack_weight: rows/cols too small");
+    long n = (long)KH * KW * rows * cols;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                       (uint16_t*)out_bf16, O, I, KH, KW, mode, rows, cols);
+    return adap_check_launch("pack_weight");
+}

@@ -1,0 +1,438 @@
+// Small HBM-bound kernels of the SD-1.5 hot path: GEGLU, time-embedding MLP (few-row linear), sinusoidal
+// timestep embedding, q_sample, posterior sample, masked weighted MSE (+ gradient), channel concat,
+// 2x2 sum-pool (adjoint of the nearest upsample), channel pad/cast, bf16 transpose, and the
+// VAE mid-attention softmax with the post-softmax fg/bg hetero-pair zero fill.
+#include "common.h"
+
+#define GRID_CAP 4096
+static inline int grid_for(long n, int per_block) {
+    long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > GRID_CAP) g = GRID_CAP;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEGLU (attention.py:32-40): h = [a | gate] along channels; out = a * gelu(gate), exact (erf) GELU.
+// h bf16 [rows][2*I] (output of ff.net.0.proj), out bf16 [rows][I] (operand of ff.net.2).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float g) {
+    return 0.5f * (1.0f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ h, long ldh, uint16_t* __restrict__ out,
+                                                        long ldo, long rows, int I) {
+    const int ch_per_row = I / 8;
+    const long total = rows * ch_per_row;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx / ch_per_row;
+        int ch = (int)(idx - r * ch_per_row);
+        uint4 av = *(const uint4*)(h + r * ldh + ch * 8);
+        uint4 gv = *(const uint4*)(h + r * ldh + I + ch * 8);
+        float a[8], g[8], o[8];
+        unpack_bf16x8(av, a);
+        unpack_bf16x8(gv, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a[e] * gelu_f(g[e]);
+        *(uint4*)(out + r * ldo + ch * 8) = pack_bf16x8(o);
+    }
+}
+
+extern "C" int adap_geglu_fwd(const void* h, long ldh, void* out, long ldo, long rows, int inner, void* stream) {
+    ADAP_REQUIRE(h && out, ADAP_ERR_SHAPE, "geglu_fwd: null pointer");
+    ADAP_REQUIRE(inner % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0 && ldh >= 2 * inner, ADAP_ERR_ALIGN, "geglu_fwd: alignment");
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(rows * (inner / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)h, ldh, (uint16_t*)out, ldo, rows, inner);
+    return adap_check_launch("geglu_fwd");
+}
+
+// dh = [dout * gelu(g) | dout * a * gelu'(g)]   (bf16 in, bf16 out: operand of the proj data-gradient)
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restrict__ dout, long lddo,
+                                                        const uint16_t* __restrict__ h, long ldh, uint16_t* __restrict__ dh,
+                                                        long lddh, long rows, int I) {
+    const int ch_per_row = I / 8;
+    const long total = rows * ch_per_row;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx / ch_per_row;
+        int ch = (int)(idx - r * ch_per_row);
+        uint4 dv = *(const uint4*)(dout + r * lddo + ch * 8);
+        uint4 av = *(const uint4*)(h + r * ldh + ch * 8);
+        uint4 gv = *(const uint4*)(h + r * ldh + I + ch * 8);
+        float d[8], a[8], g[8], da[8], dg[8];
+        unpack_bf16x8(dv, d);
+        unpack_bf16x8(av, a);
+        unpack_bf16x8(gv, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            da[e] = d[e] * gelu_f(g[e]);
+            dg[e] = d[e] * a[e] * dgelu_f(g[e]);
+        }
+        *(uint4*)(dh + r * lddh + ch * 8) = pack_bf16x8(da);
+        *(uint4*)(dh + r * lddh + I + ch * 8) = pack_bf16x8(dg);
+    }
+}
+
+extern "C" int adap_geglu_bwd(const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, long rows,
+                              int inner, void* stream) {
+    ADAP_REQUIRE(dout && h && dh, ADAP_ERR_SHAPE, "geglu_bwd: null pointer");
+    ADAP_REQUIRE(inner % 8 == 0 && ldh % 8 == 0 && lddo % 8 == 0 && lddh % 8 == 0, ADAP_ERR_ALIGN, "geglu_bwd: alignment");
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * (inner / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, lddo, (const uint16_t*)h, ldh, (uint16_t*)dh, lddh, rows, inner);
+    return adap_check_launch("geglu_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Few-row linear in exact f32: y[r][n] = bias[n] + sum_k act(x[r][k]) * w[n][k], R <= 8 rows.
+// time_embed (openaimodel.py:518-522) and every ResBlock's emb_layers (SiLU -> Linear, :217-223);
+// the weights of all 22 emb_layers can be concatenated along n and served by one launch.
+// One wave per output column.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, long ldy,
+                                                           int R, int K, int N, int pre_silu, int post_silu) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        float4 wv = *(const float4*)(w + (size_t)n * K + k);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < R) {
+                float4 xv = *(const float4*)(x + (size_t)r * ldx + k);
+                if (pre_silu) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
+                acc[r] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < R) {
+            float s = wave_sum(acc[r]);
+            if (lane == 0) {
+                s += bias ? bias[n] : 0.f;
+                if (post_silu) s = silu_f(s);
+                y[(size_t)r * ldy + n] = s;
+            }
+        }
+    }
+}
+
+extern "C" int adap_linear_small(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                                 int R, int K, int N, int pre_silu, int post_silu, void* stream) {
+    ADAP_REQUIRE(x && w && y, ADAP_ERR_SHAPE, "linear_small: null pointer");
+    ADAP_REQUIRE(R >= 1 && R <= 8, ADAP_ERR_UNSUPPORTED, "linear_small: R=%d (1..8)", R);
+    ADAP_REQUIRE(K % 4 == 0 && ldx % 4 == 0, ADAP_ERR_ALIGN, "linear_small: K/ldx alignment");
+    hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, ldy, R, K,
+                       N, pre_silu, post_silu);
+    return adap_check_launch("linear_small");
+}
+
+// ---------------------------------------------------------------------------------------------
+// timestep_embedding (util.py:154-174): [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half)
+// ---------------------------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(const long long* __restrict__ t, float* __restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * half; idx += gridDim.x * blockDim.x) {
+        int b = idx / half, i = idx - b * half;
+        float f = expf(-9.210340371976184f * (float)i / (float)half);
+        float a = (float)t[b] * f;
+        out[(size_t)b * dim + i] = cosf(a);
+        out[(size_t)b * dim + half + i] = sinf(a);
+        if ((dim & 1) && i == 0) out[(size_t)b * dim + dim - 1] = 0.f;
+    }
+}
+
+extern "C" int adap_timestep_embedding(const long long* t, float* out, int B, int dim, void* stream) {
+    ADAP_REQUIRE(t && out && B > 0 && dim >= 2, ADAP_ERR_SHAPE, "timestep_embedding: bad args");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((long)B * (dim / 2), 256)), dim3(256), 0, (hipStream_t)stream, t,
+                       out, B, dim);
+    return adap_check_launch("timestep_embedding");
+}
+
+// ---------------------------------------------------------------------------------------------
+// q_sample (ddpm.py:416-419): out = sqrt_ac[t_b] * x0 + sqrt_1mac[t_b] * noise      (any layout, per-sample scalars)
+// ---------------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
+                                const float* __restrict__ sa, const float* __restrict__ sb, float* __restrict__ out, int B,
+                                long per) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < B * per; idx += (long)gridDim.x * blockDim.x) {
+        int b = (int)(idx / per);
+        out[idx] = sa[t[b]] * x0[idx] + sb[t[b]] * noise[idx];
+    }
+}
+
+extern "C" int adap_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
+                             const float* sqrt_1mac, float* out, int B, long per_sample, void* stream) {
+    ADAP_REQUIRE(x0 && noise && t && sqrt_ac && sqrt_1mac && out, ADAP_ERR_SHAPE, "q_sample: null pointer");
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(B * per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
+                       sqrt_ac, sqrt_1mac, out, B, per_sample);
+    return adap_check_launch("q_sample");
+}
+
+// ---------------------------------------------------------------------------------------------
+// posterior sample + scale (distributions.py:24-37, ddpm.py:955-962), pixel-major moments [P][2*Z]:
+//   z = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise)
+// ---------------------------------------------------------------------------------------------
+__global__ void posterior_sample_kernel(const float* __restrict__ moments, long ldm, const float* __restrict__ noise,
+                                        float* __restrict__ z, long P, int Z, float scale) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < P * Z; idx += (long)gridDim.x * blockDim.x) {
+        long px = idx / Z;
+        int c = (int)(idx - px * Z);
+        float mean = moments[px * ldm + c];
+        float lv = fminf(fmaxf(moments[px * ldm + Z + c], -30.f), 20.f);
+        z[idx] = scale * (mean + expf(0.5f * lv) * noise[idx]);
+    }
+}
+
+extern "C" int adap_posterior_sample(const float* moments, long ldm, const float* noise, float* z, long pixels, int zch,
+                                     float scale, void* stream) {
+    ADAP_REQUIRE(moments && noise && z, ADAP_ERR_SHAPE, "posterior_sample: null pointer");
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3(grid_for(pixels * zch, 256)), dim3(256), 0, (hipStream_t)stream, moments,
+                       ldm, noise, z, pixels, zch, scale);
+    return adap_check_launch("posterior_sample");
+}
+
+// ---------------------------------------------------------------------------------------------
+// calc_recon_loss (ddpm.py:3571-3595), pixel-major [P][C] tensors, masks [P]:
+//   pix = ((out - tgt) * im)^2 ; w = fg*im*w_fg + (1-fg)*im*w_bg
+//   loss = sum(pix * w) / (C * sum(w) + 1e-6) ;  grad = 2 (out - tgt) im^2 w / den
+// One workgroup (the tensors are [4*64*64][4]): deterministic two-phase reduce.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void masked_mse_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                          const float* __restrict__ img_mask, const float* __restrict__ fg_mask,
+                                                          float w_fg, float w_bg, long P, int C, float* __restrict__ loss,
+                                                          float* __restrict__ grad) {
+    __shared__ double snum[16], sden[16];
+    __shared__ float sinv;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double num = 0.0, den = 0.0;
+    for (long px = tid; px < P; px += 1024) {
+        float im = img_mask ? img_mask[px] : 1.f;
+        float fg = fg_mask ? fg_mask[px] : 1.f;
+        float w = fg * im * w_fg + (1.f - fg) * im * w_bg;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float d = (out[px * C + c] - tgt[px * C + c]) * im;
+            s += d * d;
+        }
+        num += (double)s * w;
+        den += (double)w * C;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        num += __shfl_xor(num, o, 64);
+        den += __shfl_xor(den, o, 64);
+    }
+    if (lane == 0) { snum[wv] = num; sden[wv] = den; }
+    __syncthreads();
+    if (tid == 0) {
+        double n = 0.0, d = 0.0;
+        for (int i = 0; i < 16; ++i) { n += snum[i]; d += sden[i]; }
+        d += 1e-6;
+        loss[0] = (float)(n / d);
+        sinv = (float)(1.0 / d);
+    }
+    __syncthreads();
+    if (grad) {
+        const float inv = sinv;
+        for (long px = tid; px < P; px += 1024) {
+            float im = img_mask ? img_mask[px] : 1.f;
+            float fg = fg_mask ? fg_mask[px] : 1.f;
+            float w = fg * im * w_fg + (1.f - fg) * im * w_bg;
+            float k = 2.f * im * im * w * inv;
+            for (int c = 0; c < C; ++c) grad[px * C + c] = k * (out[px * C + c] - tgt[px * C + c]);
+        }
+    }
+}
+
+extern "C" int adap_masked_mse(const float* out, const float* tgt, const float* img_mask, const float* fg_mask, float w_fg,
+                               float w_bg, long pixels, int C, float* loss, float* grad, void* stream) {
+    ADAP_REQUIRE(out && tgt && loss, ADAP_ERR_SHAPE, "masked_mse: null pointer");
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, out, tgt, img_mask, fg_mask, w_fg, w_bg,
+                       pixels, C, loss, grad);
+    return adap_check_launch("masked_mse");
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel concat of two pixel-major f32 tensors (torch.cat([h, hs.pop()], dim=1), openaimodel.py:1018)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, long lda, int Ca, const float* __restrict__ b,
+                                                      long ldb, int Cb, float* __restrict__ out, long ldo, long rows) {
+    const int qa = Ca / 4, qb = Cb / 4, qt = qa + qb;
+    const long total = rows * qt;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx / qt;
+        int q = (int)(idx - r * qt);
+        float4 v = (q < qa) ? *(const float4*)(a + r * lda + 4 * q) : *(const float4*)(b + r * ldb + 4 * (q - qa));
+        *(float4*)(out + r * ldo + 4 * q) = v;
+    }
+}
+
+extern "C" int adap_concat2(const float* a, long lda, int Ca, const float* b, long ldb, int Cb, float* out, long ldo,
+                            long rows, void* stream) {
+    ADAP_REQUIRE(a && b && out, ADAP_ERR_SHAPE, "concat2: null pointer");
+    ADAP_REQUIRE(Ca % 4 == 0 && Cb % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0, ADAP_ERR_ALIGN, "concat2: alignment");
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(rows * ((Ca + Cb) / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, lda, Ca,
+                       b, ldb, Cb, out, ldo, rows);
+    return adap_check_launch("concat2");
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x2 sum pool, pixel-major f32: adjoint of F.interpolate(scale_factor=2, mode='nearest')
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                       int C) {
+    const int q = C / 4;
+    const long total = (long)B * H * W * q;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int cq = (int)(idx % q);
+        long px = idx / q;
+        int x = (int)(px % W);
+        long t = px / W;
+        int y = (int)(t % H);
+        int b = (int)(t / H);
+        const float* base = in + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + 4 * cq;
+        float4 v0 = *(const float4*)(base), v1 = *(const float4*)(base + C);
+        float4 v2 = *(const float4*)(base + (size_t)2 * W * C), v3 = *(const float4*)(base + (size_t)2 * W * C + C);
+        *(float4*)(out + px * C + 4 * cq) =
+            make_float4(v0.x + v1.x + v2.x + v3.x, v0.y + v1.y + v2.y + v3.y, v0.z + v1.z + v2.z + v3.z, v0.w + v1.w + v2.w + v3.w);
+    }
+}
+
+extern "C" int adap_sumpool2x2(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    ADAP_REQUIRE(in && out && C % 4 == 0, ADAP_ERR_SHAPE, "sumpool2x2: bad args");
+    hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for((long)B * H * W * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       B, H, W, C);
+    return adap_check_launch("sumpool2x2");
+}
+
+// ---------------------------------------------------------------------------------------------
+// f32 [rows][Cin] -> bf16 [rows][Cout>=Cin] with zero padding (image 3->8, latent 4->8 channels) / plain cast
+// ---------------------------------------------------------------------------------------------
+__global__ void pad_cast_kernel(const float* __restrict__ in, long ldi, int Cin, uint16_t* __restrict__ out, long ldo, int Cout,
+                                long rows) {
+    const long total = rows * Cout;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx / Cout;
+        int c = (int)(idx - r * Cout);
+        out[r * ldo + c] = c < Cin ? f32_to_bf16(in[r * ldi + c]) : (uint16_t)0;
+    }
+}
+
+extern "C" int adap_pad_cast_bf16(const float* in, long ldi, int Cin, void* out, long ldo, int Cout, long rows, void* stream) {
+    ADAP_REQUIRE(in && out && Cout >= Cin, ADAP_ERR_SHAPE, "pad_cast: bad args");
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for(rows * Cout, 256)), dim3(256), 0, (hipStream_t)stream, in, ldi, Cin,
+                       (uint16_t*)out, ldo, Cout, rows);
+    return adap_check_launch("pad_cast");
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched bf16 transpose [R][C] -> [C][R] through a 64x64 LDS tile (V^T for the VAE mid attention)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R,
+                                                             int C) {
+    __shared__ uint16_t tile[64][66];
+    const size_t boff = (size_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < R && c0 + c < C) ? in[boff + (size_t)(r0 + r) * C + c0 + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int c = i >> 6, r = i & 63;
+        if (r0 + r < R && c0 + c < C) out[boff + (size_t)(c0 + c) * R + r0 + r] = tile[r][c];
+    }
+}
+
+extern "C" int adap_transpose_bf16(const void* in, void* out, int batch, int R, int C, void* stream) {
+    ADAP_REQUIRE(in && out && batch > 0 && R > 0 && C > 0, ADAP_ERR_SHAPE, "transpose: bad args");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, (uint16_t*)out, R, C);
+    return adap_check_launch("transpose_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// VAE mid AttnBlock softmax (model.py:190-232): P = softmax_j(S[i][j] * scale); when per-pixel classes
+// are given (0 = outside aug mask, 1 = fg, 2 = bg) every pair with class_i != class_j or class 0 is zeroed
+// AFTER the softmax (no renormalisation).  S f32 [rows][N] -> P bf16.  One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_softmax_kernel(const float* __restrict__ S, long lds_, uint16_t* __restrict__ P,
+                                                          long ldp, const uint8_t* __restrict__ cls, int N, int rows_per_batch,
+                                                          float scale) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int b = (int)(row / rows_per_batch);
+    const int i = (int)(row - (long)b * rows_per_batch);
+    const float* s = S + row * lds_;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mx = -INFINITY;
+    for (int j = tid * 4; j < N; j += 1024) {
+        float4 v = *(const float4*)(s + j);
+        mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid * 4; j < N; j += 1024) {
+        float4 v = *(const float4*)(s + j);
+        sum += __expf(v.x * scale - mx) + __expf(v.y * scale - mx) + __expf(v.z * scale - mx) + __expf(v.w * scale - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    const uint8_t* cb = cls ? cls + (size_t)b * N : nullptr;
+    const int ci = cb ? cb[i] : 1;
+    for (int j = tid * 4; j < N; j += 1024) {
+        float4 v = *(const float4*)(s + j);
+        float o[4] = {__expf(v.x * scale - mx) * inv, __expf(v.y * scale - mx) * inv, __expf(v.z * scale - mx) * inv,
+                      __expf(v.w * scale - mx) * inv};
+        if (cb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ci == 0 || cb[j + e] != ci) o[e] = 0.f;
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        *(uint2*)(P + row * ldp + j) = pk;
+    }
+}
+
+extern "C" int adap_vae_softmax(const float* S, long lds_, void* P, long ldp, const uint8_t* pixel_class, long rows, int N,
+                                int rows_per_batch, float scale, void* stream) {
+    ADAP_REQUIRE(S && P && N % 4 == 0 && lds_ % 4 == 0 && ldp % 4 == 0, ADAP_ERR_ALIGN, "vae_softmax: bad args");
+    ADAP_REQUIRE(scale > 0.f, ADAP_ERR_UNSUPPORTED, "vae_softmax: scale must be positive");
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(vae_softmax_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, lds_, (uint16_t*)P, ldp,
+                       pixel_class, N, rows_per_batch, scale);
+    return adap_check_launch("vae_softmax");
+}
+
+// ---------------------------------------------------------------------------------------------
+// y += x (f32), used for gradient accumulation where two branches meet
+// ---------------------------------------------------------------------------------------------
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float a, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 xv = ((const float4*)x)[i], yv = ((float4*)y)[i];
+        ((float4*)y)[i] = make_float4(yv.x + a * xv.x, yv.y + a * xv.y, yv.z + a * xv.z, yv.w + a * xv.w);
+    }
+}
+
+extern "C" int adap_axpy(const float* x, float* y, float a, long n, void* stream) {
+    ADAP_REQUIRE(x && y && n % 4 == 0, ADAP_ERR_ALIGN, "axpy: n must be a multiple of 4");
+    if (n == 0) return ADAP_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, n / 4);
+    return adap_check_launch("axpy");
+}

@@ -1,0 +1,415 @@
+"""Raw (non-autograd) Python entry points of the HIP kernels.
+
+PyTorch is plumbing here: it owns device memory and the stream; every function checks layout,
+passes raw pointers to the C ABI (include/adaprompt_hip.h) on torch's current stream and returns
+torch tensors.  Activations are pixel-major: [B, H, W, C] / [B, N, C] with the channel dim
+contiguous and an arbitrary leading dimension (stride of dim -2)."""
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _rows_ld(t):
+    """(rows, ld) of a pixel-major tensor whose leading dims are packed with respect to stride(-2)."""
+    assert t.is_cuda, "HIP kernels need device tensors (no CPU fallback)"
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, f"channel dim must be contiguous, got strides {t.stride()}"
+    if t.dim() == 1:
+        return 1, t.shape[0]
+    ld = t.stride(-2)
+    rows = t.shape[-2]
+    exp = ld * t.shape[-2]
+    for i in range(t.dim() - 3, -1, -1):
+        assert t.shape[i] == 1 or t.stride(i) == exp, f"leading dims not packed: shape {tuple(t.shape)} strides {t.stride()}"
+        exp *= t.shape[i]
+        rows *= t.shape[i]
+    return rows, ld
+
+
+def _dt(t):
+    if t.dtype == F32:
+        return 0
+    if t.dtype == BF16:
+        return 1
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+# --------------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------------
+
+def _ceil(a, m):
+    return (a + m - 1) // m * m
+
+
+class PackedConv:
+    """bf16 weight packs of one nn.Conv2d / nn.Linear: forward [taps][O][I8] and (lazily) the
+    data-gradient pack [taps][I4..][O8] (taps flipped, roles swapped).  I is zero-padded to a
+    multiple of 8 (image 3->8, latent 4->8 channels)."""
+
+    def __init__(self, weight, bias=None):
+        w = weight.detach()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        assert w.dim() == 4 and w.is_cuda
+        self.w_f32 = w.contiguous().float()
+        self.O, self.I, self.KH, self.KW = self.w_f32.shape
+        self.I8 = _ceil(self.I, 8)
+        self.O4 = _ceil(self.O, 4)
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        if self.bias is not None and self.O4 != self.O:
+            b = torch.zeros(self.O4, device=w.device, dtype=F32)
+            b[: self.O] = self.bias
+            self.bias = b
+        self.fwd = torch.empty(self.KH * self.KW, self.O4, self.I8, device=w.device, dtype=BF16)
+        _lib.call("adap_pack_conv_weight", self.w_f32.data_ptr(), self.fwd.data_ptr(), self.O, self.I, self.KH,
+                  self.KW, 0, self.O4, self.I8, _stream())
+        self._bwd = None
+
+    @property
+    def bwd(self):
+        if self._bwd is None:
+            rows, cols = _ceil(self.I, 4), _ceil(self.O, 8)
+            self._bwd = torch.empty(self.KH * self.KW, rows, cols, device=self.fwd.device, dtype=BF16)
+            _lib.call("adap_pack_conv_weight", self.w_f32.data_ptr(), self._bwd.data_ptr(), self.O, self.I, self.KH,
+                      self.KW, 1, rows, cols, _stream())
+        return self._bwd
+
+    def drop_f32(self):
+        """free the f32 master copy once both packs exist (frozen weights)."""
+        _ = self.bwd
+        self.w_f32 = None
+
+
+def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=None, chan_add=None, residual=None,
+           out_f32=True, out_bf16=False, alpha=1.0, ksplit=1, y32=None, y16=None):
+    """x [B,H,W,Cin] (f32 / bf16) * w_packed [KH*KH][Cout][Cin] -> (y32, y16), each [B,Ho,Wo,Cout] or None.
+    Linear layers: pass x as [B, N, 1, Cin]."""
+    assert x.dim() == 4
+    B, H, W, Cin = x.shape
+    _, ldx = _rows_ld(x)
+    assert w_packed.dtype == BF16 and w_packed.is_contiguous()
+    assert w_packed.shape[0] == KH * KH and w_packed.shape[2] == Cin and w_packed.shape[1] >= Cout, \
+        f"weight pack {tuple(w_packed.shape)} vs Cin={Cin} Cout={Cout} taps={KH * KH}"
+    assert w_packed.shape[1] == Cout, "pass the padded Cout of the pack"
+    if out_hw is None:
+        He, We = (2 * H, 2 * W) if up else (H, W)
+        Ho = (He + 2 * pad - KH) // stride + 1
+        Wo = (We + 2 * pad - KH) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    dev = x.device
+    if ksplit > 1:
+        assert not out_bf16
+        if y32 is None:
+            y32 = torch.zeros(B, Ho, Wo, Cout, device=dev, dtype=F32)
+    else:
+        if out_f32 and y32 is None:
+            y32 = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=F32)
+    if out_bf16 and y16 is None:
+        y16 = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=BF16)
+    ldy32 = _rows_ld(y32)[1] if y32 is not None else 0
+    ldy16 = _rows_ld(y16)[1] if y16 is not None else 0
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == F32 and residual.shape[-1] == Cout
+        rrows, ldr = _rows_ld(residual)
+        assert rrows == B * Ho * Wo
+    ld_ca = 0
+    if chan_add is not None:
+        assert chan_add.dtype == F32 and chan_add.dim() == 2 and chan_add.shape[0] == B and chan_add.stride(1) == 1
+        ld_ca = chan_add.stride(0)
+    if bias is not None:
+        assert bias.dtype == F32 and bias.numel() >= Cout
+    _lib.call("adap_conv2d_nhwc", x.data_ptr(), _dt(x), ldx, w_packed.data_ptr(), _ptr(bias), _ptr(chan_add), ld_ca,
+              _ptr(residual), ldr, _ptr(y32), ldy32, _ptr(y16), ldy16, B, H, W, Cin, Ho, Wo, Cout, KH, KH, stride, pad,
+              up, float(alpha), ksplit, 1, 0, 0, 0, 0, _stream())
+    return y32, y16
+
+
+def linear(x, w_packed, Cout, bias=None, residual=None, out_f32=True, out_bf16=False, alpha=1.0):
+    """x [..., Cin] -> [..., Cout] through the 1x1 path."""
+    shp = x.shape
+    rows, ld = _rows_ld(x)
+    x4 = x.as_strided((1, rows, 1, shp[-1]), (rows * ld, ld, ld, 1))
+    r4 = None
+    if residual is not None:
+        rr, rl = _rows_ld(residual)
+        r4 = residual.as_strided((1, rr, 1, Cout), (rr * rl, rl, rl, 1))
+    y32, y16 = conv2d(x4, w_packed, Cout, 1, bias=bias, residual=r4, out_f32=out_f32, out_bf16=out_bf16, alpha=alpha)
+    out_shape = tuple(shp[:-1]) + (Cout,)
+    return (None if y32 is None else y32.view(out_shape)), (None if y16 is None else y16.view(out_shape))
+
+
+def batched_matmul_nt(a, b, out_dtype=F32, alpha=1.0):
+    """a [G, M, K] bf16, b [G, N, K] bf16 -> [G, M, N] (sum over K); the VAE mid attention's two bmm."""
+    G, M, K = a.shape
+    G2, N, K2 = b.shape
+    assert G == G2 and K == K2 and a.is_contiguous() and b.is_contiguous() and a.dtype == BF16 and b.dtype == BF16
+    y = torch.empty(G, M, N, device=a.device, dtype=out_dtype)
+    y32, y16 = (y, None) if out_dtype == F32 else (None, y)
+    _lib.call("adap_conv2d_nhwc", a.data_ptr(), 1, K, b.data_ptr(), 0, 0, 0, 0, 0, _ptr(y32), N, _ptr(y16), N,
+              1, M, 1, K, M, 1, N, 1, 1, 1, 0, 0, float(alpha), 1, G, M * K, N * K, M * N, M * N, _stream())
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# norms
+# --------------------------------------------------------------------------------------------
+
+def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
+    """x f32 [B, ..., C] pixel-major -> (y32, y16, mean[B,32], rstd[B,32])"""
+    assert x.dtype == F32
+    B, C = x.shape[0], x.shape[-1]
+    rows, ldx = _rows_ld(x)
+    HW = rows // B
+    ws = torch.empty(_lib.call_long("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
+    mean = torch.empty(B, 32, device=x.device, dtype=F32)
+    rstd = torch.empty(B, 32, device=x.device, dtype=F32)
+    y32 = torch.empty(x.shape, device=x.device, dtype=F32) if out_f32 else None
+    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
+    _lib.call("adap_groupnorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
+              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), B, HW, C, float(eps), int(act), _stream())
+    return y32, y16, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=False, accumulate_into=None):
+    assert x.dtype == F32
+    B, C = x.shape[0], x.shape[-1]
+    rows, ldx = _rows_ld(x)
+    _, lddy = _rows_ld(dy)
+    HW = rows // B
+    ws = torch.empty(_lib.call_long("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
+    acc = 0
+    dx32 = None
+    if accumulate_into is not None:
+        dx32, acc = accumulate_into, 1
+    elif out_f32:
+        dx32 = torch.empty(x.shape, device=x.device, dtype=F32)
+    lddx32 = _rows_ld(dx32)[1] if dx32 is not None else 0
+    dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
+    _lib.call("adap_groupnorm_bwd", dy.data_ptr(), _dt(dy), lddy, x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(),
+              mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, ws.data_ptr(), B, HW, C, int(act),
+              _stream())
+    return dx32, dx16
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    assert x.dtype == F32
+    rows, ldx = _rows_ld(x)
+    D = x.shape[-1]
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    mean = torch.empty(rows, device=x.device, dtype=F32)
+    rstd = torch.empty(rows, device=x.device, dtype=F32)
+    _lib.call("adap_layernorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), D, mean.data_ptr(),
+              rstd.data_ptr(), rows, D, float(eps), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None):
+    assert dy.dtype == F32 and x.dtype == F32
+    rows, ldx = _rows_ld(x)
+    _, lddy = _rows_ld(dy)
+    D = x.shape[-1]
+    if accumulate_into is None:
+        dx, acc = torch.empty(x.shape, device=x.device, dtype=F32), 0
+    else:
+        dx, acc = accumulate_into, 1
+    _lib.call("adap_layernorm_bwd", dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), dx.data_ptr(), _rows_ld(dx)[1], acc, rows, D, _stream())
+    return dx
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+
+def attention_fwd(q, k, v, heads, key_mask=None):
+    """q [B,N,C], k/v [B,M,C] bf16 -> out [B,N,C] bf16, lse [B,H,N] f32."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    d = C // heads
+    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16
+    out = torch.empty(B, N, C, device=q.device, dtype=BF16)
+    lse = torch.empty(B, heads, N, device=q.device, dtype=F32)
+    if key_mask is not None:
+        assert key_mask.dtype == torch.uint8 and key_mask.shape == (B, M) and key_mask.is_contiguous()
+    _lib.call("adap_attention_fwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
+              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d, float(d) ** -0.5,
+              _stream())
+    return out, lse
+
+
+def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq_bf16=True, dkv_bf16=True):
+    B, N, C = q.shape
+    M = k.shape[1]
+    d = C // heads
+    assert dout.dtype == BF16 and out.dtype == BF16
+    dev = q.device
+    delta = torch.empty(B, heads, N, device=dev, dtype=F32)
+    dq = torch.empty(B, N, C, device=dev, dtype=BF16 if dq_bf16 else F32)
+    dk = torch.empty(B, M, C, device=dev, dtype=BF16 if dkv_bf16 else F32)
+    dv = torch.empty(B, M, C, device=dev, dtype=BF16 if dkv_bf16 else F32)
+    _lib.call("adap_attention_bwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
+              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, dout.data_ptr(), _rows_ld(dout)[1], lse.data_ptr(),
+              delta.data_ptr(),
+              0 if dq_bf16 else dq.data_ptr(), dq.data_ptr() if dq_bf16 else 0, C,
+              0 if dkv_bf16 else dk.data_ptr(), dk.data_ptr() if dkv_bf16 else 0, C,
+              0 if dkv_bf16 else dv.data_ptr(), dv.data_ptr() if dkv_bf16 else 0, C,
+              B, heads, N, M, d, float(d) ** -0.5, _stream())
+    return dq, dk, dv
+
+
+def attention_capture(q, k, heads, want_q=True):
+    """side outputs of attention.py:245-255 -> (attnscore, attn, q_scaled)."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    d = C // heads
+    dev = q.device
+    score = torch.empty(B, heads, N, M, device=dev, dtype=F32)
+    prob = torch.empty(B, heads, N, M, device=dev, dtype=F32)
+    qs = torch.empty(B, heads, N, d, device=dev, dtype=F32) if want_q else None
+    _lib.call("adap_attention_capture", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], score.data_ptr(),
+              prob.data_ptr(), _ptr(qs), B, heads, N, M, d, float(d) ** -0.5, _stream())
+    return score, prob, qs
+
+
+# --------------------------------------------------------------------------------------------
+# misc
+# --------------------------------------------------------------------------------------------
+
+def geglu_fwd(h):
+    rows, ldh = _rows_ld(h)
+    inner = h.shape[-1] // 2
+    out = torch.empty(tuple(h.shape[:-1]) + (inner,), device=h.device, dtype=BF16)
+    _lib.call("adap_geglu_fwd", h.data_ptr(), ldh, out.data_ptr(), inner, rows, inner, _stream())
+    return out
+
+
+def geglu_bwd(dout, h):
+    rows, ldh = _rows_ld(h)
+    inner = h.shape[-1] // 2
+    dh = torch.empty(h.shape, device=h.device, dtype=BF16)
+    _lib.call("adap_geglu_bwd", dout.data_ptr(), _rows_ld(dout)[1], h.data_ptr(), ldh, dh.data_ptr(), 2 * inner, rows,
+              inner, _stream())
+    return dh
+
+
+def linear_small(x, w, bias=None, pre_silu=False, post_silu=False):
+    """exact f32, x [R<=8, K] -> [R, N]"""
+    R, K = x.shape
+    N = w.shape[0]
+    assert x.dtype == F32 and w.dtype == F32 and w.is_contiguous() and x.stride(1) == 1
+    y = torch.empty(R, N, device=x.device, dtype=F32)
+    _lib.call("adap_linear_small", x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), N, R, K, N,
+              int(pre_silu), int(post_silu), _stream())
+    return y
+
+
+def timestep_embedding(t, dim):
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=F32)
+    _lib.call("adap_timestep_embedding", t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream())
+    return out
+
+
+def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
+    x0, noise = x0.contiguous(), noise.contiguous()
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    _lib.call("adap_q_sample", x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+              out.data_ptr(), B, x0.numel() // B, _stream())
+    return out
+
+
+def posterior_sample(moments, noise, scale):
+    """moments [..., 2Z] pixel-major f32, noise [..., Z] -> z [..., Z]"""
+    rows, ldm = _rows_ld(moments)
+    Z = moments.shape[-1] // 2
+    noise = noise.contiguous()
+    z = torch.empty_like(noise)
+    _lib.call("adap_posterior_sample", moments.data_ptr(), ldm, noise.data_ptr(), z.data_ptr(), rows, Z, float(scale),
+              _stream())
+    return z
+
+
+def masked_mse(out, tgt, img_mask, fg_mask, w_fg, w_bg, want_grad=True):
+    """out/tgt [B,H,W,C] f32 contiguous, masks [B,H,W] f32 or None -> (loss[1], grad or None)"""
+    out, tgt = out.contiguous(), tgt.contiguous()
+    C = out.shape[-1]
+    P = out.numel() // C
+    loss = torch.empty(1, device=out.device, dtype=F32)
+    grad = torch.empty_like(out) if want_grad else None
+    if img_mask is not None:
+        img_mask = img_mask.contiguous().float()
+        assert img_mask.numel() == P
+    if fg_mask is not None:
+        fg_mask = fg_mask.contiguous().float()
+        assert fg_mask.numel() == P
+    _lib.call("adap_masked_mse", out.data_ptr(), tgt.data_ptr(), _ptr(img_mask), _ptr(fg_mask), float(w_fg), float(w_bg),
+              P, C, loss.data_ptr(), _ptr(grad), _stream())
+    return loss, grad
+
+
+def concat2(a, b):
+    ra, lda = _rows_ld(a)
+    rb, ldb = _rows_ld(b)
+    assert ra == rb and a.dtype == F32 and b.dtype == F32
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    out = torch.empty(tuple(a.shape[:-1]) + (Ca + Cb,), device=a.device, dtype=F32)
+    _lib.call("adap_concat2", a.data_ptr(), lda, Ca, b.data_ptr(), ldb, Cb, out.data_ptr(), Ca + Cb, ra, _stream())
+    return out
+
+
+def sumpool2x2(x):
+    B, H2, W2, C = x.shape
+    assert x.is_contiguous() and x.dtype == F32
+    out = torch.empty(B, H2 // 2, W2 // 2, C, device=x.device, dtype=F32)
+    _lib.call("adap_sumpool2x2", x.data_ptr(), out.data_ptr(), B, H2 // 2, W2 // 2, C, _stream())
+    return out
+
+
+def pad_cast_bf16(x, Cout=None):
+    rows, ldi = _rows_ld(x)
+    Cin = x.shape[-1]
+    Cout = Cin if Cout is None else Cout
+    out = torch.empty(tuple(x.shape[:-1]) + (Cout,), device=x.device, dtype=BF16)
+    _lib.call("adap_pad_cast_bf16", x.data_ptr(), ldi, Cin, out.data_ptr(), Cout, Cout, rows, _stream())
+    return out
+
+
+def transpose_bf16(x):
+    G, R, C = x.shape
+    assert x.is_contiguous() and x.dtype == BF16
+    out = torch.empty(G, C, R, device=x.device, dtype=BF16)
+    _lib.call("adap_transpose_bf16", x.data_ptr(), out.data_ptr(), G, R, C, _stream())
+    return out
+
+
+def vae_softmax(S, scale, pixel_class=None):
+    """S f32 [G, N, N] -> P bf16 [G, N, N] with the post-softmax hetero-pair zero fill."""
+    G, N, N2 = S.shape
+    assert S.is_contiguous() and S.dtype == F32
+    P = torch.empty(G, N, N2, device=S.device, dtype=BF16)
+    if pixel_class is not None:
+        assert pixel_class.dtype == torch.uint8 and pixel_class.shape == (G, N2) and pixel_class.is_contiguous()
+    _lib.call("adap_vae_softmax", S.data_ptr(), N2, P.data_ptr(), N2, _ptr(pixel_class), G * N, N2, N, float(scale),
+              _stream())
+    return P
+
+
+def axpy_(y, x, a=1.0):
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == F32 and y.dtype == F32
+    _lib.call("adap_axpy", x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream())
+    return y

@@ -1,0 +1,173 @@
+/*
+ * adaprompt_hip.h -- C ABI of libadaprompt_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * SD-1.5 UNet denoising + distillation training hot path of askerlee/adaprompt (AdaFace).
+ *
+ * The reference is pure Python on stock torch ops and has no FFI of its own;
+ * each entry point below names the reference code (file:line under /root/reference) whose arithmetic
+ * it replaces.  How a reference maintainer binds them (ctypes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: device pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - every function returns 0 on success or a negative ADAP_ERR_* code; adap_last_error() holds
+ *     the message (thread local).  Nothing throws; nothing falls back to a CPU path.
+ *   - the caller owns every buffer (including workspaces); kernels never allocate, free or
+ *     synchronise; all work is enqueued on `stream`; entry points are re-entrant.
+ *   - activations are PIXEL-MAJOR ("NHWC" / token-major): element (b, y, x, c) of a [B,H,W,C] tensor
+ *     is at ((b*H + y)*W + x)*ld + c, where ld >= C is the leading dimension passed with the pointer.
+ *     SpatialTransformer's 'b c h w -> b (h w) c' (attention.py:325) is therefore free.
+ *   - dtype codes: 0 = f32, 1 = bf16.  The fp32 residual stream of the reference is kept in f32;
+ *     bf16 is used only for MFMA operands (outputs of norm / activation / projection kernels).
+ *   - conv / linear weights are pre-packed bf16, see adap_pack_conv_weight.
+ */
+#ifndef ADAPROMPT_HIP_H
+#define ADAPROMPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADAP_OK 0
+#define ADAP_ERR_SHAPE (-1)
+#define ADAP_ERR_ALIGN (-2)
+#define ADAP_ERR_UNSUPPORTED (-3)
+#define ADAP_ERR_HIP (-4)
+
+#define ADAP_F32 0
+#define ADAP_BF16 1
+
+const char* adap_last_error(void);
+int adap_abi_version(void);
+int adap_device_info(char* name, int name_cap, int* num_cus, char* arch, int arch_cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Contractions: nn.Conv2d 3x3 / 1x1 and nn.Linear on the matrix cores (implicit GEMM).
+ * Replaces: ResBlock convs openaimodel.py:205-236,259-279; Downsample :138-164 (stride 2, pad 1);
+ * Upsample :95-123 (up = 1: nearest x2 fused into the gather); SpatialTransformer proj_in/proj_out
+ * attention.py:302-341; CrossAttention to_q/to_k/to_v/to_out :176-243; GEGLU/FeedForward :32-59;
+ * VAE ResnetBlock / conv_in / conv_out / nin_shortcut model.py:83-142,474-499 and its Downsample
+ * (pad = 0 with Hout = Hin/2 reproduces F.pad(0,1,0,1) + stride 2, model.py:73-77); quant_conv
+ * autoencoder.py:302,326; and, with a mode-1 weight pack, the data gradient of each of them
+ * (up = 2: zero-insert gather = transposed stride-2 conv).
+ *
+ *   y[b,oy,ox,co] = alpha * sum_{ky,kx,ci} x[b, oy*stride-pad+ky, ox*stride-pad+kx, ci] * w[ky,kx,co,ci]
+ *                   + bias[co] + chan_add[b*ld_ca + co] + residual[pixel*ldr + co]
+ *
+ * x: f32 or bf16 (x_dtype); w_packed: bf16 [KH*KW][Cout][Cin]; Cin % 8 == 0, Cout % 4 == 0.
+ * y32 and/or y16 receive the result.  ksplit > 1 splits the K loop over grid.z and accumulates with
+ * f32 atomics: y32 must be zero-filled by the caller and y16 must be NULL.
+ * nbatch > 1 runs independent problems (grid.y) with the given element strides (VAE mid attention).
+ */
+int adap_conv2d_nhwc(const void* x, int x_dtype, long ldx, const void* w_packed,
+                     const float* bias, const float* chan_add, long ld_ca,
+                     const float* residual, long ldr,
+                     float* y32, long ldy32, void* y16, long ldy16,
+                     int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                     int KH, int KW, int stride, int pad, int up,
+                     float alpha, int ksplit,
+                     int nbatch, long bs_x, long bs_w, long bs_y32, long bs_y16,
+                     void* stream);
+
+/* OIHW f32 (checkpoint layout, ddpm.py:321-344) -> bf16 [KH*KW][rows][cols].
+ * mode 0 (forward): rows >= O, cols >= I, out[t][o][i] = w[o][i][ky][kx] (zero padded).
+ * mode 1 (data gradient): rows >= I, cols >= O, out[t][i][o] = w[o][i][KH-1-ky][KW-1-kx]. */
+int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O, int I, int KH, int KW, int mode,
+                          int rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm(32) [+ SiLU]: GroupNorm32 util.py:217-219 (+ nn.SiLU), Normalize attention.py:71-72 and
+ * model.py:39-40 (+ nonlinearity model.py:34-36).  x f32 [B][HW][C]; mean/rstd [B][32] are saved for
+ * the backward; workspace holds adap_groupnorm_workspace_floats(B,HW,C) floats.  act: 0 none, 1 SiLU.
+ */
+long adap_groupnorm_workspace_floats(int B, int HW, int C);
+int adap_groupnorm_fwd(const float* x, long ldx, const float* gamma, const float* beta,
+                       float* y32, long ldy32, void* y16, long ldy16,
+                       float* mean, float* rstd, float* workspace,
+                       int B, int HW, int C, float eps, int act, void* stream);
+/* dx (f32, optionally accumulated into, and/or bf16) from dy (f32 or bf16). */
+int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const float* x, long ldx,
+                       const float* gamma, const float* beta, const float* mean, const float* rstd,
+                       float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
+                       float* workspace, int B, int HW, int C, int act, void* stream);
+
+/* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3, attention.py:267-269,275-285. */
+int adap_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y16, long ldy,
+                       float* mean, float* rstd, long rows, int D, float eps, void* stream);
+int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
+                       const float* mean, const float* rstd, float* dx, long lddx, int accumulate,
+                       long rows, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CrossAttention core, attention.py:195-243: softmax((q k^T) * scale [+ key mask]) v, fused.
+ * q [B][N][H*d], k/v [B][M][H*d] bf16; key_mask [B][M] bytes (0 = masked with -finfo.max, :223-232)
+ * or NULL; out bf16 [B][N][H*d]; lse f32 [B][H][N].  d % 8 == 0, d <= 160.
+ */
+int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                       const uint8_t* key_mask, void* out, long ldo, float* lse,
+                       int B, int H, int N, int M, int d, float scale, void* stream);
+/* dq/dk/dv as f32 and/or bf16; delta_ws: B*H*N floats of scratch. */
+int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                       const uint8_t* key_mask, const void* out, long ldo, const void* dout, long lddo,
+                       const float* lse, float* delta_ws,
+                       float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
+                       float* dv32, void* dv16, long lddv,
+                       int B, int H, int N, int M, int d, float scale, void* stream);
+/* side outputs of the distillation layers, attention.py:245-255: attnscore / attn [B][H][N][M] f32,
+ * q_scaled = q * scale^0.5 [B][H][N][d] f32 (any of them may be NULL).  M <= 192. */
+int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
+                           float* q_scaled, int B, int H, int N, int M, int d, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEGLU, attention.py:32-40: h = [a | gate] bf16 [rows][2*inner] -> a * gelu(gate) bf16 [rows][inner].
+ */
+int adap_geglu_fwd(const void* h, long ldh, void* out, long ldo, long rows, int inner, void* stream);
+int adap_geglu_bwd(const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, long rows,
+                   int inner, void* stream);
+
+/* time_embed MLP openaimodel.py:518-522 and ResBlock emb_layers :217-223 (R <= 8 rows, exact f32):
+ * y[r][n] = post( bias[n] + sum_k pre(x[r][k]) w[n][k] ), pre/post = SiLU when the flag is set. */
+int adap_linear_small(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                      int R, int K, int N, int pre_silu, int post_silu, void* stream);
+
+/* timestep_embedding, util.py:154-174 (t int64 [B] -> [B][dim]). */
+int adap_timestep_embedding(const long long* t, float* out, int B, int dim, void* stream);
+
+/* q_sample, ddpm.py:416-419 with extract_into_tensor util.py:99-102. */
+int adap_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
+                  const float* sqrt_1mac, float* out, int B, long per_sample, void* stream);
+
+/* DiagonalGaussianDistribution.sample + scale_factor, distributions.py:24-37, ddpm.py:955-962.
+ * moments pixel-major [pixels][2*zch] (mean | logvar), noise / z [pixels][zch]. */
+int adap_posterior_sample(const float* moments, long ldm, const float* noise, float* z, long pixels, int zch,
+                          float scale, void* stream);
+
+/* calc_recon_loss, ddpm.py:3571-3595: masked, fg/bg-weighted MSE; writes loss[0] and (optionally) d loss / d out. */
+int adap_masked_mse(const float* out, const float* tgt, const float* img_mask, const float* fg_mask, float w_fg,
+                    float w_bg, long pixels, int C, float* loss, float* grad, void* stream);
+
+/* torch.cat([h, hs.pop()], dim=1), openaimodel.py:1018, for pixel-major f32 tensors. */
+int adap_concat2(const float* a, long lda, int Ca, const float* b, long ldb, int Cb, float* out, long ldo,
+                 long rows, void* stream);
+
+/* adjoint of F.interpolate(scale_factor=2, mode='nearest') (openaimodel.py:118): [B][2H][2W][C] -> [B][H][W][C]. */
+int adap_sumpool2x2(const float* in, float* out, int B, int H, int W, int C, void* stream);
+
+/* f32 [rows][Cin] -> bf16 [rows][Cout >= Cin], zero padded (image 3->8 / latent 4->8 channels, or a plain cast). */
+int adap_pad_cast_bf16(const float* in, long ldi, int Cin, void* out, long ldo, int Cout, long rows, void* stream);
+
+/* batched bf16 transpose [R][C] -> [C][R] (V^T of the VAE mid attention, model.py:236-239). */
+int adap_transpose_bf16(const void* in, void* out, int batch, int R, int C, void* stream);
+
+/* VAE mid AttnBlock softmax with the post-softmax hetero-pair zero fill, model.py:190-232.
+ * pixel_class [batch][N] bytes: 0 outside aug mask, 1 fg, 2 bg; NULL = no masking. */
+int adap_vae_softmax(const float* S, long lds, void* P, long ldp, const uint8_t* pixel_class, long rows, int N,
+                     int rows_per_batch, float scale, void* stream);
+
+/* y += a * x (f32; n % 4 == 0). */
+int adap_axpy(const float* x, float* y, float a, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPROMPT_HIP_H */

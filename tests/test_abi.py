@@ -1,0 +1,41 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol that include/adaprompt_hip.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+
+import pytest
+
+from adaprompt_amd import _lib, build
+
+
+def test_library_builds_and_exports_header_symbols():
+    path = build.build(verbose=False)
+    assert os.path.exists(path)
+    protos = _lib.parse_header()
+    assert len(protos) >= 25
+    lib = ctypes.CDLL(path)
+    for name in protos:
+        assert hasattr(lib, name), f"{name} declared in include/adaprompt_hip.h but not exported"
+    lib.adap_abi_version.restype = ctypes.c_int
+    assert lib.adap_abi_version() == 1
+
+
+def test_bad_arguments_return_status_not_crash():
+    """argument validation happens on the host before any launch, so it is checkable without a GPU."""
+    lib = _lib.load()
+    # Cin = 12 is not a multiple of 8 -> ADAP_ERR_ALIGN, message set
+    rc = lib.adap_conv2d_nhwc(16, 1, 12, 16, 0, 0, 0, 0, 0, 16, 8, 0, 0, 1, 4, 4, 12, 4, 4, 8, 1, 1, 1, 0, 0, 1.0, 1,
+                              1, 0, 0, 0, 0, 0)
+    assert rc == -2 and b"Cin" in lib.adap_last_error()
+    with pytest.raises(_lib.HipError):
+        _lib.call("adap_attention_fwd", 16, 40, 16, 40, 16, 40, 0, 16, 40, 0, 1, 8, 16, 16, 5, 0.1, 0)   # d = 5
+
+
+def test_product_package_does_not_import_oracle():
+    import re
+    root = os.path.dirname(os.path.abspath(build.__file__))
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"

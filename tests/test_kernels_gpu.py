@@ -1,0 +1,354 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against a plain PyTorch fp32
+reference of the same op (run on the same device), on seeded inputs.  Inputs of the bf16
+matrix-core kernels are pre-rounded to bf16 so the only difference is accumulation order."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from adaprompt_amd import ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(x):     # [B,C,H,W] -> [B,H,W,C] contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# conv / linear
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, Cin, Cout, H, W, K, stride, pad, up, x bf16?
+    (2, 320, 320, 16, 16, 3, 1, 1, 0, True),
+    (2, 320, 320, 16, 16, 3, 1, 1, 0, False),
+    (1, 640, 320, 8, 8, 3, 1, 1, 0, True),
+    (2, 128, 128, 20, 12, 3, 1, 1, 0, True),       # non-square, Cout tile 128
+    (2, 64, 256, 9, 7, 3, 1, 1, 0, False),         # ragged pixel tile
+    (2, 8, 320, 16, 16, 3, 1, 1, 0, True),         # padded 4->8 input channels
+    (2, 320, 4, 16, 16, 3, 1, 1, 0, True),         # final conv 320->4
+    (2, 320, 320, 16, 16, 3, 2, 1, 0, False),      # UNet downsample
+    (2, 128, 128, 16, 16, 3, 2, 0, 0, False),      # VAE downsample: pad (0,1,0,1)
+    (2, 320, 320, 8, 8, 3, 1, 1, 1, False),        # nearest x2 upsample fused
+    (2, 960, 640, 8, 8, 1, 1, 0, 0, False),        # 1x1 skip
+    (1, 2560, 1280, 8, 8, 3, 1, 1, 0, True),       # long K
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case):
+    B, Cin, Cout, H, W, K, stride, pad, up, xb = case
+    x = bf(rnd(B, Cin, H, W, seed=1))
+    w = bf(rnd(Cout, Cin, K, K, seed=2, scale=(Cin * K * K) ** -0.5))
+    bias = rnd(Cout, seed=3)
+    xr = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    if stride == 2 and pad == 0:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), w, bias, stride=2)
+        out_hw = (H // 2, W // 2)
+    else:
+        ref = F.conv2d(xr, w, bias, stride=stride, padding=pad)
+        out_hw = None
+    pk = ops.PackedConv(w, bias)
+    xin = nhwc(x)
+    if xb:
+        xin = xin.to(torch.bfloat16)
+    y32, y16 = ops.conv2d(xin, pk.fwd, pk.O4, K, stride, pad, up, out_hw=out_hw, bias=pk.bias, out_f32=True,
+                          out_bf16=True)
+    got = nchw(y32)[:, :Cout]
+    assert got.shape == ref.shape
+    assert rel(got, ref) < 2e-5, rel(got, ref)
+    assert rel(nchw(y16.float())[:, :Cout], ref) < 4e-3
+
+
+def test_conv2d_epilogue_and_splitk():
+    B, Cin, Cout, H = 2, 640, 320, 8
+    x = bf(rnd(B, Cin, H, H, seed=1))
+    w = bf(rnd(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5))
+    bias, emb, res = rnd(Cout, seed=3), rnd(B, Cout, seed=4), rnd(B, Cout, H, H, seed=5)
+    ref = 0.5 * F.conv2d(x, w, None, padding=1) + bias[None, :, None, None] + emb[:, :, None, None] + res
+    pk = ops.PackedConv(w, bias)
+    xin = nhwc(x).to(torch.bfloat16)
+    y32, _ = ops.conv2d(xin, pk.fwd, Cout, 3, 1, 1, bias=pk.bias, chan_add=emb, residual=nhwc(res), alpha=0.5)
+    assert rel(nchw(y32), ref) < 2e-5
+    y32s, _ = ops.conv2d(xin, pk.fwd, Cout, 3, 1, 1, bias=pk.bias, chan_add=emb, residual=nhwc(res), alpha=0.5, ksplit=4)
+    assert rel(nchw(y32s), ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 320, 320, 16, 3, 1, 1, 0), (2, 640, 320, 8, 1, 1, 0, 0),
+                                  (2, 320, 320, 16, 3, 2, 1, 0), (2, 320, 320, 8, 3, 1, 1, 1),
+                                  (2, 128, 256, 8, 3, 1, 1, 0)])
+def test_conv2d_data_grad(case):
+    """dX of the conv through the same kernel with the mode-1 weight pack."""
+    B, Cin, Cout, H, K, stride, pad, up = case
+    x = bf(rnd(B, Cin, H, H, seed=1)).requires_grad_(True)
+    w = bf(rnd(Cout, Cin, K, K, seed=2, scale=(Cin * K * K) ** -0.5))
+    xr = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    y = F.conv2d(xr, w, None, stride=stride, padding=pad)
+    gy = bf(rnd(*y.shape, seed=7))
+    (gx_ref,) = torch.autograd.grad(y, x, gy)
+    pk = ops.PackedConv(w)
+    g = nhwc(gy)
+    if stride == 2:
+        # transposed conv: zero-insert gather (up=2), pad K-1-pad, output = input size
+        gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], K, 1, K - 1 - pad, up=2, out_hw=(H, H))
+    else:
+        gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], K, 1, K - 1 - pad)
+        if up:
+            gx = ops.sumpool2x2(gx)
+    assert rel(nchw(gx)[:, :Cin], gx_ref) < 2e-5
+
+
+def test_linear_and_batched_matmul():
+    x = bf(rnd(3, 77, 768, seed=1))
+    w = bf(rnd(320, 768, seed=2, scale=768 ** -0.5))
+    b = rnd(320, seed=3)
+    r = rnd(3, 77, 320, seed=4)
+    pk = ops.PackedConv(w, b)
+    y32, y16 = ops.linear(x, pk.fwd, 320, bias=pk.bias, residual=r, out_bf16=True)
+    ref = F.linear(x, w, b) + r
+    assert rel(y32, ref) < 2e-5 and rel(y16.float(), ref) < 4e-3
+    a = bf(rnd(2, 200, 64, seed=5)).to(torch.bfloat16)
+    c = bf(rnd(2, 136, 64, seed=6)).to(torch.bfloat16)
+    got = ops.batched_matmul_nt(a, c, alpha=0.25)
+    assert rel(got, 0.25 * torch.einsum("gmk,gnk->gmn", a.float(), c.float())) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,H,eps,act", [(2, 320, 16, 1e-5, 1), (2, 1920, 8, 1e-5, 1), (1, 2560, 8, 1e-5, 1),
+                                           (2, 640, 8, 1e-6, 0), (2, 128, 40, 1e-6, 1), (2, 32, 8, 1e-5, 1),
+                                           (4, 960, 32, 1e-5, 1)])
+def test_groupnorm_fwd_bwd(B, C, H, eps, act):
+    x = (rnd(B, C, H, H, seed=1) * 1.5 + 0.3).requires_grad_(True)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    if act:
+        ref = F.silu(ref)
+    y32, y16, mean, rstd = ops.groupnorm_fwd(nhwc(x.detach()), gamma, beta, eps, act, out_f32=True, out_bf16=True)
+    assert rel(nchw(y32), ref) < 1e-5
+    assert rel(nchw(y16.float()), ref) < 4e-3
+    gy = rnd(*ref.shape, seed=4)
+    (gx_ref,) = torch.autograd.grad(ref, x, gy)
+    dx32, dx16 = ops.groupnorm_bwd(nhwc(gy), nhwc(x.detach()), gamma, beta, mean, rstd, act, out_f32=True, out_bf16=True)
+    assert rel(nchw(dx32), gx_ref) < 2e-5
+    assert rel(nchw(dx16.float()), gx_ref) < 4e-3
+    base = rnd(B, H, H, C, seed=9)
+    acc = base.clone()
+    ops.groupnorm_bwd(nhwc(gy).to(torch.bfloat16), nhwc(x.detach()), gamma, beta, mean, rstd, act, accumulate_into=acc)
+    assert rel(nchw(acc - base), gx_ref) < 4e-3
+
+
+@pytest.mark.parametrize("rows,D", [(512, 320), (100, 640), (64, 1280), (33, 32)])
+def test_layernorm_fwd_bwd(rows, D):
+    x = (rnd(rows, D, seed=1) * 2 + 0.5).requires_grad_(True)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    ref = F.layer_norm(x, (D,), gamma, beta, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.detach(), gamma, beta)
+    assert rel(y.float(), ref) < 4e-3
+    gy = rnd(rows, D, seed=4)
+    (gx_ref,) = torch.autograd.grad(ref, x, gy)
+    dx = ops.layernorm_bwd(gy, x.detach(), gamma, mean, rstd)
+    assert rel(dx, gx_ref) < 2e-5
+    acc = torch.ones_like(dx)
+    ops.layernorm_bwd(gy, x.detach(), gamma, mean, rstd, accumulate_into=acc)
+    assert rel(acc - 1, gx_ref) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def ref_attention(q, k, v, heads, mask=None):
+    B, N, C = q.shape
+    d = C // heads
+
+    def sp(t):
+        return t.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+    qq, kk, vv = sp(q), sp(k), sp(v)
+    sim = torch.einsum("bhid,bhjd->bhij", qq, kk) * d ** -0.5
+    if mask is not None:
+        sim = sim.masked_fill(~mask.bool()[:, None, None, :], -torch.finfo(sim.dtype).max)
+    attn = sim.softmax(-1)
+    out = torch.einsum("bhij,bhjd->bhid", attn, vv)
+    return out.permute(0, 2, 1, 3).reshape(B, N, C), sim, attn
+
+
+ATTN_CASES = [
+    # B, heads, N, M, d, mask
+    (2, 8, 256, 256, 40, False),
+    (2, 8, 256, 256, 40, True),
+    (1, 8, 1024, 1024, 40, False),
+    (2, 8, 200, 200, 80, True),          # ragged N and M
+    (2, 8, 64, 64, 160, False),
+    (2, 8, 256, 77, 40, False),          # cross attention
+    (2, 8, 64, 77, 160, False),
+    (2, 8, 128, 77, 80, False),
+    (2, 8, 96, 40, 8, False),            # narrow test model dims
+    (2, 8, 96, 96, 16, True),
+    (1, 8, 64, 64, 32, False),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(case):
+    B, H, N, M, d, use_mask = case
+    C = H * d
+    q = bf(rnd(B, N, C, seed=1)).requires_grad_(True)
+    k = bf(rnd(B, M, C, seed=2)).requires_grad_(True)
+    v = bf(rnd(B, M, C, seed=3)).requires_grad_(True)
+    mask = None
+    if use_mask:
+        g = torch.Generator().manual_seed(5)
+        mask = (torch.rand(B, M, generator=g) > 0.3).to(dev())
+        mask[:, 0] = True
+    ref, sim, attn = ref_attention(q, k, v, H, mask)
+    km = mask.to(torch.uint8).contiguous() if mask is not None else None
+    qb, kb, vb = (t.detach().to(torch.bfloat16) for t in (q, k, v))
+    out, lse = ops.attention_fwd(qb, kb, vb, H, km)
+    assert rel(out.float(), ref) < 6e-3, rel(out.float(), ref)
+    lse_ref = torch.logsumexp(sim, dim=-1)
+    assert rel(lse, lse_ref) < 1e-4
+    do = bf(rnd(B, N, C, seed=4))
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), do)
+    dq, dk, dv = ops.attention_bwd(qb, kb, vb, out, do.to(torch.bfloat16), lse, H, km, dq_bf16=False, dkv_bf16=False)
+    assert rel(dv, gv) < 1e-2, ("dv", rel(dv, gv))
+    assert rel(dq, gq) < 1e-2, ("dq", rel(dq, gq))
+    assert rel(dk, gk) < 1e-2, ("dk", rel(dk, gk))
+
+
+def test_attention_online_softmax_rescale():
+    """one key whose score dwarfs the others appears late: forces the running-max rescale branch."""
+    B, H, N, M, d = 1, 8, 64, 256, 40
+    C = H * d
+    q = bf(rnd(B, N, C, seed=1))
+    k = bf(rnd(B, M, C, seed=2))
+    v = bf(rnd(B, M, C, seed=3))
+    k[:, 200] = q[:, 5] * 4.0          # huge score for query 5 (and large for others) in the 4th key tile
+    ref, _, _ = ref_attention(q, k, v, H)
+    out, _ = ops.attention_fwd(q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16), H)
+    assert rel(out.float(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("B,N,M,d", [(2, 256, 77, 40), (1, 64, 77, 160), (2, 100, 154, 80)])
+def test_attention_capture(B, N, M, d):
+    H = 8
+    C = H * d
+    q, k = bf(rnd(B, N, C, seed=1)), bf(rnd(B, M, C, seed=2))
+    _, sim, attn = ref_attention(q, k, k, H)
+    score, prob, qs = ops.attention_capture(q.to(torch.bfloat16), k.to(torch.bfloat16), H)
+    assert rel(score, sim) < 1e-5 and rel(prob, attn) < 1e-5
+    qref = q.reshape(B, N, H, d).permute(0, 2, 1, 3) * math.sqrt(d ** -0.5)
+    assert rel(qs, qref) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# small kernels
+# ---------------------------------------------------------------------------------------------
+def test_geglu_fwd_bwd():
+    h = bf(rnd(300, 2 * 1280, seed=1)).requires_grad_(True)
+    a, g = h.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    out = ops.geglu_fwd(h.detach().to(torch.bfloat16))
+    assert rel(out.float(), ref) < 4e-3
+    do = bf(rnd(300, 1280, seed=2))
+    (gh,) = torch.autograd.grad(ref, h, do)
+    dh = ops.geglu_bwd(do.to(torch.bfloat16), h.detach().to(torch.bfloat16))
+    assert rel(dh.float(), gh) < 4e-3
+
+
+def test_linear_small_and_timestep_embedding():
+    t = torch.tensor([0, 1, 500, 999], device=dev())
+    emb = ops.timestep_embedding(t, 320)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev()) / half)
+    args = t[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    assert float((emb - ref).abs().max()) < 2e-4          # sin/cos of arguments up to 999 rad in fp32
+    w1, b1 = rnd(1280, 320, seed=1, scale=320 ** -0.5), rnd(1280, seed=2)
+    y = ops.linear_small(ref, w1, b1, post_silu=True)
+    assert rel(y, F.silu(F.linear(ref, w1, b1))) < 1e-5
+    w2 = rnd(640, 1280, seed=3, scale=1280 ** -0.5)
+    y2 = ops.linear_small(y, w2, None, pre_silu=True)
+    assert rel(y2, F.linear(F.silu(y), w2)) < 1e-5
+
+
+def test_q_sample_posterior_mse():
+    B = 4
+    x0, n = rnd(B, 64, 64, 4, seed=1), rnd(B, 64, 64, 4, seed=2)
+    t = torch.tensor([0, 10, 500, 999], device=dev())
+    sa, sb = torch.rand(1000, device=dev()), torch.rand(1000, device=dev())
+    got = ops.q_sample(x0, n, t, sa, sb)
+    ref = sa[t].view(B, 1, 1, 1) * x0 + sb[t].view(B, 1, 1, 1) * n
+    assert rel(got, ref) < 1e-6
+    mom = rnd(B, 64, 64, 8, seed=3) * 3
+    mom[..., 4:] *= 10
+    z = ops.posterior_sample(mom, n, 0.18215)
+    refz = 0.18215 * (mom[..., :4] + torch.exp(0.5 * mom[..., 4:].clamp(-30, 20)) * n)
+    assert rel(z, refz) < 1e-5
+    out = rnd(B, 64, 64, 4, seed=4).requires_grad_(True)
+    im = (torch.rand(B, 64, 64, device=dev()) > 0.2).float()
+    fg = (torch.rand(B, 64, 64, device=dev()) > 0.6).float()
+    pix = F.mse_loss(n * im[..., None], out * im[..., None], reduction="none")
+    wfg = (fg * im)[..., None].expand_as(pix)
+    wbg = ((1 - fg) * im * 0.1)[..., None].expand_as(pix)
+    ref_loss = ((pix * wfg).sum() + (pix * wbg).sum()) / (wfg.sum() + wbg.sum() + 1e-6)
+    (gref,) = torch.autograd.grad(ref_loss, out)
+    loss, grad = ops.masked_mse(out.detach(), n, im, fg, 1.0, 0.1)
+    assert abs(float(loss) - float(ref_loss)) / float(ref_loss) < 1e-5
+    assert rel(grad, gref) < 1e-5
+
+
+def test_concat_pool_pad_transpose_softmax_axpy():
+    a, b = rnd(2, 8, 8, 320, seed=1), rnd(2, 8, 8, 640, seed=2)
+    assert torch.equal(ops.concat2(a, b), torch.cat([a, b], dim=-1))
+    x = rnd(2, 16, 16, 64, seed=3)
+    ref = x.reshape(2, 8, 2, 8, 2, 64).sum(dim=(2, 4))
+    assert rel(ops.sumpool2x2(x), ref) < 1e-6
+    img = rnd(2, 32, 32, 3, seed=4)
+    p = ops.pad_cast_bf16(img, 8)
+    assert p.shape[-1] == 8 and torch.equal(p[..., :3], img.to(torch.bfloat16)) and float(p[..., 3:].abs().max()) == 0
+    t = rnd(2, 100, 72, seed=5).to(torch.bfloat16)
+    assert torch.equal(ops.transpose_bf16(t), t.transpose(1, 2).contiguous())
+    S = rnd(2, 256, 256, seed=6) * 8
+    cls = torch.randint(0, 3, (2, 256), device=dev(), dtype=torch.uint8)
+    P = ops.vae_softmax(S, 0.125, cls)
+    ref = (S * 0.125).softmax(-1)
+    allowed = (cls[:, :, None] == cls[:, None, :]) & (cls[:, :, None] != 0)
+    assert rel(P.float(), ref * allowed) < 4e-3
+    assert rel(ops.vae_softmax(S, 0.125).float(), ref) < 4e-3
+    y, xx = rnd(1024, seed=7), rnd(1024, seed=8)
+    y0 = y.clone()
+    ops.axpy_(y, xx, 0.5)
+    assert rel(y, y0 + 0.5 * xx) < 1e-6
+
+
+def test_errors_are_loud():
+    from adaprompt_amd._lib import HipError
+    x = rnd(1, 4, 4, 12).to(torch.bfloat16)       # Cin not a multiple of 8
+    w = torch.zeros(1, 8, 12, device=dev(), dtype=torch.bfloat16)
+    with pytest.raises(HipError):
+        ops.conv2d(x, w, 8, 1)
