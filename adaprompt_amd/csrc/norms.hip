@@ -32,16 +32,35 @@ __device__ __forceinline__ GnGeom gn_geom(int C) {
     return g;
 }
 
+// Deterministic block reduction of per-thread channel sums into the 32 group sums: every thread parks its
+// (slot, e) partials in LDS, then thread g < 32 adds the contributions of group g's channels in a fixed order
+// (no float atomics, so results are bit-reproducible run to run).  sm: [GN_MAXSLOT*4][256] floats.
+__device__ __forceinline__ float gn_group_sum(const float* sm, const GnGeom& g, int cpg, int grp) {
+    float acc = 0.f;
+    for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) {
+        int q = c >> 2, e = c & 3;
+        int slot = q / g.TPR, lir = q - slot * g.TPR;
+        const float* col = sm + (slot * 4 + e) * 256 + lir;
+        for (int r0 = 0; r0 < g.rpp; ++r0) acc += col[r0 * g.TPR];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void gn_park(float* sm, const float (*v)[4], int tid) {
+#pragma unroll
+    for (int k = 0; k < GN_MAXSLOT; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm[(k * 4 + e) * 256 + tid] = v[k][e];
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward pass 1: per-slab partial sums.  grid (nchunks, B), block 256.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long ldx, int HW, int C,
                                                        int rows_per_chunk, float* __restrict__ partial) {
-    __shared__ float lsum[GN_G], lsq[GN_G];
+    __shared__ float smA[GN_MAXSLOT * 4 * 256], smB[GN_MAXSLOT * 4 * 256];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-    if (tid < GN_G) { lsum[tid] = 0.f; lsq[tid] = 0.f; }
-    __syncthreads();
     const GnGeom g = gn_geom(C);
     const int cpg = C / GN_G;
     const int lir = tid % g.TPR, r0 = tid / g.TPR;
@@ -68,22 +87,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < GN_MAXSLOT; ++k) {
-            int q = lir + k * g.TPR;
-            if (k < g.nslots && q < g.Q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int grp = (4 * q + e) / cpg;
-                    atomicAdd(&lsum[grp], s[k][e]);
-                    atomicAdd(&lsq[grp], ss[k][e]);
-                }
-            }
-        }
     }
+    gn_park(smA, s, tid);
+    gn_park(smB, ss, tid);
     __syncthreads();
     if (tid < GN_G) {
-        float2 o = make_float2(lsum[tid], lsq[tid]);
+        float2 o = make_float2(gn_group_sum(smA, g, cpg, tid), gn_group_sum(smB, g, cpg, tid));
         *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = o;
     }
 }
@@ -230,23 +239,24 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int act, int rows_per_chunk,
                                                            float* __restrict__ partial) {
-    __shared__ float lA[GN_G], lB[GN_G];
+    __shared__ float smA[GN_MAXSLOT * 4 * 256], smB[GN_MAXSLOT * 4 * 256];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-    if (tid < GN_G) { lA[tid] = 0.f; lB[tid] = 0.f; }
-    __syncthreads();
     const GnGeom g = gn_geom(C);
     const int cpg = C / GN_G;
     const int lir = tid % g.TPR, r0 = tid / g.TPR;
+    float sA[GN_MAXSLOT][4], sB[GN_MAXSLOT][4];
+#pragma unroll
+    for (int k = 0; k < GN_MAXSLOT; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sA[k][e] = 0.f; sB[k][e] = 0.f; }
     if (r0 < g.rpp) {
         float sc[GN_MAXSLOT][4], sh[GN_MAXSLOT][4], ga[GN_MAXSLOT][4], be[GN_MAXSLOT][4];
-        float sA[GN_MAXSLOT][4], sB[GN_MAXSLOT][4];
 #pragma unroll
         for (int k = 0; k < GN_MAXSLOT; ++k) {
             int q = lir + k * g.TPR;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sA[k][e] = 0.f; sB[k][e] = 0.f;
                 if (k < g.nslots && q < g.Q) {
                     int c = 4 * q + e, grp = c / cpg;
                     float rs = rstd[b * GN_G + grp];
@@ -281,22 +291,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < GN_MAXSLOT; ++k) {
-            int q = lir + k * g.TPR;
-            if (k < g.nslots && q < g.Q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int grp = (4 * q + e) / cpg;
-                    atomicAdd(&lA[grp], sA[k][e]);
-                    atomicAdd(&lB[grp], sB[k][e]);
-                }
-            }
-        }
     }
+    gn_park(smA, sA, tid);
+    gn_park(smB, sB, tid);
     __syncthreads();
     if (tid < GN_G)
-        *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = make_float2(lA[tid], lB[tid]);
+        *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = make_float2(gn_group_sum(smA, g, cpg, tid), gn_group_sum(smB, g, cpg, tid));
 }
 
 template <bool DY_BF16>

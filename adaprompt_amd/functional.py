@@ -1,0 +1,262 @@
+"""Block-level autograd Functions of the UNet: each one sequences HIP kernels for the forward
+and, explicitly, for the data-gradient backward (the UNet is frozen in the shipped config,
+``unfreeze_model: False`` v1-finetune-ada.yaml:26 / ddpm.py:775-786, so gradients flow only to
+the inputs -- ultimately to the layerwise text context that the subject-basis generators
+produced).  torch.autograd is used as the tape between blocks; inside a block nothing is
+left to it: residual adds, time-embedding adds, bias adds and gradient accumulation are fused
+into kernel epilogues.
+
+All activations are pixel-major f32 (the residual stream) or bf16 (matrix-core operands)."""
+import torch
+
+from . import ops
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+class WeightCache:
+    """bf16 packs of a module's parameters, rebuilt when a parameter changes (``_version``)."""
+
+    def __init__(self):
+        self._packs = {}
+
+    def get(self, key, weights, bias=None, cat_dim0=False):
+        ws = weights if isinstance(weights, (list, tuple)) else [weights]
+        bs = bias if isinstance(bias, (list, tuple)) else [bias]
+        stamp = tuple((w.data_ptr(), w._version) for w in ws) + tuple((b.data_ptr(), b._version) for b in bs if b is not None)
+        hit = self._packs.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            w = torch.cat([x.detach() for x in ws], dim=0) if len(ws) > 1 else ws[0].detach()
+            b = None
+            if bs[0] is not None:
+                b = torch.cat([x.detach() for x in bs], dim=0) if len(bs) > 1 else bs[0].detach()
+            pk = ops.PackedConv(w, b)
+        self._packs[key] = (stamp, pk)
+        return pk
+
+    def clear(self):
+        self._packs.clear()
+
+
+def _conv_bwd_data(g, pk, K, pad):
+    """dX of a stride-1 conv: the same implicit GEMM with the flipped/transposed pack."""
+    gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], K, 1, K - 1 - pad)
+    return gx
+
+
+def _lin_bwd(g, pk, out_f32=True, out_bf16=False):
+    """dX of a Linear / 1x1 conv: g [..., O] -> [..., I]."""
+    return ops.linear(g, pk.bwd[:, :, :], pk.bwd.shape[1], out_f32=out_f32, out_bf16=out_bf16)
+
+
+# ---------------------------------------------------------------------------------------------
+# ResBlock (openaimodel.py:259-279)
+# ---------------------------------------------------------------------------------------------
+class ResBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, emb_out, P):
+        """x [B,H,W,Cin] f32; emb_out [B,Cout] f32 (= emb_layers(emb), added per (batch, channel));
+        P: dict with gn1/gn2 (gamma, beta), conv1/conv2/skip PackedConv."""
+        g1w, g1b = P["gn1"]
+        g2w, g2b = P["gn2"]
+        c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
+        _, a1, m1, r1 = ops.groupnorm_fwd(x, g1w, g1b, 1e-5, 1)
+        h1, _ = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, chan_add=emb_out)
+        _, a2, m2, r2 = ops.groupnorm_fwd(h1, g2w, g2b, 1e-5, 1)
+        if sk is None:
+            skip = x
+        else:
+            skip, _ = ops.conv2d(x, sk.fwd, sk.O4, 1, bias=sk.bias)
+        out, _ = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip)
+        ctx.P = P
+        ctx.save_for_backward(x, h1, m1, r1, m2, r2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h1, m1, r1, m2, r2 = ctx.saved_tensors
+        P = ctx.P
+        g1w, g1b = P["gn1"]
+        g2w, g2b = P["gn2"]
+        c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
+        ga2 = _conv_bwd_data(g, c2, 3, 1)                                        # f32
+        _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
+        ga1 = _conv_bwd_data(gh1, c1, 3, 1)
+        if sk is None:
+            gx = g.clone(memory_format=torch.contiguous_format)
+        else:
+            gx, _ = ops.conv2d(g, sk.bwd, sk.bwd.shape[1], 1)
+        ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, accumulate_into=gx)
+        return gx, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# SpatialTransformer with one BasicTransformerBlock (attention.py:260-341)
+# ---------------------------------------------------------------------------------------------
+class SpatialTransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture):
+        B, H, W, C = x.shape
+        N = H * W
+        same_ctx = ctx_k is ctx_v or (ctx_k.data_ptr() == ctx_v.data_ptr() and ctx_k.shape == ctx_v.shape)
+        gnw, gnb = P["norm"]
+        _, xn, gm, gr = ops.groupnorm_fwd(x, gnw, gnb, 1e-6, 0)
+        pin = P["proj_in"]
+        t0, _ = ops.linear(xn.view(B, N, C), pin.fwd, C, bias=pin.bias)
+        # --- attn1 (self) : fused q|k|v projection -------------------------------------------
+        n1, l1m, l1r = ops.layernorm_fwd(t0, *P["norm1"])
+        qkv = P["qkv1"]
+        _, qkv1 = ops.linear(n1, qkv.fwd, 3 * C, out_f32=False, out_bf16=True)
+        q1, k1, v1 = qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:]
+        o1, lse1 = ops.attention_fwd(q1, k1, v1, heads, key_mask)
+        to1 = P["to_out1"]
+        t1, _ = ops.linear(o1, to1.fwd, C, bias=to1.bias, residual=t0)
+        # --- attn2 (cross) ----------------------------------------------------------------------
+        n2, l2m, l2r = ops.layernorm_fwd(t1, *P["norm2"])
+        _, q2 = ops.linear(n2, P["q2"].fwd, C, out_f32=False, out_bf16=True)
+        M = ctx_k.shape[1]
+        if same_ctx:
+            _, kv2 = ops.linear(ctx_k, P["kv2"].fwd, 2 * C, out_f32=False, out_bf16=True)
+        else:
+            kv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
+            _, kk = ops.linear(ctx_k, P["k2"].fwd, C, out_f32=False, out_bf16=True)
+            _, vv = ops.linear(ctx_v, P["v2"].fwd, C, out_f32=False, out_bf16=True)
+            kv2[..., :C].copy_(kk)
+            kv2[..., C:].copy_(vv)
+        k2, v2 = kv2[..., :C], kv2[..., C:]
+        o2, lse2 = ops.attention_fwd(q2, k2, v2, heads, None)
+        cap = (None, None, None)
+        if capture:
+            cap = ops.attention_capture(q2, k2, heads)
+        to2 = P["to_out2"]
+        t2, _ = ops.linear(o2, to2.fwd, C, bias=to2.bias, residual=t1)
+        # --- GEGLU feed-forward -----------------------------------------------------------------
+        n3, l3m, l3r = ops.layernorm_fwd(t2, *P["norm3"])
+        ff1, ff2 = P["ff1"], P["ff2"]
+        _, hh = ops.linear(n3, ff1.fwd, 8 * C, bias=ff1.bias, out_f32=False, out_bf16=True)
+        gg = ops.geglu_fwd(hh)
+        t3, _ = ops.linear(gg, ff2.fwd, C, bias=ff2.bias, residual=t2)
+        pout = P["proj_out"]
+        out, _ = ops.linear(t3, pout.fwd, C, bias=pout.bias, residual=x.view(B, N, C))
+        ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
+        ctx.key_mask = key_mask
+        ctx.save_for_backward(x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh,
+                              ctx_k, ctx_v)
+        out = out.view(B, H, W, C)
+        if capture:
+            ctx.mark_non_differentiable(*cap)
+            return (out,) + tuple(cap)
+        return out
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        (x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh, ctx_k,
+         ctx_v) = ctx.saved_tensors
+        P, heads = ctx.P, ctx.heads
+        B, H, W, C = x.shape
+        N = H * W
+        g = g.reshape(B, N, C) if g.is_contiguous() else g.contiguous().view(B, N, C)
+        gt3, _ = _lin_bwd(g, P["proj_out"])                                       # f32 [B,N,C]
+        # feed-forward
+        _, ggg = _lin_bwd(gt3, P["ff2"], out_f32=False, out_bf16=True)           # bf16 [B,N,4C]
+        ghh = ops.geglu_bwd(ggg, hh)                                              # bf16 [B,N,8C]
+        gn3, _ = _lin_bwd(ghh, P["ff1"])
+        gt2 = ops.layernorm_bwd(gn3, t2, P["norm3"][0], l3m, l3r, accumulate_into=gt3)
+        # cross attention
+        _, go2 = _lin_bwd(gt2, P["to_out2"], out_f32=False, out_bf16=True)
+        M = kv2.shape[1]
+        dq2 = torch.empty(B, N, C, device=x.device, dtype=BF16)
+        dkv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
+        ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
+                          dv=dkv2[..., C:])
+        gn2, _ = _lin_bwd(dq2, P["q2"])
+        gt1 = ops.layernorm_bwd(gn2, t1, P["norm2"][0], l2m, l2r, accumulate_into=gt2)
+        g_ck = g_cv = None
+        if ctx.same_ctx:
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                g_ck, _ = _lin_bwd(dkv2, P["kv2"])                                # dK Wk + dV Wv in one contraction
+        else:
+            if ctx.needs_input_grad[1]:
+                g_ck, _ = _lin_bwd(dkv2[..., :C], P["k2"])
+            if ctx.needs_input_grad[2]:
+                g_cv, _ = _lin_bwd(dkv2[..., C:], P["v2"])
+        # self attention
+        _, go1 = _lin_bwd(gt1, P["to_out1"], out_f32=False, out_bf16=True)
+        dqkv1 = torch.empty(B, N, 3 * C, device=x.device, dtype=BF16)
+        ops.attention_bwd(qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:], o1, go1, lse1, heads, ctx.key_mask,
+                          dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:])
+        gn1, _ = _lin_bwd(dqkv1, P["qkv1"])
+        gt0 = ops.layernorm_bwd(gn1, t0, P["norm1"][0], l1m, l1r, accumulate_into=gt1)
+        # proj_in, GroupNorm
+        _, gxn = _lin_bwd(gt0, P["proj_in"], out_f32=False, out_bf16=True)
+        gx = g.clone(memory_format=torch.contiguous_format).view(B, H, W, C)
+        gnw, gnb = P["norm"]
+        ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, accumulate_into=gx)
+        return gx, g_ck, g_cv, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# Downsample / Upsample / head / concat
+# ---------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """conv3x3 on the f32 residual stream: stride 1 (mode 'same'), UNet Downsample (stride 2, pad 1;
+    openaimodel.py:138-164) or Upsample (nearest x2 then conv; openaimodel.py:95-123)."""
+
+    @staticmethod
+    def forward(ctx, x, pk, mode):
+        ctx.pk, ctx.mode, ctx.in_hw = pk, mode, (x.shape[1], x.shape[2])
+        if mode == "down":
+            y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 2, 1, bias=pk.bias)
+        elif mode == "up":
+            y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias)
+        else:
+            y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        pk, mode = ctx.pk, ctx.mode
+        if mode == "down":
+            gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], 3, 1, 1, up=2, out_hw=ctx.in_hw)
+        elif mode == "up":
+            gx = ops.sumpool2x2(_conv_bwd_data(g, pk, 3, 1))
+        else:
+            gx = _conv_bwd_data(g, pk, 3, 1)
+        return gx, None, None
+
+
+class OutHeadFn(torch.autograd.Function):
+    """``out``: GroupNorm32(1e-5) -> SiLU -> conv3x3 320->4 (openaimodel.py:693-697)."""
+
+    @staticmethod
+    def forward(ctx, h, gn, pk):
+        _, a, m, r = ops.groupnorm_fwd(h, gn[0], gn[1], 1e-5, 1)
+        y, _ = ops.conv2d(a, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
+        ctx.gn, ctx.pk = gn, pk
+        ctx.save_for_backward(h, m, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        h, m, r = ctx.saved_tensors
+        pk = ctx.pk
+        g16 = ops.pad_cast_bf16(g.contiguous(), pk.bwd.shape[2])          # 4 -> 8 channels for the K dim
+        ga = _conv_bwd_data(g16, pk, 3, 1)
+        gh, _ = ops.groupnorm_bwd(ga, h, ctx.gn[0], ctx.gn[1], m, r, 1)
+        return gh, None, None
+
+
+class ConcatFn(torch.autograd.Function):
+    """torch.cat([h, skip], dim=channels) (openaimodel.py:1018) for pixel-major tensors."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = a.shape[-1]
+        return ops.concat2(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.ca], g[..., ctx.ca:]

@@ -1,0 +1,144 @@
+"""SpatialTransformer / BasicTransformerBlock / CrossAttention / GEGLU FeedForward
+(reference ldm/modules/attention.py:32-59, 147-341) as parameter containers with the
+reference's attribute names (so checkpoints load by key), executed by one fused block Function
+(adaprompt_amd.functional.SpatialTransformerFn): pixel-major activations, fused q|k|v
+projection, flash attention on the matrix cores, residual adds in GEMM epilogues."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import functional as HF
+from ... import ops
+from ..util import default
+from .diffusionmodules.util import zero_module
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0):
+        super().__init__()
+        assert glu, "SD-1.5 uses the gated feed-forward"
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+
+
+def Normalize(in_channels):
+    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class CrossAttention(nn.Module):
+    """to_q / to_k / to_v / to_out parameters + the flags the reference toggles from UNetModel.forward
+    (save_attn_vars, use_conv_attn_kernel_size, is_training; attention.py:147-170)."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = default(context_dim, query_dim)
+        assert inner_dim == query_dim
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.save_attn_vars = False
+        self.cached_activations = None
+        self.use_conv_attn_kernel_size = -1
+        self.infeat_size = None
+        self.is_training = True
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                                    dropout=dropout)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+
+class SpatialTransformer(nn.Module):
+    """forward(x, context, mask): x pixel-major [B,H,W,C] f32; ``context`` is a tensor, a
+    (v_context, k_context) tuple or -- as UNetModel passes it -- a callable returning
+    ((v_context, k_context), placeholder2indices) (attention.py:184-191); ``mask`` [B,1,h,w] is
+    nearest-resized to this level and masks self-attention keys (attention.py:223-232, 332)."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None):
+        super().__init__()
+        assert depth == 1, "SD-1.5: transformer_depth = 1"
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.n_heads = n_heads
+        self.norm = Normalize(in_channels)
+        self.proj_in = nn.Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim)])
+        self.proj_out = zero_module(nn.Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
+        self.save_feat = False
+        self._wc = HF.WeightCache()
+
+    def _packs(self, same_ctx):
+        wc, b = self._wc, self.transformer_blocks[0]
+        P = {
+            "norm": (self.norm.weight, self.norm.bias),
+            "proj_in": wc.get("proj_in", self.proj_in.weight, self.proj_in.bias),
+            "norm1": (b.norm1.weight, b.norm1.bias),
+            "norm2": (b.norm2.weight, b.norm2.bias),
+            "norm3": (b.norm3.weight, b.norm3.bias),
+            "qkv1": wc.get("qkv1", [b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight]),
+            "to_out1": wc.get("to_out1", b.attn1.to_out[0].weight, b.attn1.to_out[0].bias),
+            "q2": wc.get("q2", b.attn2.to_q.weight),
+            "to_out2": wc.get("to_out2", b.attn2.to_out[0].weight, b.attn2.to_out[0].bias),
+            "ff1": wc.get("ff1", b.ff.net[0].proj.weight, b.ff.net[0].proj.bias),
+            "ff2": wc.get("ff2", b.ff.net[2].weight, b.ff.net[2].bias),
+            "proj_out": wc.get("proj_out", self.proj_out.weight, self.proj_out.bias),
+        }
+        if same_ctx:
+            P["kv2"] = wc.get("kv2", [b.attn2.to_k.weight, b.attn2.to_v.weight])
+        else:
+            P["k2"] = wc.get("k2", b.attn2.to_k.weight)
+            P["v2"] = wc.get("v2", b.attn2.to_v.weight)
+        return P
+
+    def forward(self, x, context=None, mask=None):
+        B, H, W, C = x.shape
+        blk = self.transformer_blocks[0]
+        blk.attn2.infeat_size = (H, W)
+        if callable(context):
+            context, _placeholder2indices = context()
+        if context is None:
+            raise NotImplementedError("SpatialTransformer without a text context is not on the SD-1.5 path")
+        if isinstance(context, (list, tuple)):
+            v_ctx, k_ctx = context
+        else:
+            v_ctx = k_ctx = context
+        if blk.attn2.use_conv_attn_kernel_size is not None and blk.attn2.use_conv_attn_kernel_size > 0:
+            raise NotImplementedError("conv-attn (use_conv_attn_kernel_size > 0) is off in the shipped config "
+                                      "(embedding_manager.py:967) and not built")
+        same = v_ctx is k_ctx
+        k_ctx = k_ctx.contiguous().float()
+        v_ctx = k_ctx if same else v_ctx.contiguous().float()
+        key_mask = None
+        if mask is not None:
+            m2 = F.interpolate(mask.float(), size=(H, W), mode="nearest")
+            key_mask = (m2.reshape(B, H * W) != 0).to(torch.uint8).contiguous()
+        capture = bool(blk.attn2.save_attn_vars)
+        res = HF.SpatialTransformerFn.apply(x.contiguous(), k_ctx, v_ctx, self._packs(same), self.n_heads, key_mask, capture)
+        if capture:
+            out, score, prob, qs = res
+            blk.attn2.cached_activations = {"q": qs, "attn": prob, "attnscore": score}
+        else:
+            out = res
+        if self.save_feat:
+            raise NotImplementedError("save_feat (pre-proj_out feature tap) is not on the training hot path")
+        return out

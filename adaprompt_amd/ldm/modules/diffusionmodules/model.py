@@ -1,0 +1,183 @@
+"""VAE ``Encoder`` of the first stage on the MI355X kernels (reference
+ldm/modules/diffusionmodules/model.py:408-499 with ResnetBlock :83-142, Downsample :61-80,
+AttnBlock :151-242, Normalize :39-40).  Parameter names follow the reference
+(``first_stage_model.encoder.*`` checkpoints load by key).  Forward only: the first stage is
+frozen and runs under no_grad on the training path (ddpm.py:1381-1419).
+
+Activations are pixel-major; the 512x512x3 image is consumed in the dataloader's own HWC layout
+(ddpm.py:480-481 permutes it to CHW for the reference -- here that permute is the identity).
+The mid AttnBlock (single head, N=4096, C=512) is two batched contractions around a softmax
+kernel that applies the reference's POST-softmax zero fill of fg/bg hetero pairs."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import functional as HF
+from .... import ops
+
+
+def Normalize(in_channels, num_groups=32):
+    return nn.GroupNorm(num_groups=num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class Downsample(nn.Module):
+    """F.pad(x, (0,1,0,1)) + conv3x3 stride 2 pad 0 == zero-predicated taps with pad 0 and Hout = H/2."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        self._wc = HF.WeightCache()
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        pk = self._wc.get("conv", self.conv.weight, self.conv.bias)
+        y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 2, 0, out_hw=(H // 2, W // 2), bias=pk.bias)
+        return y
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
+        super().__init__()
+        assert not conv_shortcut and temb_channels == 0
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if self.in_channels != self.out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        self._wc = HF.WeightCache()
+
+    def forward(self, x, temb=None):
+        assert temb is None
+        wc = self._wc
+        c1 = wc.get("conv1", self.conv1.weight, self.conv1.bias)
+        c2 = wc.get("conv2", self.conv2.weight, self.conv2.bias)
+        _, a1, _, _ = ops.groupnorm_fwd(x, self.norm1.weight, self.norm1.bias, 1e-6, 1)
+        h, _ = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias)
+        _, a2, _, _ = ops.groupnorm_fwd(h, self.norm2.weight, self.norm2.bias, 1e-6, 1)
+        if self.in_channels != self.out_channels:
+            sk = wc.get("nin", self.nin_shortcut.weight, self.nin_shortcut.bias)
+            skip, _ = ops.conv2d(x, sk.fwd, sk.O4, 1, bias=sk.bias)
+        else:
+            skip = x
+        y, _ = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip)
+        return y
+
+
+class AttnBlock(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.k = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.v = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self.proj_out = nn.Conv2d(in_channels, in_channels, kernel_size=1)
+        self._wc = HF.WeightCache()
+
+    @staticmethod
+    def pixel_classes(mask, hw, like):
+        """mask dict {'fg_mask','aug_mask'} [B,1,H,W] -> uint8 [B, h*w]: 0 outside aug, 1 fg, 2 bg (model.py:196-232)."""
+        if mask is None or mask.get("fg_mask") is None:
+            return None
+        B = like.shape[0]
+        fg = F.interpolate(mask["fg_mask"].float(), size=hw, mode="nearest")
+        aug = mask["aug_mask"]
+        aug = torch.ones_like(fg) if aug is None else F.interpolate(aug.float(), size=hw, mode="nearest")
+        cls = torch.where(fg * aug != 0, 1, torch.where((1 - fg) * aug != 0, 2, 0))
+        return cls.reshape(B, -1).to(torch.uint8).contiguous()
+
+    def forward(self, x, mask=None):
+        B, H, W, C = x.shape
+        N = H * W
+        wc = self._wc
+        _, hn, _, _ = ops.groupnorm_fwd(x, self.norm.weight, self.norm.bias, 1e-6, 0)
+        qkv = wc.get("qkv", [self.q.weight, self.k.weight, self.v.weight], [self.q.bias, self.k.bias, self.v.bias])
+        _, y = ops.linear(hn.view(B, N, C), qkv.fwd, 3 * C, bias=qkv.bias, out_f32=False, out_bf16=True)
+        q = y[..., :C].contiguous()
+        k = y[..., C:2 * C].contiguous()
+        vT = ops.transpose_bf16(y[..., 2 * C:].contiguous())                 # [B, C, N]
+        S = ops.batched_matmul_nt(q, k)                                       # [B, N, N] f32, unscaled
+        P = ops.vae_softmax(S, float(int(C) ** -0.5), self.pixel_classes(mask, (H, W), x))
+        o = ops.batched_matmul_nt(P, vT, out_dtype=torch.bfloat16)           # [B, N, C]
+        po = wc.get("proj_out", self.proj_out.weight, self.proj_out.bias)
+        out, _ = ops.linear(o, po.fwd, C, bias=po.bias, residual=x.view(B, N, C))
+        return out.view(B, H, W, C)
+
+
+def make_attn(in_channels, attn_type="vanilla"):
+    assert attn_type == "vanilla"
+    return AttnBlock(in_channels)
+
+
+class Encoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        assert not use_linear_attn and len(list(attn_resolutions)) == 0, "SD-1.5 VAE: attention only in mid"
+        self.ch = ch
+        self.temb_ch = 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.conv_in = nn.Conv2d(in_channels, self.ch, kernel_size=3, stride=1, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+            down = nn.Module()
+            down.block = block
+            down.attn = nn.ModuleList()
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1,
+                                  padding=1)
+        self._wc = HF.WeightCache()
+
+    def forward_nhwc(self, x_hwc, mask=None):
+        """x_hwc [B,H,W,3] f32 (the dataloader's layout) -> pixel-major h [B,H/8,W/8,2*z]."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x_hwc.requires_grad:
+            raise NotImplementedError("the first stage is frozen: encode runs under no_grad (ddpm.py:1381-1419)")
+        if not x_hwc.is_cuda:
+            raise RuntimeError("adaprompt_amd Encoder runs on the MI355X HIP kernels only; got a CPU tensor")
+        wc = self._wc
+        cin = wc.get("conv_in", self.conv_in.weight, self.conv_in.bias)
+        x16 = ops.pad_cast_bf16(x_hwc.contiguous().float(), cin.I8)
+        h, _ = ops.conv2d(x16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias)
+        for i_level in range(self.num_resolutions):
+            for blk in self.down[i_level].block:
+                h = blk(h)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample(h)
+        h = self.mid.block_1(h)
+        h = self.mid.attn_1(h, mask)
+        h = self.mid.block_2(h)
+        _, a, _, _ = ops.groupnorm_fwd(h, self.norm_out.weight, self.norm_out.bias, 1e-6, 1)
+        co = wc.get("conv_out", self.conv_out.weight, self.conv_out.bias)
+        y, _ = ops.conv2d(a, co.fwd, co.O4, 3, 1, 1, bias=co.bias)
+        return y
+
+    def forward(self, x, mask=None):
+        """reference signature: x NCHW -> NCHW (a view of the pixel-major result)."""
+        with torch.no_grad():
+            return self.forward_nhwc(x.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)

@@ -1,0 +1,382 @@
+"""SD-1.5 ``UNetModel`` on the MI355X kernels -- the drop-in for the reference class of the same
+dotted name (reference ldm/modules/diffusionmodules/openaimodel.py:447-1052).
+
+Same constructor arguments, same parameter names (checkpoints with the
+``model.diffusion_model.*`` namespace load by key), same ``forward(x, timesteps, context, y,
+context_in, extra_info)`` contract including the AdaFace additions: 16-way layerwise context
+(:866-877), ``mix_hijk`` K/V split (:885-891), ``img_mask`` on self-attention keys, and the
+capture of cross-attention activations into ``extra_info['ca_layers_activations']`` for layers
+{7,8,12,16..24} (:947-952, 1031-1035).
+
+Inside, nothing is the reference's: activations are pixel-major (NHWC) f32 with bf16 operand
+copies produced by the norm kernels, every block is one autograd Function sequencing HIP
+kernels (adaprompt_amd.functional), and the 22 ResBlock time-embedding projections run as one
+launch.  x / eps are converted from / to the reference's NCHW at the boundary (a [B,4,64,64]
+tensor)."""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import functional as HF
+from .... import ops
+from ..attention import SpatialTransformer
+from .util import conv_nd, linear, normalization, timestep_embedding, zero_module
+
+# layer_idx -> index into the 16-way layerwise context (reference :876-877)
+LAYER2CA = {1: 0, 2: 1, 4: 2, 5: 3, 7: 4, 8: 5, 12: 6, 16: 7, 17: 8, 18: 9, 19: 10, 20: 11, 21: 12, 22: 13, 23: 14,
+            24: 15}
+ALL_CA_LAYERS = sorted(LAYER2CA)
+DISTILL_LAYERS = [7, 8, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+
+
+def extract_layerwise_value(v, ca_idx, is_array, is_dict):
+    if is_array:
+        return v[ca_idx]
+    if is_dict:
+        return v.get(ca_idx, None)
+    return v
+
+
+class TimestepBlock(nn.Module):
+    pass
+
+
+class Upsample(nn.Module):
+    """nearest x2 + conv3x3, the upsample folded into the conv's gather."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert use_conv and dims == 2 and padding == 1
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+        self._wc = HF.WeightCache()
+
+    def forward(self, x):
+        assert x.shape[-1] == self.channels
+        return HF.ConvFn.apply(x, self._wc.get("conv", self.conv.weight, self.conv.bias), "up")
+
+
+class Downsample(nn.Module):
+    """conv3x3 stride 2 pad 1."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert use_conv and dims == 2 and padding == 1
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+        self._wc = HF.WeightCache()
+
+    def forward(self, x):
+        assert x.shape[-1] == self.channels
+        return HF.ConvFn.apply(x, self._wc.get("op", self.op.weight, self.op.bias), "down")
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        assert not (use_conv or use_scale_shift_norm or up or down), "not used by the SD-1.5 config"
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(),
+                                       conv_nd(dims, channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+        self._wc = HF.WeightCache()
+
+    def forward(self, x, emb, emb_out=None):
+        """x pixel-major [B,H,W,C]; ``emb_out`` = emb_layers(emb) when the UNet has already computed
+        all blocks' projections in one launch, else it is computed here."""
+        if emb_out is None:
+            emb_out = ops.linear_small(emb, self.emb_layers[1].weight, self.emb_layers[1].bias, pre_silu=True)
+        wc = self._wc
+        sk = None
+        if not isinstance(self.skip_connection, nn.Identity):
+            sk = wc.get("skip", self.skip_connection.weight, self.skip_connection.bias)
+        P = {"gn1": (self.in_layers[0].weight, self.in_layers[0].bias),
+             "gn2": (self.out_layers[0].weight, self.out_layers[0].bias),
+             "conv1": wc.get("conv1", self.in_layers[2].weight, self.in_layers[2].bias),
+             "conv2": wc.get("conv2", self.out_layers[3].weight, self.out_layers[3].bias),
+             "skip": sk}
+        return HF.ResBlockFn.apply(x, emb_out, P)
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    def forward(self, x, emb, context=None, mask=None, emb_outs=None):
+        """``emb_outs``: {id(ResBlock): emb_layers(emb)} when the UNet pre-computed all projections."""
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x = layer(x, emb, None if emb_outs is None else emb_outs[id(layer)])
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context, mask=mask)
+            else:
+                x = layer(x)
+        return x
+
+
+class _InConv(nn.Conv2d):
+    """input_blocks.0.0: conv3x3 in_channels(4)->model_channels; the latent is padded to 8 channels (bf16)."""
+
+    def forward(self, x):
+        if not hasattr(self, "_wc"):
+            self._wc = HF.WeightCache()
+        pk = self._wc.get("w", self.weight, self.bias)
+        if x.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the noisy latent is not on the training hot path")
+        x16 = ops.pad_cast_bf16(x, pk.I8)
+        y, _ = ops.conv2d(x16, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
+        return y
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        assert use_spatial_transformer and context_dim is not None, "SD-1.5: spatial transformer with a text context"
+        assert dims == 2 and num_classes is None and not use_fp16 and not resblock_updown and n_embed is None
+        assert num_heads != -1 and num_head_channels == -1, "SD-1.5: num_heads = 8"
+        assert conv_resample and not use_scale_shift_norm
+        if not isinstance(context_dim, int):
+            context_dim = list(context_dim)
+            assert len(context_dim) == 1
+            context_dim = context_dim[0]
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads
+        self.predict_codebook_ids = False
+        self.debug_attn = False
+        self.backup_vars = {"use_conv_attn_kernel_size:layerwise": [-1] * 16, "save_attn_vars": False,
+                            "is_training": True}
+        attention_resolutions = list(attention_resolutions)
+
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, ted), nn.SiLU(), linear(ted, ted))
+        self.input_blocks = nn.ModuleList(
+            [TimestepEmbedSequential(_InConv(in_channels, model_channels, 3, padding=1))])
+        chans = [model_channels]
+        ch, ds = model_channels, 1
+
+        def st(c):
+            return SpatialTransformer(c, num_heads, c // num_heads, depth=transformer_depth, context_dim=context_dim)
+
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, ted, dropout, out_channels=mult * model_channels, dims=dims,
+                                   use_checkpoint=use_checkpoint)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, ted, dropout, dims=dims, use_checkpoint=use_checkpoint), st(ch),
+            ResBlock(ch, ted, dropout, dims=dims, use_checkpoint=use_checkpoint))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [ResBlock(ch + ich, ted, dropout, out_channels=model_channels * mult, dims=dims,
+                                   use_checkpoint=use_checkpoint)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(st(ch))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(),
+                                 zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        self._wc = HF.WeightCache()
+        self._emb_cat = None
+
+    # ---- flag plumbing kept from the reference (openaimodel.py:722-824) --------------------------------
+    def _ca_modules(self):
+        """[(layer_idx, SpatialTransformer)] in layer order (input 0-11, middle 12, output 13-24)."""
+        out, idx = [], 0
+        for m in self.input_blocks:
+            if len(m) > 1 and isinstance(m[1], SpatialTransformer):
+                out.append((idx, m[1]))
+            idx += 1
+        out.append((idx, self.middle_block[1]))
+        idx += 1
+        for m in self.output_blocks:
+            if len(m) > 1 and isinstance(m[1], SpatialTransformer):
+                out.append((idx, m[1]))
+            idx += 1
+        return out
+
+    def set_cross_attn_flags(self, ca_flag_dict=None, ca_layer_indices=None, trans_flag_dict=None,
+                             trans_layer_indices=None):
+        if ca_flag_dict is None and trans_flag_dict is None:
+            return None, None
+        if ca_layer_indices is None:
+            ca_layer_indices = ALL_CA_LAYERS
+        if trans_layer_indices is None:
+            trans_layer_indices = ALL_CA_LAYERS
+
+        def apply(flags, indices, on_attn2):
+            if flags is None or len(indices) == 0:
+                return None
+            old = {}
+            for k, v in flags.items():
+                old[k] = self.backup_vars[k]
+                self.backup_vars[k] = v
+                is_array = is_dict = False
+                if k.endswith(":layerwise"):
+                    k, is_array = k[:-len(":layerwise")], v is not None
+                if k.endswith(":layerwise-dict"):
+                    k, is_dict = k[:-len(":layerwise-dict")], v is not None
+                for layer_idx, stm in self._ca_modules():
+                    if layer_idx in indices and layer_idx in LAYER2CA:
+                        v2 = extract_layerwise_value(v, LAYER2CA[layer_idx], is_array, is_dict)
+                        tgt = stm.transformer_blocks[0].attn2 if on_attn2 else stm.transformer_blocks[0]
+                        tgt.__dict__[k] = v2
+            return old
+
+        return apply(ca_flag_dict, ca_layer_indices, True), apply(trans_flag_dict, trans_layer_indices, False)
+
+    # ---- all ResBlock time-embedding projections in one launch -------------------------------------------
+    def _resblocks(self):
+        for seq in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+            for m in seq:
+                if isinstance(m, ResBlock):
+                    yield m
+
+    def _emb_projections(self, emb):
+        blocks = list(self._resblocks())
+        stamp = tuple((b.emb_layers[1].weight.data_ptr(), b.emb_layers[1].weight._version,
+                       b.emb_layers[1].bias._version) for b in blocks)
+        if self._emb_cat is None or self._emb_cat[0] != stamp:
+            with torch.no_grad():
+                w = torch.cat([b.emb_layers[1].weight.detach().float() for b in blocks], dim=0).contiguous()
+                bias = torch.cat([b.emb_layers[1].bias.detach().float() for b in blocks], dim=0).contiguous()
+            self._emb_cat = (stamp, w, bias)
+        _, w, bias = self._emb_cat
+        allp = ops.linear_small(emb, w, bias, pre_silu=True)          # [B, sum Cout]
+        outs, off = {}, 0
+        for b in blocks:
+            outs[id(b)] = allp[:, off:off + b.out_channels]
+            off += b.out_channels
+        return outs
+
+    def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
+        assert y is None, "the SD-1.5 UNet is not class-conditional"
+        ei = extra_info if extra_info is not None else {}
+        use_layerwise_context = ei.get("use_layerwise_context", False)
+        iter_type = ei.get("iter_type", "normal_recon")
+        is_training = ei.get("is_training", True)
+        capture_distill_attn = ei.get("capture_distill_attn", False)
+        use_conv_attn_kernel_size = ei.get("use_conv_attn_kernel_size", None)
+        placeholder2indices = ei.get("placeholder2indices", None)
+        img_mask = ei.get("img_mask", None)
+        if ei.get("apply_compel_cfg_prob", 0) > 0:
+            raise NotImplementedError("compel-style cfg on the context (apply_compel_cfg_prob > 0) is not built")
+        if not use_layerwise_context:
+            raise NotImplementedError("only the layerwise-context path works in the reference (SURVEY.md 3.2)")
+        if not x.is_cuda:
+            raise RuntimeError("adaprompt_amd UNetModel runs on the MI355X HIP kernels only; got a CPU tensor")
+        B = x.shape[0]
+        M2, Cctx = context.shape[-2], context.shape[-1]
+        # [16*B, M, C] -> [16, B, M, C]: one small copy, so every layer's context is a packed view
+        ctx_l = context.reshape(B, 16, M2, Cctx).permute(1, 0, 2, 3).contiguous().float()
+
+        def get_layer_context(layer_idx):
+            if layer_idx not in LAYER2CA:
+                return None, None
+            c = ctx_l[LAYER2CA[layer_idx]]
+            if iter_type == "mix_hijk":
+                v, k = c.chunk(2, dim=1)
+                return (v.contiguous(), k.contiguous()), placeholder2indices
+            return (c, c), placeholder2indices
+
+        if not isinstance(use_conv_attn_kernel_size, (int, np.integer)):
+            # the reference fails here too (np.ones(16) * None, openaimodel.py:922): an integer is required
+            raise TypeError("extra_info['use_conv_attn_kernel_size'] must be an int (-1 = off)")
+        sizes = np.ones(16, dtype=int) * use_conv_attn_kernel_size
+        if use_conv_attn_kernel_size > 0:
+            sizes[6:11] = 1
+        stack = []
+        old, _ = self.set_cross_attn_flags(ca_flag_dict={"use_conv_attn_kernel_size:layerwise": sizes,
+                                                         "is_training": is_training}, ca_layer_indices=None)
+        stack.append((old, None))
+        distill = []
+        if capture_distill_attn or ei.get("debug_attn", self.debug_attn):
+            distill = DISTILL_LAYERS
+            old, _ = self.set_cross_attn_flags(ca_flag_dict={"save_attn_vars": True}, ca_layer_indices=distill)
+            stack.append((old, distill))
+
+        t_emb = timestep_embedding(timesteps, self.model_channels)
+        te = self.time_embed
+        emb = ops.linear_small(ops.linear_small(t_emb, te[0].weight, te[0].bias, post_silu=True), te[2].weight,
+                               te[2].bias)
+        emb_outs = self._emb_projections(emb)
+
+        def run(seq, h, layer_idx):
+            return seq(h, emb, partial(get_layer_context, layer_idx), mask=img_mask, emb_outs=emb_outs)
+
+        acts = {}
+
+        def grab(layer_idx, stm, h):
+            if layer_idx in distill:
+                a2 = stm.transformer_blocks[0].attn2
+                acts[layer_idx] = dict(a2.cached_activations)
+                acts[layer_idx]["outfeat"] = h.permute(0, 3, 1, 2)        # NCHW view of the pixel-major tensor
+                a2.cached_activations = None
+
+        h = x.float().permute(0, 2, 3, 1).contiguous()                   # NCHW latent -> pixel-major
+        hs = []
+        layer_idx = 0
+        for module in self.input_blocks:
+            h = run(module, h, layer_idx)
+            hs.append(h)
+            if len(module) > 1:
+                grab(layer_idx, module[1], h)
+            layer_idx += 1
+        h = run(self.middle_block, h, layer_idx)
+        grab(layer_idx, self.middle_block[1], h)
+        layer_idx += 1
+        for module in self.output_blocks:
+            h = HF.ConcatFn.apply(h, hs.pop())
+            h = run(module, h, layer_idx)
+            if len(module) > 1 and isinstance(module[1], SpatialTransformer):
+                grab(layer_idx, module[1], h)
+            layer_idx += 1
+        if extra_info is not None:
+            extra_info["ca_layers_activations"] = {
+                key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q")}
+        for old, idxs in reversed(stack):
+            self.set_cross_attn_flags(ca_flag_dict=old, ca_layer_indices=idxs)
+
+        o = self.out
+        eps = HF.OutHeadFn.apply(h, (o[0].weight, o[0].bias), self._wc.get("out", o[2].weight, o[2].bias))
+        return eps.permute(0, 3, 1, 2)                                    # back to the reference's NCHW

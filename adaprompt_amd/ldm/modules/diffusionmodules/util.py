@@ -1,0 +1,65 @@
+"""Host-side helpers of the diffusion modules (reference ldm/modules/diffusionmodules/util.py):
+beta schedule (:21-43), extract_into_tensor (:99-102), timestep_embedding (:154-174) on the HIP
+kernel, and the parameter containers ``GroupNorm32`` (:217-219), ``conv_nd`` (:222-232),
+``linear`` (:235-239), ``zero_module`` (:177-183).  ``checkpoint`` is a plain call, as in the
+reference where it is hard-disabled (:105-119)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    if schedule == "linear":
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    elif schedule == "sqrt_linear":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    elif schedule == "sqrt":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    elif schedule == "cosine":
+        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        alphas = torch.cos(ts / (1 + cosine_s) * np.pi / 2).pow(2)
+        alphas = alphas / alphas[0]
+        betas = torch.clamp(1 - alphas[1:] / alphas[:-1], 0, 0.999)
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
+
+
+def extract_into_tensor(a, t, x_shape):
+    b = t.shape[0]
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    assert not repeat_only and max_period == 10000
+    return ops.timestep_embedding(timesteps, dim)
+
+
+def checkpoint(func, inputs, params, flag):
+    return func(*inputs)
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class GroupNorm32(nn.GroupNorm):
+    """parameter container; the arithmetic runs in adap_groupnorm_fwd (fp32 statistics)."""
+
+
+def normalization(channels):
+    return GroupNorm32(32, channels)
+
+
+def conv_nd(dims, *args, **kwargs):
+    if dims != 2:
+        raise ValueError(f"unsupported dimensions: {dims}")
+    return nn.Conv2d(*args, **kwargs)
+
+
+def linear(*args, **kwargs):
+    return nn.Linear(*args, **kwargs)

@@ -16,6 +16,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py's roofline leg): brackets every launch of the selected
+    kernel families with events on the stream the kernel runs on (torch's current stream) and keeps the
+    algorithmic work of each launch.  Off (None) on the normal path."""
+
+    def __init__(self):
+        self.records = []          # (family, work, start_event, end_event)
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, family, work, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((family, work, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, work, e0, e1 in self.records:
+            d = out.setdefault(fam, {"launches": 0, "work": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["work"] += work
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+TIMER = None
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -131,9 +163,13 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
         ld_ca = chan_add.stride(0)
     if bias is not None:
         assert bias.dtype == F32 and bias.numel() >= Cout
+    e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_conv2d_nhwc", x.data_ptr(), _dt(x), ldx, w_packed.data_ptr(), _ptr(bias), _ptr(chan_add), ld_ca,
               _ptr(residual), ldr, _ptr(y32), ldy32, _ptr(y16), ldy16, B, H, W, Cin, Ho, Wo, Cout, KH, KH, stride, pad,
               up, float(alpha), ksplit, 1, 0, 0, 0, 0, _stream())
+    if e0 is not None:
+        # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
+        TIMER.stop("conv_gemm", 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0)
     return y32, y16
 
 
@@ -178,8 +214,12 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     rstd = torch.empty(B, 32, device=x.device, dtype=F32)
     y32 = torch.empty(x.shape, device=x.device, dtype=F32) if out_f32 else None
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
+    e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_groupnorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
               mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), B, HW, C, float(eps), int(act), _stream())
+    if e0 is not None:
+        # algorithmic bytes: read x once (4 B) + write y (2 B bf16 / 4 B f32) per element
+        TIMER.stop("groupnorm_fwd", float(x.numel()) * (4 + (4 if out_f32 else 0) + (2 if out_bf16 else 0)), e0)
     return y32, y16, mean, rstd
 
 
@@ -244,28 +284,35 @@ def attention_fwd(q, k, v, heads, key_mask=None):
     lse = torch.empty(B, heads, N, device=q.device, dtype=F32)
     if key_mask is not None:
         assert key_mask.dtype == torch.uint8 and key_mask.shape == (B, M) and key_mask.is_contiguous()
+    e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_attention_fwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
               _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d, float(d) ** -0.5,
               _stream())
+    if e0 is not None:
+        TIMER.stop("attention_fwd", 4.0 * B * heads * N * M * d, e0)      # QK^T + PV, SURVEY.md 8d
     return out, lse
 
 
-def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq_bf16=True, dkv_bf16=True):
+def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=None, dv=None, out_dtype=BF16):
+    """dq/dk/dv may be caller-provided pixel-major views (e.g. slices of one fused [B,N,3C] buffer);
+    otherwise fresh tensors of ``out_dtype`` are allocated."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
     assert dout.dtype == BF16 and out.dtype == BF16
     dev = q.device
     delta = torch.empty(B, heads, N, device=dev, dtype=F32)
-    dq = torch.empty(B, N, C, device=dev, dtype=BF16 if dq_bf16 else F32)
-    dk = torch.empty(B, M, C, device=dev, dtype=BF16 if dkv_bf16 else F32)
-    dv = torch.empty(B, M, C, device=dev, dtype=BF16 if dkv_bf16 else F32)
+    dq = torch.empty(B, N, C, device=dev, dtype=out_dtype) if dq is None else dq
+    dk = torch.empty(B, M, C, device=dev, dtype=out_dtype) if dk is None else dk
+    dv = torch.empty(B, M, C, device=dev, dtype=out_dtype) if dv is None else dv
+
+    def pp(t):
+        return (0, t.data_ptr()) if t.dtype == BF16 else (t.data_ptr(), 0)
+    (dq32, dq16), (dk32, dk16), (dv32, dv16) = pp(dq), pp(dk), pp(dv)
     _lib.call("adap_attention_bwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
-              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, dout.data_ptr(), _rows_ld(dout)[1], lse.data_ptr(),
-              delta.data_ptr(),
-              0 if dq_bf16 else dq.data_ptr(), dq.data_ptr() if dq_bf16 else 0, C,
-              0 if dkv_bf16 else dk.data_ptr(), dk.data_ptr() if dkv_bf16 else 0, C,
-              0 if dkv_bf16 else dv.data_ptr(), dv.data_ptr() if dkv_bf16 else 0, C,
+              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), _rows_ld(out)[1], dout.data_ptr(), _rows_ld(dout)[1],
+              lse.data_ptr(), delta.data_ptr(),
+              dq32, dq16, _rows_ld(dq)[1], dk32, dk16, _rows_ld(dk)[1], dv32, dv16, _rows_ld(dv)[1],
               B, heads, N, M, d, float(d) ** -0.5, _stream())
     return dq, dk, dv
 

@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SD-1.5 UNet training images/sec @512px, bs=4/GPU (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torchrun, one rank per GPU, RCCL gradient all-reduce over xGMI)
+
+A "step" is one pure-recon distillation micro-batch of Stage-1 AdaFace training at the full
+SD-1.5 sizes (BASELINE.json configs[1], the stable sub-case of SURVEY.md 8d config 2):
+  VAE encode of 4 synthetic 512x512 face-shaped images with fg/aug masks (no grad)
+  -> posterior sample x 0.18215 -> q_sample -> UNet eps-prediction forward with the 16-way
+  layerwise context, img_mask on self-attention and capture of the 12 distillation layers
+  -> masked fg/bg-weighted MSE -> backward through the frozen UNet to the context
+  -> backward through the embedding hook -> data-parallel mean of the trainable gradients
+  (every micro-batch, as DDP does) -> every 2nd micro-batch: clip 0.5 + optimizer step + zero_grad.
+Weights are random (no checkpoints offline), data synthetic.  The embedding hook (CLIP text
+encoder + SubjBasisGenerator, HF weights unavailable offline) is replaced by a stand-in with the
+same trainable byte size (149 M fp32 parameters, adaprompt_amd/hook_standin.py).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel family,
+HIP-event timed) and `cpu_baseline` (the oracle on the host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+# algorithmic work per image of the step (SURVEY.md 8d, 2*MAC, forward): UNet 803.7 GFLOP, bwd (dX only) ~1x,
+# VAE encoder 1116.7 GFLOP
+GFLOP_PER_IMAGE = 1116.7 + 2 * 803.7
+
+
+def synthetic_batch(B, device, seed):
+    """image = clamp(randn*0.5,-1,1) HWC, centred-ellipse fg mask (~35 % area), aug mask with a
+    zero border of U{0..76} px, L2-normalised id embedding."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = (torch.randn(B, 512, 512, 3, generator=g) * 0.5).clamp(-1, 1)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+    fg = ((xx / 0.62) ** 2 + (yy / 0.72) ** 2 <= 1.0).float()[None].repeat(B, 1, 1)
+    aug = torch.zeros(B, 512, 512)
+    for b in range(B):
+        bd = int(torch.randint(0, 77, (1,), generator=g))
+        aug[b, bd:512 - bd, bd:512 - bd] = 1
+    ids = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1)
+    return {"image": img.to(device), "fg_mask": fg.to(device), "aug_mask": aug.to(device), "zs_id_embs": ids.to(device)}
+
+
+def device_state_dict(shapes, prefix, device, seed):
+    """random-init weights of the named architecture, generated on the device (fan-in scaled, norms ~1)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in shapes:
+        if len(shape) >= 2:
+            fan = 1
+            for s in shape[1:]:
+                fan *= s
+            t = torch.randn(shape, device=device, generator=g) * (0.8 / fan ** 0.5)
+        elif name.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, device=device, generator=g)
+        else:
+            t = 0.05 * torch.randn(shape, device=device, generator=g)
+        sd[prefix + name] = t
+    return sd
+
+
+def build_model(device, seed=0):
+    from adaprompt_amd import synth
+    from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    with torch.device(device):        # parameters are created (and default-initialised) directly in HBM
+        ld = LatentDiffusion(
+            {"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": dict(synth.SD15_VAE_DD), "embed_dim": 4}},
+            {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.SD15_UNET)})
+    ld = ld.to(device)
+    sd = device_state_dict(synth.unet_param_shapes(**synth.SD15_UNET), "model.diffusion_model.", device, seed)
+    sd.update(device_state_dict(synth.vae_encoder_param_shapes(**synth.SD15_VAE_DD), "first_stage_model.", device, seed + 1))
+    missing, unexpected = ld.load_state_dict(sd, strict=False)
+    assert not unexpected
+    del sd
+    ld.freeze_unet()
+    with torch.device(device):
+        hook = SyntheticSubjBasisGenerator()
+    ld.cond_fn = make_cond_fn(hook, capture=True)
+    return ld, hook
+
+
+def cpu_baseline(threads):
+    """the oracle (a CPU port of the reference path, pinned by the reference's golden vectors) on the host cores:
+    ONE image of the same pure-recon step at full SD-1.5 size."""
+    from adaprompt_amd import synth
+    from oracle import ldm_oracle as O
+    torch.set_num_threads(threads)
+    usd = synth.synthetic_unet_state_dict()
+    vsd = synth.synthetic_vae_state_dict()
+    B = 1
+    g = torch.Generator().manual_seed(7)
+    img = (torch.randn(B, 3, 512, 512, generator=g) * 0.5).clamp(-1, 1)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+    fg = ((xx / 0.62) ** 2 + (yy / 0.72) ** 2 <= 1.0).float()[None, None].repeat(B, 1, 1, 1)
+    aug = torch.zeros(B, 1, 512, 512)
+    aug[:, :, 20:492, 20:492] = 1
+    fg64 = torch.nn.functional.interpolate(fg, size=(64, 64), mode="nearest")
+    im64 = torch.nn.functional.interpolate(aug, size=(64, 64), mode="nearest")
+    ctx = torch.randn(16 * B, 77, 768, generator=g) * 0.05
+    t0 = time.time()
+    O.recon_step(usd, vsd, dict(synth.SD15_UNET), dict(synth.SD15_VAE_DD), img, {"fg_mask": fg, "aug_mask": aug},
+                 torch.randn(B, 4, 64, 64, generator=g), torch.tensor([500]), torch.randn(B, 4, 64, 64, generator=g), ctx,
+                 im64, fg64, 0.1, need_grad=True)
+    dt = time.time() - t0
+    return {"value": round(B / dt, 5), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "1 image (bs=1, 1 step) of the same pure-recon step at full SD-1.5 size: VAE encode + UNet fwd + "
+                      "bwd-to-context, oracle/ldm_oracle.py (torch fp32) on the host CPU",
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per micro-batch (reference: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    from adaprompt_amd import _lib, ops
+    from adaprompt_amd.parallel import GradReducer, init_distributed
+
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    _lib.load()
+
+    ld, hook = build_model(device)
+    params = list(hook.parameters())
+    reducer = GradReducer(params)
+    opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, foreach=True)
+    B = args.batch
+    batches = [synthetic_batch(B, device, 1234 + rank * 100 + i) for i in range(2)]
+    gen = torch.Generator(device=device).manual_seed(99 + rank)
+
+    def step(i):
+        batch = batches[i % 2]
+        t = torch.randint(0, 1000, (B,), device=device, generator=gen)
+        noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+        pn = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+        # the all-reduce issued by the previous micro-batch overlaps this VAE encode + UNet forward and is
+        # awaited just before this micro-batch's backward writes into the gradient buffer
+        loss, grad, out, aux = ld.shared_step(batch, t=t, noise=noise, post_noise=pn)
+        reducer.wait()
+        out.backward(grad)
+        reducer.reduce()
+        ld.batch_idx += 1
+        if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
+            reducer.wait()
+            torch.nn.utils.clip_grad_norm_(params, ld.grad_clip)
+            opt.step()
+            reducer.zero()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss_val = float(loss)
+
+    roofline = None
+    if not args.no_roofline:
+        # live HIP-event timing of the dominant kernel family on the same workload (2 extra, separately run steps)
+        ops.TIMER = ops.KernelTimer()
+        for i in range(2):
+            step(i)
+        summ = ops.TIMER.summary()
+        ops.TIMER = None
+        c = summ["conv_gemm"]
+        tf = c["work"] / (c["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/linear + data-gradients, all launches)",
+                    "bound": "mfma", "achieved": round(tf, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": c["launches"] // 2, "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 2),
+                    "ms_per_step_in_kernel": round(c["ms"] / 2, 3),
+                    "others": {k: {"launches_per_step": v["launches"] // 2, "ms_per_step": round(v["ms"] / 2, 3),
+                                   "achieved": round(v["work"] / (v["ms"] * 1e-3) / (1e12 if "attention" in k else 1e9), 2),
+                                   "unit": "TFLOP/s" if "attention" in k else "GB/s"}
+                               for k, v in summ.items() if k != "conv_gemm"}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or len(os.sched_getaffinity(0))
+        del ld, hook, reducer, opt
+        torch.cuda.empty_cache()
+        cpu = cpu_baseline(threads)
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        ms = 1e3 * dt / args.steps
+        res = {
+            "metric": "SD-1.5 UNet training images/sec @512px bs=4/GPU",
+            "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
+                                   "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, "
+                                   "hook stand-in with 149M trainable fp32 params, clip+AdamW step every 2nd micro-batch",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "grad_allreduce_bytes": reducer_bytes(world)},
+            "model_tflops_per_step": round(GFLOP_PER_IMAGE * B / 1e3, 2),
+            "achieved_model_tflops_per_gpu": round(GFLOP_PER_IMAGE * B / 1e3 / (ms * 1e-3), 1),
+            "final_loss": round(loss_val, 5),
+        }
+        if roofline is not None:
+            res["roofline"] = roofline
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def reducer_bytes(world):
+    return 149_000_000 // (16 * 77 * 768) * (16 * 77 * 768) * 4 if world > 1 else 0
+
+
+if __name__ == "__main__":
+    main()

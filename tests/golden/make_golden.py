@@ -22,12 +22,18 @@ import types
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, ROOT)
+
+import importlib.util
 
 import numpy as np
 import torch
 
-from adaprompt_amd import synth
+# load adaprompt_amd/synth.py by path: putting the repo root on sys.path would let this repo's own
+# ``ldm`` alias package shadow the reference's (namespace) ``ldm`` package.
+_spec = importlib.util.spec_from_file_location("adaprompt_synth", os.path.join(ROOT, "adaprompt_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+sys.path = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != ROOT]
 
 REF = "/root/reference"
 
@@ -63,7 +69,12 @@ def fill(module, prefix, seed):
     return module.eval()
 
 
+ONLY = ""
+
+
 def save(name, **arrs):
+    if ONLY and ONLY not in name:
+        return
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
@@ -98,7 +109,10 @@ def subsample_act(key, ten):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="", help="only (re)write fixtures whose name contains this substring")
     args = ap.parse_args()
+    global ONLY
+    ONLY = args.only
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     openaimodel, model, util, attention, distributions = import_reference()
@@ -241,7 +255,7 @@ def main():
              t=tt, **out)
         del unet
 
-    narrow = dict(synth.SD15_UNET, model_channels=32, context_dim=64)
+    narrow = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
     run_unet(narrow, 2, 77, "narrow_recon", with_grad=True)
     run_unet(narrow, 2, 77, "narrow_mask", use_mask=True, capture=False)
     run_unet(narrow, 2, 77, "narrow_mixhijk", iter_type="mix_hijk")

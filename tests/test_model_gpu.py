@@ -1,0 +1,196 @@
+"""Whole-model parity on the MI355X: the HIP UNet / VAE encoder / training step against
+(a) the golden vectors captured from the reference's own modules and (b) the oracle run on the
+same inputs.  Tolerances: matrix-core operands are bf16 (fp32 accumulate, fp32 residual stream,
+fp32 norm / softmax statistics); the north-star bar is <= 1e-3 relative on the eps-prediction
+MSE loss, per-tensor errors are reported and bounded at the bf16 level."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adaprompt_amd import synth
+from conftest import load_golden, rel_err, ellipse_mask, border_mask, subsample_act
+
+pytestmark = pytest.mark.gpu
+
+EPS_TOL = 2.5e-2       # relative L2 of eps-hat (bf16 operands through ~60 contractions)
+LOSS_TOL = 1e-3        # north_star: eps-pred MSE, relative
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def build_unet(cfg):
+    from adaprompt_amd.ldm.util import instantiate_from_config
+    m = instantiate_from_config({"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(cfg)})
+    P = "model.diffusion_model."          # tensors are seeded by their full checkpoint name
+    sd = {k[len(P):]: v for k, v in synth.synthetic_unet_state_dict(cfg, prefix=P).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev()).eval()
+
+
+def mse_loss_vs_noise(eps, seed_tag):
+    """the parity scalar: masked MSE of eps-hat against a fixed synthetic noise target (calc_recon_loss)."""
+    from oracle import ldm_oracle as O
+    noise = synth.synthetic_input(seed_tag + ".noise", eps.shape)
+    B = eps.shape[0]
+    fg = ellipse_mask(B, 64, 64)
+    im = border_mask(B, 64, 64, 4)
+    loss, _ = O.calc_recon_loss(eps.detach().float().cpu(), noise, im, fg, 1.0, 0.1)
+    return float(loss)
+
+
+def run_unet_case(cfg, tag, g, with_grad, subs_grad=False):
+    B, M = g["B"], g["M"]
+    unet = build_unet(cfg)
+    x = synth.synthetic_input(f"unet.{tag}.x", (B, 4, 64, 64)).to(dev())
+    ntok = 2 * M if g["iter_type"] == "mix_hijk" else M
+    ctx = synth.synthetic_input(f"unet.{tag}.ctx", (16 * B, ntok, cfg["context_dim"])).to(dev())
+    img_mask = border_mask(B, 64, 64, 6).to(dev()) if g["use_mask"] else None
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": g["iter_type"],
+             "is_training": True, "capture_distill_attn": bool(g["capture"]), "placeholder2indices": None,
+             "img_mask": img_mask}
+    if with_grad:
+        ctx = ctx.clone().requires_grad_(True)
+    eps = unet(x, g["t"].to(dev()), context=ctx, context_in=None, extra_info=extra)
+    assert eps.shape == g["eps"].shape
+    e = rel_err(eps.cpu(), g["eps"])
+    l_hip, l_ref = mse_loss_vs_noise(eps, tag), mse_loss_vs_noise(g["eps"], tag)
+    print(f"[{tag}] eps rel L2 {e:.3e}   loss hip {l_hip:.6f} ref {l_ref:.6f} rel {abs(l_hip - l_ref) / l_ref:.2e}")
+    assert e < EPS_TOL
+    assert abs(l_hip - l_ref) / l_ref < LOSS_TOL
+    acts = extra["ca_layers_activations"]
+    n = 0
+    for key in ("outfeat", "attn", "attnscore", "q"):
+        for li, ten in acts[key].items():
+            got = subsample_act(key, ten.detach().float().cpu())
+            ea = rel_err(got, g[f"{key}_{li}"])
+            assert ea < 4e-2, (key, li, ea)
+            n += 1
+    if g["capture"]:
+        assert n == 48
+    if with_grad:
+        w = synth.synthetic_input(f"unet.{tag}.gw", tuple(eps.shape)).to(dev())
+        (eps * w).sum().backward()
+        gr = ctx.grad.cpu()
+        ref = g["grad_context"]
+        got = gr[:, ::4, ::8] if subs_grad else gr
+        eg = rel_err(got, ref)
+        print(f"[{tag}] grad_context rel L2 {eg:.3e}  norm hip {float(gr.norm()):.5f} ref {float(g['grad_context_norm']):.5f}")
+        assert eg < 5e-2
+        assert abs(float(gr.norm()) / float(g["grad_context_norm"]) - 1) < 2e-2
+
+
+NARROW = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+
+
+def test_unet_narrow_recon_and_grad():
+    run_unet_case(NARROW, "narrow_recon", load_golden("unet_narrow_recon"), True)
+
+
+def test_unet_narrow_mask():
+    run_unet_case(NARROW, "narrow_mask", load_golden("unet_narrow_mask"), False)
+
+
+def test_unet_narrow_mixhijk():
+    run_unet_case(NARROW, "narrow_mixhijk", load_golden("unet_narrow_mixhijk"), False)
+
+
+def test_unet_sd15_full_size_vs_reference_golden():
+    """the 859.5 M-parameter SD-1.5 UNet on the output of the reference's UNetModel (config 1) + grad wrt context"""
+    run_unet_case(dict(synth.SD15_UNET), "sd15_recon", load_golden("unet_sd15_recon"), True, subs_grad=True)
+
+
+def build_vae(dd):
+    from adaprompt_amd.ldm.models.autoencoder import AutoencoderKL
+    m = AutoencoderKL(dict(dd), None, 4)
+    P = "first_stage_model."
+    sd = {k[len(P):]: v for k, v in synth.synthetic_vae_state_dict(dd, prefix=P).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("post_quant_conv") for k in missing)
+    return m.to(dev()).eval()
+
+
+def run_vae_case(dd, tag, g, tol):
+    B, res = g["B"], g["res"]
+    vae = build_vae(dd)
+    x = synth.synthetic_input(f"vae.{tag}.x", (B, 3, res, res), 0, 0.5).clamp(-1, 1).to(dev())
+    mask = None
+    if g["use_mask"]:
+        mask = {"fg_mask": ellipse_mask(B, res, res).to(dev()), "aug_mask": border_mask(B, res, res, res // 16).to(dev())}
+    post = vae.encode(x, mask)
+    e = rel_err(post.parameters.cpu(), g["moments"])
+    em = rel_err(post.mean.cpu(), g["mean"])
+    print(f"[vae {tag}] moments rel L2 {e:.3e}  mean {em:.3e}")
+    assert e < tol and em < tol
+    # the pixel-major fast path agrees with the NCHW boundary path
+    m2 = vae.encode_moments_nhwc(x.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)
+    assert torch.equal(m2, post.parameters)
+
+
+@pytest.mark.parametrize("tag", ["narrow_nomask", "narrow_mask"])
+def test_vae_narrow(tag):
+    run_vae_case(dict(synth.SD15_VAE_DD, ch=32, resolution=64), tag, load_golden("vae_" + tag), 2e-2)
+
+
+def test_vae_sd15_full_size_vs_reference_golden():
+    run_vae_case(dict(synth.SD15_VAE_DD), "sd15_mask", load_golden("vae_sd15_mask"), 2e-2)
+
+
+def test_training_step_matches_oracle():
+    """one pure-recon micro-batch through LatentDiffusion.training_step vs oracle.recon_step, narrow widths"""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import ldm_oracle as O
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                         {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    vsd = synth.synthetic_vae_state_dict(vdd)
+    missing, unexpected = ld.load_state_dict({**usd, **vsd}, strict=False)
+    assert not unexpected
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    B, res = 2, 64
+    # the narrow VAE maps 64x64 -> 8x8 latents; the UNet needs 64x64, so drive the UNet with its own latent here:
+    # parity of the step is checked stage by stage
+    img = synth.synthetic_input("step.img", (B, res, res, 3), 0, 0.5).clamp(-1, 1)
+    fgm = ellipse_mask(B, res, res)[:, 0]
+    augm = border_mask(B, res, res, 4)[:, 0]
+    post_noise = synth.synthetic_input("step.pn", (B, 4, 8, 8))
+    batch = {"image": img.to(dev()), "fg_mask": fgm.to(dev()), "aug_mask": augm.to(dev())}
+    z, _ = ld.get_input(batch, post_noise.to(dev()))
+    with torch.no_grad():
+        mom = O.autoencoder_encode_moments(vsd, vdd, img.permute(0, 3, 1, 2),
+                                           {"fg_mask": fgm[:, None], "aug_mask": augm[:, None]})
+        z_ref = O.get_first_stage_encoding(mom, post_noise)
+    assert rel_err(z.cpu(), z_ref) < 2e-2
+    # UNet part of the step at 64x64 latents
+    x0 = synth.synthetic_input("step.x0", (B, 4, 64, 64))
+    noise = synth.synthetic_input("step.noise", (B, 4, 64, 64))
+    t = torch.tensor([200, 900])
+    ctx = synth.synthetic_input("step.ctx", (16 * B, 77, ucfg["context_dim"]))
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+    sched = O.make_schedule()
+    ctx_ref = ctx.clone().requires_grad_(True)
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": True, "img_mask": im64}
+    eps_ref = O.unet_forward(usd, ucfg, O.q_sample(sched, x0, t, noise), t, ctx_ref, extra)
+    loss_ref, _ = O.calc_recon_loss(eps_ref, noise, im64, fg64, 1.0, 0.1)
+    (g_ref,) = torch.autograd.grad(loss_ref, ctx_ref)
+    ctx_hip = ctx.to(dev()).clone().requires_grad_(True)
+    extra_h = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+               "is_training": True, "capture_distill_attn": True, "img_mask": im64.to(dev())}
+    eps_hip, x_noisy = ld.guided_denoise(x0.to(dev()), noise.to(dev()), t.to(dev()), (ctx_hip, None, extra_h))
+    loss_hip, grad = ld.calc_recon_loss(eps_hip, noise.to(dev()), im64.to(dev()), fg64.to(dev()), 1.0, 0.1)
+    eps_hip.backward(grad)
+    print(f"[step] loss hip {float(loss_hip):.6f} ref {float(loss_ref):.6f}  grad rel {rel_err(ctx_hip.grad.cpu(), g_ref):.3e}")
+    assert abs(float(loss_hip) - float(loss_ref)) / float(loss_ref) < LOSS_TOL
+    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
+
+
+def test_cpu_tensor_fails_loudly():
+    unet = build_unet(NARROW)
+    with pytest.raises(RuntimeError):
+        unet(torch.zeros(1, 4, 64, 64), torch.zeros(1, dtype=torch.long), context=torch.zeros(16, 77, 128),
+             extra_info={"use_layerwise_context": True, "use_conv_attn_kernel_size": -1})

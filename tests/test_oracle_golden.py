@@ -194,7 +194,7 @@ def run_unet_case(cfg, tag, g, with_grad):
 
 def test_unet_narrow_recon_and_grad():
     g = load_golden("unet_narrow_recon")
-    cfg = dict(synth.SD15_UNET, model_channels=32, context_dim=64)
+    cfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
     grad = run_unet_case(cfg, "narrow_recon", g, True)
     assert rel_err(grad, g["grad_context"]) < 1e-4
     assert abs(float(grad.norm()) / float(g["grad_context_norm"]) - 1) < 1e-4
@@ -202,12 +202,12 @@ def test_unet_narrow_recon_and_grad():
 
 def test_unet_narrow_mask():
     g = load_golden("unet_narrow_mask")
-    run_unet_case(dict(synth.SD15_UNET, model_channels=32, context_dim=64), "narrow_mask", g, False)
+    run_unet_case(dict(synth.SD15_UNET, model_channels=64, context_dim=128), "narrow_mask", g, False)
 
 
 def test_unet_narrow_mixhijk():
     g = load_golden("unet_narrow_mixhijk")
-    run_unet_case(dict(synth.SD15_UNET, model_channels=32, context_dim=64), "narrow_mixhijk", g, False)
+    run_unet_case(dict(synth.SD15_UNET, model_channels=64, context_dim=128), "narrow_mixhijk", g, False)
 
 
 @pytest.mark.slow
