@@ -6,6 +6,10 @@ import ctypes
 import os
 import re
 
+# torch first: its bundled HIP runtime must be the one (and only) libamdhip64 in the process, otherwise the
+# kernels would be launched through a second, uninitialised runtime on streams it does not know.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "adaprompt_hip.h")

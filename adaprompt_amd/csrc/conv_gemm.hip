@@ -21,7 +21,9 @@
 //
 // Epilogue (fused): * alpha, + bias[c], + chan_add[b][c] (the ResBlock time-embedding add,
 // openaimodel.py:271-277), + residual[pixel][c] (skip / transformer residual), written as f32
-// and/or bf16.  Split-K (grid.z) accumulates with f32 atomics into a pre-zeroed f32 output.
+// and/or bf16.  Split-K (grid.z) for the small-pixel-count / long-K layers of the UNet's low
+// resolutions: every split writes its raw fp32 tile to a workspace slab and a second kernel sums the
+// slabs in a fixed order and applies the epilogue -- no float atomics, bit-reproducible.
 #include "common.h"
 
 struct ConvParams {
@@ -45,6 +47,7 @@ struct ConvParams {
     int ntiles_n;                  // ceil(Cout / BN)
     int ntiles_m;                  // ceil(M / 128)
     float alpha;
+    float* ws;              // split-K slabs [ksplit][M][Cout] f32
     long batch_stride_x;    // batched mode (B2 > 1 via grid.y): element strides per batch item
     long batch_stride_w;
     long batch_stride_y32;
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
 
     // ---- epilogue ----------------------------------------------------------------------------
     // acc[i][j][r] = C[cout = n0 + wn*WN + i*16 + (lane>>4)*4 + r][pixel = m0 + wm*64 + j*16 + (lane&15)]
-    const bool lead = (p.ksplit <= 1) || (blockIdx.z == 0);
     float* y32 = p.y32 ? p.y32 + (size_t)bz * p.batch_stride_y32 : nullptr;
     uint16_t* y16 = p.y16 ? p.y16 + (size_t)bz * p.batch_stride_y16 : nullptr;
+    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         const int m = m0 + wm * 64 + j * 16 + frow;
@@ -224,36 +227,67 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
         for (int i = 0; i < MT; ++i) {
             const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
             if (c0 >= p.Cout) continue;
+            if (slab) {
+                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                continue;
+            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            if (lead) {
-                if (p.bias) {
-                    float4 t = *(const float4*)(p.bias + c0);
-                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                }
-                if (p.chan_add) {
-                    float4 t = *(const float4*)(p.chan_add + (size_t)b * p.ld_ca + c0);
-                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                }
-                if (p.residual) {
-                    float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
-                    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                }
+            if (p.bias) {
+                float4 t = *(const float4*)(p.bias + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
-            if (p.ksplit > 1) {
-                float* dst = y32 + (size_t)m * p.ldy32 + c0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(dst + r, v[r]);
-            } else {
-                if (y32) *(float4*)(y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-                if (y16) {
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *(uint2*)(y16 + (size_t)m * p.ldy16 + c0) = o;
-                }
+            if (p.chan_add) {
+                float4 t = *(const float4*)(p.chan_add + (size_t)b * p.ld_ca + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
+            if (p.residual) {
+                float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (y32) *(float4*)(y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (y16) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(y16 + (size_t)m * p.ldy16 + c0) = o;
+            }
+        }
+    }
+}
+
+// split-K second pass: fixed-order sum of the slabs + the fused epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p, int M, int HWo) {
+    const int q = p.Cout >> 2;
+    const long total = (long)M * q;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / q);
+        const int c0 = (int)(idx - (long)m * q) * 4;
+        float4 a = *(const float4*)(p.ws + (size_t)m * p.Cout + c0);
+        for (int z = 1; z < p.ksplit; ++z) {
+            float4 t = *(const float4*)(p.ws + ((size_t)z * M + m) * p.Cout + c0);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+        if (p.bias) {
+            float4 t = *(const float4*)(p.bias + c0);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (p.chan_add) {
+            float4 t = *(const float4*)(p.chan_add + (size_t)(m / HWo) * p.ld_ca + c0);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (p.residual) {
+            float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.y16) {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
         }
     }
 }
@@ -269,7 +303,42 @@ static int launch(const ConvParams& p, int nbatch, hipStream_t stream) {
     }
     dim3 grid(p.ntiles_m * p.ntiles_n, nbatch, p.ksplit);
     hipLaunchKernelGGL((conv_gemm_kernel<BN, A_F32>), grid, dim3(256), lds, stream, p);
+    if (p.ksplit > 1) {
+        const int M = p.B * p.Hout * p.Wout;
+        long total = (long)M * (p.Cout >> 2);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, M, p.Hout * p.Wout);
+    }
     return adap_check_launch("conv_gemm");
+}
+
+static int choose_bn(int Cout) {
+    // channel tile: 160 divides 320/640/960/1280/...; 128 for the VAE's powers of two; 64 for tiny Cout
+    if (Cout <= 64) return 64;
+    if (Cout % 160 == 0) return 160;
+    return 128;
+}
+
+// split-K plan: a launch needs >> 256 workgroups to fill the chip; the UNet's 32x32 .. 8x8 levels have few pixel
+// tiles but very long K (up to 9*2560), so split K until there are ~2 workgroups per CU.
+static int choose_ksplit(long M, int Cout, int ktiles_total) {
+    int bn = choose_bn(Cout);
+    long blocks = ((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
+    if (blocks >= 384) return 1;
+    int ks = (int)((512 + blocks - 1) / blocks);
+    int cap = ktiles_total / 4;
+    if (ks > cap) ks = cap;
+    if (ks > 16) ks = 16;
+    return ks < 1 ? 1 : ks;
+}
+
+// floats of split-K workspace adap_conv2d_nhwc needs for this problem with ksplit = 0 (auto); 0 = none
+extern "C" long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW) {
+    long M = (long)B * Hout * Wout;
+    int kt = KH * KW * ((Cin + BK - 1) / BK);
+    int ks = choose_ksplit(M, Cout, kt);
+    return ks > 1 ? (long)ks * M * Cout : 0;
 }
 
 extern "C" int adap_conv2d_nhwc(
@@ -280,7 +349,7 @@ extern "C" int adap_conv2d_nhwc(
     float* y32, long ldy32, void* y16, long ldy16,
     int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
     int KH, int KW, int stride, int pad, int up,
-    float alpha, int ksplit,
+    float alpha, int ksplit, float* splitk_ws,
     int nbatch, long bs_x, long bs_w, long bs_y32, long bs_y16,
     void* stream) {
     ADAP_REQUIRE(x && w_packed && (y32 || y16), ADAP_ERR_SHAPE, "conv2d: null pointer");
@@ -305,8 +374,7 @@ extern "C" int adap_conv2d_nhwc(
                  "conv2d: kernel %dx%d", KH, KW);
     ADAP_REQUIRE(stride == 1 || stride == 2, ADAP_ERR_UNSUPPORTED, "conv2d: stride %d", stride);
     ADAP_REQUIRE(up >= 0 && up <= 2, ADAP_ERR_UNSUPPORTED, "conv2d: up %d", up);
-    ADAP_REQUIRE(ksplit >= 1 && (ksplit == 1 || (y32 && !y16)), ADAP_ERR_UNSUPPORTED,
-                 "conv2d: split-K needs an f32-only output");
+    ADAP_REQUIRE(ksplit >= 0 && ksplit <= 64, ADAP_ERR_UNSUPPORTED, "conv2d: ksplit %d", ksplit);
     ADAP_REQUIRE(nbatch >= 1, ADAP_ERR_SHAPE, "conv2d: nbatch");
     long M = (long)B * Hout * Wout;
     ADAP_REQUIRE(M < (1L << 31) && (long)B * Hin * Win < (1L << 31), ADAP_ERR_SHAPE, "conv2d: too many pixels");
@@ -318,17 +386,21 @@ extern "C" int adap_conv2d_nhwc(
     p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.up = up;
     p.ktiles_per_tap = (Cin + BK - 1) / BK;
     p.ktiles_total = KH * KW * p.ktiles_per_tap;
+    if (ksplit == 0) ksplit = (nbatch == 1 && splitk_ws) ? choose_ksplit(M, Cout, p.ktiles_total) : 1;
     p.ksplit = ksplit < p.ktiles_total ? ksplit : p.ktiles_total;
+    {   // every split must own at least one K tile (an empty split would leave its slab unwritten)
+        int per = (p.ktiles_total + p.ksplit - 1) / p.ksplit;
+        p.ksplit = (p.ktiles_total + per - 1) / per;
+    }
+    ADAP_REQUIRE(p.ksplit == 1 || (splitk_ws && nbatch == 1 && ((uintptr_t)splitk_ws % 16) == 0), ADAP_ERR_SHAPE,
+                 "conv2d: split-K needs a workspace (adap_conv2d_workspace_floats) and nbatch == 1");
+    p.ws = splitk_ws;
     p.ntiles_m = (int)((M + BM - 1) / BM);
     p.alpha = alpha;
     p.batch_stride_x = bs_x; p.batch_stride_w = bs_w; p.batch_stride_y32 = bs_y32; p.batch_stride_y16 = bs_y16;
     hipStream_t s = (hipStream_t)stream;
 
-    // channel-tile choice: 160 divides 320/640/960/1280/...; 128 for the VAE's powers of two; 64 for tiny Cout.
-    int bn;
-    if (Cout <= 64) bn = 64;
-    else if (Cout % 160 == 0) bn = 160;
-    else bn = 128;
+    const int bn = choose_bn(Cout);
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (x_dtype == 0) {
         if (bn == 160) return launch<160, true>(p, nbatch, s);

@@ -12,13 +12,13 @@ from .... import ops
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     if schedule == "linear":
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64, device="cpu") ** 2
     elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64, device="cpu")
     elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64, device="cpu") ** 0.5
     elif schedule == "cosine":
-        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        ts = torch.arange(n_timestep + 1, dtype=torch.float64, device="cpu") / n_timestep + cosine_s
         alphas = torch.cos(ts / (1 + cosine_s) * np.pi / 2).pow(2)
         alphas = alphas / alphas[0]
         betas = torch.clamp(1 - alphas[1:] / alphas[:-1], 0, 0.999)

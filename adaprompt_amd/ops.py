@@ -124,7 +124,7 @@ class PackedConv:
 
 
 def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=None, chan_add=None, residual=None,
-           out_f32=True, out_bf16=False, alpha=1.0, ksplit=1, y32=None, y16=None):
+           out_f32=True, out_bf16=False, alpha=1.0, ksplit=0, y32=None, y16=None):
     """x [B,H,W,Cin] (f32 / bf16) * w_packed [KH*KH][Cout][Cin] -> (y32, y16), each [B,Ho,Wo,Cout] or None.
     Linear layers: pass x as [B, N, 1, Cin]."""
     assert x.dim() == 4
@@ -141,13 +141,15 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
     else:
         Ho, Wo = out_hw
     dev = x.device
-    if ksplit > 1:
-        assert not out_bf16
-        if y32 is None:
-            y32 = torch.zeros(B, Ho, Wo, Cout, device=dev, dtype=F32)
+    if out_f32 and y32 is None:
+        y32 = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=F32)
+    ws = None
+    if ksplit == 0:
+        nws = _lib.call_long("adap_conv2d_workspace_floats", B, Ho, Wo, Cin, Cout, KH, KH)
     else:
-        if out_f32 and y32 is None:
-            y32 = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=F32)
+        nws = ksplit * B * Ho * Wo * Cout if ksplit > 1 else 0
+    if nws:
+        ws = torch.empty(nws, device=dev, dtype=F32)
     if out_bf16 and y16 is None:
         y16 = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=BF16)
     ldy32 = _rows_ld(y32)[1] if y32 is not None else 0
@@ -166,7 +168,7 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
     e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_conv2d_nhwc", x.data_ptr(), _dt(x), ldx, w_packed.data_ptr(), _ptr(bias), _ptr(chan_add), ld_ca,
               _ptr(residual), ldr, _ptr(y32), ldy32, _ptr(y16), ldy16, B, H, W, Cin, Ho, Wo, Cout, KH, KH, stride, pad,
-              up, float(alpha), ksplit, 1, 0, 0, 0, 0, _stream())
+              up, float(alpha), ksplit, _ptr(ws), 1, 0, 0, 0, 0, _stream())
     if e0 is not None:
         # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
         TIMER.stop("conv_gemm", 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0)
@@ -195,7 +197,7 @@ def batched_matmul_nt(a, b, out_dtype=F32, alpha=1.0):
     y = torch.empty(G, M, N, device=a.device, dtype=out_dtype)
     y32, y16 = (y, None) if out_dtype == F32 else (None, y)
     _lib.call("adap_conv2d_nhwc", a.data_ptr(), 1, K, b.data_ptr(), 0, 0, 0, 0, 0, _ptr(y32), N, _ptr(y16), N,
-              1, M, 1, K, M, 1, N, 1, 1, 1, 0, 0, float(alpha), 1, G, M * K, N * K, M * N, M * N, _stream())
+              1, M, 1, K, M, 1, N, 1, 1, 1, 0, 0, float(alpha), 1, 0, G, M * K, N * K, M * N, M * N, _stream())
     return y
 
 

@@ -215,7 +215,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or len(os.sched_getaffinity(0))
+        # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
+        threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         del ld, hook, reducer, opt
         torch.cuda.empty_cache()
         cpu = cpu_baseline(threads)

@@ -55,8 +55,10 @@ int adap_device_info(char* name, int name_cap, int* num_cus, char* arch, int arc
  *                   + bias[co] + chan_add[b*ld_ca + co] + residual[pixel*ldr + co]
  *
  * x: f32 or bf16 (x_dtype); w_packed: bf16 [KH*KW][Cout][Cin]; Cin % 8 == 0, Cout % 4 == 0.
- * y32 and/or y16 receive the result.  ksplit > 1 splits the K loop over grid.z and accumulates with
- * f32 atomics: y32 must be zero-filled by the caller and y16 must be NULL.
+ * y32 and/or y16 receive the result.  Split-K: ksplit = 1 none; ksplit > 1 forced; ksplit = 0 lets the library
+ * split the K loop over grid.z when the problem has too few pixel tiles to fill 256 CUs (only if splitk_ws is
+ * given).  Splits write fp32 slabs to splitk_ws (adap_conv2d_workspace_floats floats, or ksplit*M*Cout when
+ * forced) and a second kernel sums them in a fixed order and applies the epilogue: no float atomics.
  * nbatch > 1 runs independent problems (grid.y) with the given element strides (VAE mid attention).
  */
 int adap_conv2d_nhwc(const void* x, int x_dtype, long ldx, const void* w_packed,
@@ -65,9 +67,11 @@ int adap_conv2d_nhwc(const void* x, int x_dtype, long ldx, const void* w_packed,
                      float* y32, long ldy32, void* y16, long ldy16,
                      int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
                      int KH, int KW, int stride, int pad, int up,
-                     float alpha, int ksplit,
+                     float alpha, int ksplit, float* splitk_ws,
                      int nbatch, long bs_x, long bs_w, long bs_y32, long bs_y16,
                      void* stream);
+
+long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW);
 
 /* OIHW f32 (checkpoint layout, ddpm.py:321-344) -> bf16 [KH*KW][rows][cols].
  * mode 0 (forward): rows >= O, cols >= I, out[t][o][i] = w[o][i][ky][kx] (zero padded).

@@ -24,7 +24,7 @@ def test_bad_arguments_return_status_not_crash():
     """argument validation happens on the host before any launch, so it is checkable without a GPU."""
     lib = _lib.load()
     # Cin = 12 is not a multiple of 8 -> ADAP_ERR_ALIGN, message set
-    rc = lib.adap_conv2d_nhwc(16, 1, 12, 16, 0, 0, 0, 0, 0, 16, 8, 0, 0, 1, 4, 4, 12, 4, 4, 8, 1, 1, 1, 0, 0, 1.0, 1,
+    rc = lib.adap_conv2d_nhwc(16, 1, 12, 16, 0, 0, 0, 0, 0, 16, 8, 0, 0, 1, 4, 4, 12, 4, 4, 8, 1, 1, 1, 0, 0, 1.0, 1, 0,
                               1, 0, 0, 0, 0, 0)
     assert rc == -2 and b"Cin" in lib.adap_last_error()
     with pytest.raises(_lib.HipError):

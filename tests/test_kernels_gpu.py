@@ -94,8 +94,13 @@ def test_conv2d_epilogue_and_splitk():
     xin = nhwc(x).to(torch.bfloat16)
     y32, _ = ops.conv2d(xin, pk.fwd, Cout, 3, 1, 1, bias=pk.bias, chan_add=emb, residual=nhwc(res), alpha=0.5)
     assert rel(nchw(y32), ref) < 2e-5
-    y32s, _ = ops.conv2d(xin, pk.fwd, Cout, 3, 1, 1, bias=pk.bias, chan_add=emb, residual=nhwc(res), alpha=0.5, ksplit=4)
-    assert rel(nchw(y32s), ref) < 2e-5
+    for ks in (4, 0):          # forced and automatic split-K (slab reduce: bit-reproducible)
+        y32s, y16s = ops.conv2d(xin, pk.fwd, Cout, 3, 1, 1, bias=pk.bias, chan_add=emb, residual=nhwc(res), alpha=0.5,
+                                ksplit=ks, out_bf16=True)
+        assert rel(nchw(y32s), ref) < 2e-5
+        assert rel(nchw(y16s.float()), ref) < 4e-3
+        y32t, _ = ops.conv2d(xin, pk.fwd, Cout, 3, 1, 1, bias=pk.bias, chan_add=emb, residual=nhwc(res), alpha=0.5, ksplit=ks)
+        assert torch.equal(y32s, y32t)
 
 
 @pytest.mark.parametrize("case", [(2, 320, 320, 16, 3, 1, 1, 0), (2, 640, 320, 8, 1, 1, 0, 0),
