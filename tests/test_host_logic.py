@@ -1,0 +1,131 @@
+"""Host-side logic of the drop-in boundary, checkable without a GPU: config targets, state-dict
+namespace, flag plumbing, schedule buffers, checkpoint API, loud failure without the device."""
+import os
+
+import pytest
+import torch
+
+from adaprompt_amd import synth
+from oracle import ldm_oracle as O
+
+NARROW = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+
+
+def test_reference_yaml_targets_resolve_to_this_package():
+    from adaprompt_amd.ldm.util import instantiate_from_config, get_obj_from_str
+    import ldm  # noqa: F401  (alias package of this repo)
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.models.autoencoder import AutoencoderKL
+    import adaprompt_amd.ldm.modules.diffusionmodules.openaimodel as mine
+    assert UNetModel is mine.UNetModel
+    assert get_obj_from_str("ldm.models.autoencoder.AutoencoderKL") is AutoencoderKL
+    m = instantiate_from_config({"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": NARROW})
+    assert isinstance(m, mine.UNetModel)
+    with pytest.raises(KeyError):
+        instantiate_from_config({"params": {}})
+
+
+def test_state_dict_namespace_matches_reference_checkpoints():
+    """686 UNet tensors / 859 520 964 parameters, named as in the reference."""
+    from adaprompt_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    with torch.device("meta"):
+        m = UNetModel(**synth.SD15_UNET)
+    sd = m.state_dict()
+    ref = dict(synth.unet_param_shapes(**synth.SD15_UNET))
+    assert set(sd) == set(ref) and len(sd) == 686
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    assert sum(v.numel() for v in sd.values()) == 859_520_964
+    from adaprompt_amd.ldm.models.autoencoder import AutoencoderKL
+    with torch.device("meta"):
+        v = AutoencoderKL(dict(synth.SD15_VAE_DD), None, 4)
+    enc = {k: v_ for k, v_ in v.state_dict().items() if not k.startswith("post_quant")}
+    refv = dict(synth.vae_encoder_param_shapes(**synth.SD15_VAE_DD))
+    assert set(enc) == set(refv)
+    assert sum(p.numel() for n, p in enc.items() if n.startswith("encoder.")) == 34_163_592
+
+
+def test_cross_attn_flag_plumbing():
+    """set_cross_attn_flags: layerwise arrays, subset of layers, and restore (openaimodel.py:722-824)."""
+    from adaprompt_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel, DISTILL_LAYERS
+    with torch.device("meta"):
+        m = UNetModel(**NARROW)
+    mods = dict(m._ca_modules())
+    assert sorted(mods) == [1, 2, 4, 5, 7, 8, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24]
+    old, _ = m.set_cross_attn_flags(ca_flag_dict={"save_attn_vars": True}, ca_layer_indices=DISTILL_LAYERS)
+    assert old == {"save_attn_vars": False}
+    on = [li for li, s in mods.items() if s.transformer_blocks[0].attn2.save_attn_vars]
+    assert on == DISTILL_LAYERS
+    m.set_cross_attn_flags(ca_flag_dict=old, ca_layer_indices=DISTILL_LAYERS)
+    assert not any(s.transformer_blocks[0].attn2.save_attn_vars for s in mods.values())
+    sizes = list(range(16))
+    m.set_cross_attn_flags(ca_flag_dict={"use_conv_attn_kernel_size:layerwise": sizes})
+    assert mods[12].transformer_blocks[0].attn2.use_conv_attn_kernel_size == 6
+    assert mods[24].transformer_blocks[0].attn2.use_conv_attn_kernel_size == 15
+
+
+def test_schedule_buffers_match_oracle():
+    from adaprompt_amd.ldm.models.diffusion.ddpm import DDPM
+    with torch.device("meta"):
+        pass
+    d = DDPM({"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": NARROW},
+             linear_start=0.00085, linear_end=0.012)
+    s = O.make_schedule()
+    for k, v in s.items():
+        assert torch.equal(getattr(d, k), v), k
+    assert d.num_timesteps == 1000
+
+
+def test_checkpoint_api_roundtrip(tmp_path):
+    """.ckpt (['state_dict']) and .safetensors, strict=False with missing/unexpected reporting (ddpm.py:321-344)."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    cfgs = ({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+            {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": NARROW})
+    sd = {**synth.synthetic_unet_state_dict(NARROW), **synth.synthetic_vae_state_dict(vdd)}
+    sd["cond_stage_model.transformer.text_model.final_layer_norm.weight"] = torch.ones(4)     # an "unexpected" key
+    ck = os.path.join(tmp_path, "m.ckpt")
+    torch.save({"state_dict": sd, "global_step": 7}, ck)
+    ld = LatentDiffusion(*cfgs)
+    missing, unexpected = ld.init_from_ckpt(ck)
+    assert unexpected == ["cond_stage_model.transformer.text_model.final_layer_norm.weight"]
+    buffers = {n for n, _ in ld.named_buffers()}
+    assert all(k.startswith("first_stage_model.post_quant_conv") or k in buffers for k in missing)
+    k = "model.diffusion_model.output_blocks.5.1.transformer_blocks.0.attn2.to_k.weight"
+    assert torch.equal(ld.state_dict()[k], sd[k])
+    from safetensors.torch import save_file
+    st = os.path.join(tmp_path, "m.safetensors")
+    save_file({k_: v.contiguous() for k_, v in sd.items()}, st)
+    ld2 = LatentDiffusion(*cfgs)
+    ld2.init_from_ckpt(st, ignore_keys=["cond_stage_model"])
+    assert torch.equal(ld2.state_dict()[k], sd[k])
+    ld2.freeze_unet()
+    assert not any(p.requires_grad for p in ld2.model.parameters())
+    assert not any(p.requires_grad for p in ld2.first_stage_model.parameters())
+
+
+def test_no_cpu_fallback():
+    """the product path refuses CPU tensors instead of silently computing somewhere else."""
+    from adaprompt_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from adaprompt_amd.ldm.models.autoencoder import AutoencoderKL
+    m = UNetModel(**NARROW)
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1}
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        m(torch.zeros(1, 4, 64, 64), torch.zeros(1, dtype=torch.long), context=torch.zeros(16, 77, 128), extra_info=extra)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, 64, 64), torch.zeros(1, dtype=torch.long), context=torch.zeros(16, 77, 128),
+          extra_info={"use_layerwise_context": False})
+    v = AutoencoderKL(dict(synth.SD15_VAE_DD, ch=32, resolution=64), None, 4)
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        v.encode(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError):
+        v.decode(torch.zeros(1, 4, 8, 8))
+
+
+def test_hook_standin_contract():
+    from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
+    h = SyntheticSubjBasisGenerator(n_params=4 * 16 * 77 * 32, dim=32)
+    ids = torch.nn.functional.normalize(torch.randn(3, 512), dim=-1)
+    ctx, prompts, extra = make_cond_fn(h)({"zs_id_embs": ids})
+    assert ctx.shape == (48, 77, 32) and extra["use_layerwise_context"] and extra["capture_distill_attn"]
+    ctx.sum().backward()
+    assert h.bases.grad is not None and h.bases.grad.abs().sum() > 0

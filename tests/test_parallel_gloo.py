@@ -1,0 +1,81 @@
+"""The data-parallel gradient exchange on CPU: world_size 2, gloo backend (the GPU path uses the same code
+over RCCL).  Checks the DDP semantics of the reference: gradients are averaged over the ranks after EVERY
+micro-batch backward and accumulated over 2 micro-batches before the step."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from adaprompt_amd.parallel import GradReducer, init_distributed
+    r, w, _ = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 4)
+    extra = torch.nn.Parameter(torch.zeros(3))            # a trainable parameter that gets no gradient (unused-param tolerance)
+    params = list(lin.parameters()) + [extra]
+    red = GradReducer(params, bucket_bytes=64)            # tiny buckets: several collectives
+    assert lin.weight.grad.data_ptr() == red.flat.data_ptr()
+    xs = [torch.full((2, 8), float(rank + 1 + 10 * i)) for i in range(2)]
+    local = []
+    for i in range(2):
+        red.wait()                                    # the previous exchange must land before backward writes
+        before = red.flat.clone()
+        lin(xs[i]).sum().backward()
+        local.append((red.flat - before).clone())
+        red.reduce()
+    red.wait()
+    # expected: mean over ranks of each micro-batch gradient, summed over the 2 micro-batches
+    gathered = [[torch.zeros_like(local[i]) for _ in range(world)] for i in range(2)]
+    for i in range(2):
+        dist.all_gather(gathered[i], local[i])
+    expect = sum(torch.stack(gathered[i]).mean(0) for i in range(2))
+    ok = torch.allclose(red.flat, expect, rtol=1e-6, atol=1e-6)
+    # replicas stay identical after the step
+    opt = torch.optim.SGD(params, lr=0.1)
+    opt.step()
+    wl = [torch.zeros_like(lin.weight) for _ in range(world)]
+    dist.all_gather(wl, lin.weight.detach())
+    same = torch.equal(wl[0], wl[1])
+    red.zero()
+    q.put((rank, bool(ok), bool(same), float(red.flat.abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, same, z in res:
+        assert ok and same and z == 0.0, (rank, ok, same, z)
+
+
+def test_single_process_reducer_is_a_noop():
+    from adaprompt_amd.parallel import GradReducer
+    lin = torch.nn.Linear(4, 2)
+    red = GradReducer(lin.parameters())
+    lin(torch.ones(1, 4)).sum().backward()
+    g = red.flat.clone()
+    red.reduce()
+    red.wait()
+    assert torch.equal(red.flat, g) and red.world == 1
