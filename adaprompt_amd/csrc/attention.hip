@@ -92,6 +92,36 @@ __device__ __forceinline__ void stage_tile(char* dst, int stride, int nch, const
     }
 }
 
+// Register-staged prefetch of a [64 x NCH*8] bf16 tile: the global loads of tile t+1 are issued before tile t is
+// multiplied and written to LDS after it (guide T14), so HBM/L2 latency hides under the MFMA phase.
+template <int NCH>
+struct TileRegs {
+    static constexpr int CPT = (64 * NCH + 255) / 256;
+    uint4 v[CPT];
+};
+
+template <int NCH>
+__device__ __forceinline__ void tile_load(TileRegs<NCH>& r, const uint16_t* src, long ld, int nvalid, int d, int tid) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<NCH>::CPT; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx / NCH, ch = idx - row * NCH;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (idx < 64 * NCH && row < nvalid && ch * 8 < d) v = *(const uint4*)(src + (size_t)row * ld + ch * 8);
+        r.v[i] = v;
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void tile_store(const TileRegs<NCH>& r, char* dst, int stride, int tid) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<NCH>::CPT; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx / NCH, ch = idx - row * NCH;
+        if (idx < 64 * NCH) *(uint4*)(dst + row * stride + ch * 16) = r.v[i];
+    }
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -131,11 +161,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
     const int ntiles = (p.M + 63) / 64;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int key0 = kt * 64;
-        const int nvalid = min(64, p.M - key0);
-        stage_tile(sK, KSTRIDE, G::NCH, kb + (size_t)key0 * p.ldk, p.ldk, 64, nvalid, d, tid);
-        stage_tile(sV, VSTRIDE, (d + 7) / 8, vb + (size_t)key0 * p.ldv, p.ldv, 64, nvalid, d, tid);
+    TileRegs<G::NCH> rK, rV;
+    auto key_bias = [&](int key0) {
         if (tid < 64) {
             int key = key0 + tid;
             float bias = 0.f;
@@ -143,7 +170,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
         }
-        __syncthreads();
+    };
+    tile_load(rK, kb, p.ldk, min(64, p.M), d, tid);
+    tile_load(rV, vb, p.ldv, min(64, p.M), d, tid);
+    tile_store(rK, sK, KSTRIDE, tid);
+    tile_store(rV, sV, VSTRIDE, tid);
+    key_bias(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const bool more = kt + 1 < ntiles;
+        if (more) {
+            const int key1 = (kt + 1) * 64;
+            tile_load(rK, kb + (size_t)key1 * p.ldk, p.ldk, min(64, p.M - key1), d, tid);
+            tile_load(rV, vb + (size_t)key1 * p.ldv, p.ldv, min(64, p.M - key1), d, tid);
+        }
 
         f32x16 S[2];
 #pragma unroll
@@ -202,6 +242,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 }
             }
         __syncthreads();
+        if (more) {
+            tile_store(rK, sK, KSTRIDE, tid);
+            tile_store(rV, sV, VSTRIDE, tid);
+            key_bias((kt + 1) * 64);
+            __syncthreads();
+        }
     }
     const float ltot = l + __shfl_xor(l, 32, 64);
     const float inv = 1.0f / ltot;
@@ -302,11 +348,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
     const int ntiles = (p.M + 63) / 64;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int key0 = kt * 64;
-        const int nvalid = min(64, p.M - key0);
-        stage_tile(sK, KSTRIDE, G::NCH, kb + (size_t)key0 * p.ldk, p.ldk, 64, nvalid, d, tid);
-        stage_tile(sV, KSTRIDE, G::NCH, vb + (size_t)key0 * p.ldv, p.ldv, 64, nvalid, d, tid);
+    TileRegs<G::NCH> rK, rV;
+    auto key_bias = [&](int key0) {
         if (tid < 64) {
             int key = key0 + tid;
             float bias = 0.f;
@@ -314,7 +357,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
         }
-        __syncthreads();
+    };
+    tile_load(rK, kb, p.ldk, min(64, p.M), d, tid);
+    tile_load(rV, vb, p.ldv, min(64, p.M), d, tid);
+    tile_store(rK, sK, KSTRIDE, tid);
+    tile_store(rV, sV, KSTRIDE, tid);
+    key_bias(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const bool more = kt + 1 < ntiles;
+        if (more) {
+            const int key1 = (kt + 1) * 64;
+            tile_load(rK, kb + (size_t)key1 * p.ldk, p.ldk, min(64, p.M - key1), d, tid);
+            tile_load(rV, vb + (size_t)key1 * p.ldv, p.ldv, min(64, p.M - key1), d, tid);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 S, dP;
@@ -348,6 +404,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
             }
         }
         __syncthreads();
+        if (more) {
+            tile_store(rK, sK, KSTRIDE, tid);
+            tile_store(rV, sV, KSTRIDE, tid);
+            key_bias((kt + 1) * 64);
+            __syncthreads();
+        }
     }
     if (q < p.N) {
 #pragma unroll
@@ -418,17 +480,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const float* lseb = p.lse + ((size_t)b * p.H + head) * p.N;
     const float* dlb = p.delta + ((size_t)b * p.H + head) * p.N;
     const int ntiles = (p.N + 63) / 64;
-    for (int qt = 0; qt < ntiles; ++qt) {
-        const int q0 = qt * 64;
-        const int nvalid = min(64, p.N - q0);
-        stage_tile(sQ, QSTRIDE, G::NCH, qb + (size_t)q0 * p.ldq, p.ldq, 64, nvalid, d, tid);
-        stage_tile(sDO, QSTRIDE, G::NCH, dob + (size_t)q0 * p.lddo, p.lddo, 64, nvalid, d, tid);
+    TileRegs<G::NCH> rQ, rDO;
+    float rl = 0.f, rd = 0.f;
+    auto row_stats_load = [&](int q0) {
         if (tid < 64) {
-            bool ok = tid < nvalid;
-            sLse[tid] = ok ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
-            sDl[tid] = ok ? dlb[q0 + tid] : 0.f;
+            bool ok = q0 + tid < p.N;
+            rl = ok ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
+            rd = ok ? dlb[q0 + tid] : 0.f;
         }
-        __syncthreads();
+    };
+    tile_load(rQ, qb, p.ldq, min(64, p.N), d, tid);
+    tile_load(rDO, dob, p.lddo, min(64, p.N), d, tid);
+    row_stats_load(0);
+    tile_store(rQ, sQ, QSTRIDE, tid);
+    tile_store(rDO, sDO, QSTRIDE, tid);
+    if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
+    __syncthreads();
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const bool more = qt + 1 < ntiles;
+        if (more) {
+            const int q1 = (qt + 1) * 64;
+            tile_load(rQ, qb + (size_t)q1 * p.ldq, p.ldq, min(64, p.N - q1), d, tid);
+            tile_load(rDO, dob + (size_t)q1 * p.lddo, p.lddo, min(64, p.N - q1), d, tid);
+            row_stats_load(q1);
+        }
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             f32x16 S, dP;
@@ -468,6 +543,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
             }
         }
         __syncthreads();
+        if (more) {
+            tile_store(rQ, sQ, QSTRIDE, tid);
+            tile_store(rDO, sDO, QSTRIDE, tid);
+            if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
+            __syncthreads();
+        }
     }
     if (key < p.M) {
 #pragma unroll

@@ -48,6 +48,7 @@ struct ConvParams {
     int ntiles_m;                  // ceil(M / 128)
     float alpha;
     float* ws;              // split-K slabs [ksplit][M][Cout] f32
+    unsigned x_bytes, w_bytes;   // extents of one batch item's activation / weight block (buffer descriptors)
     long batch_stride_x;    // batched mode (B2 > 1 via grid.y): element strides per batch item
     long batch_stride_w;
     long batch_stride_y32;
@@ -56,6 +57,8 @@ struct ConvParams {
 
 #define BM 128
 #define BK 64
+
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int BN, bool A_F32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
@@ -116,9 +119,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     const int Heff = p.up ? 2 * p.Hin : p.Hin;
     const int Weff = p.up ? 2 * p.Win : p.Win;
 
-    uint4 ra[4], rb[BROWS];
+    // One staged K tile in registers.  f32 activations stay raw until the LDS write (converting at load time
+    // would put the load's s_waitcnt at the issue point and serialise the pipeline).
+    struct Stage {
+        float4 af[4][2];
+        uint4 b[BROWS];
+    };
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](Stage& st, int kt) {
         int tap = kt / p.ktiles_per_tap;
         int c = (kt - tap * p.ktiles_per_tap) * BK + chunk * 8;
         int ky = tap / p.KW, kx = tap - ky * p.KW;
@@ -129,21 +137,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
             bool ok = cok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;
             if (p.up == 2) ok = ok && !((iy | ix) & 1);
             if (p.up) { iy >>= 1; ix >>= 1; }
-            uint4 v = make_uint4(0, 0, 0, 0);
+            size_t off = ok ? (size_t)(a_boff[i] + iy * p.Win + ix) * p.ldx + c : 0;
+            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
             if (ok) {
-                size_t off = (size_t)(a_boff[i] + iy * p.Win + ix) * p.ldx + c;
-                if (A_F32) {
-                    const float4* src = (const float4*)(xbase + off * 4);
-                    float4 f0 = src[0], f1 = src[1];
-                    v.x = pack_bf16x2(f0.x, f0.y);
-                    v.y = pack_bf16x2(f0.z, f0.w);
-                    v.z = pack_bf16x2(f1.x, f1.y);
-                    v.w = pack_bf16x2(f1.z, f1.w);
-                } else {
-                    v = *(const uint4*)(xbase + off * 2);
-                }
+                const float4* src = (const float4*)(xbase + off * 4);
+                f0 = src[0];
+                f1 = src[1];
             }
-            ra[i] = v;
+            st.af[i][0] = f0;
+            st.af[i][1] = f1;
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
@@ -151,22 +153,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (cok && n < p.Cout)
                 v = *(const uint4*)(wbase + ((size_t)tap * p.Cout + n) * p.Cin + c);
-            rb[i] = v;
+            st.b[i] = v;
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](Stage& st, int buf) {
         char* a = sA + buf * (BM * 128);
         char* b = sB + buf * (BN * 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = srow + 32 * i;
-            *(uint4*)(a + r * 128 + ((chunk ^ (r & 7)) << 4)) = ra[i];
+            uint4 v;
+            const float4 f0 = st.af[i][0], f1 = st.af[i][1];
+            v.x = pack_bf16x2(f0.x, f0.y);
+            v.y = pack_bf16x2(f0.z, f0.w);
+            v.z = pack_bf16x2(f1.x, f1.y);
+            v.w = pack_bf16x2(f1.z, f1.w);
+            *(uint4*)(a + r * 128 + ((chunk ^ (r & 7)) << 4)) = v;
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             int r = srow + 32 * i;
-            *(uint4*)(b + r * 128 + ((chunk ^ (r & 7)) << 4)) = rb[i];
+            *(uint4*)(b + r * 128 + ((chunk ^ (r & 7)) << 4)) = st.b[i];
         }
     };
 
@@ -179,15 +187,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
 
-    load_tile(kt_begin);
-    store_tile(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1 < kt_end);
-        if (more) load_tile(kt + 1);
-        const char* a = sA + cur * (BM * 128);
-        const char* b = sB + cur * (BN * 128);
+    auto compute = [&](int buf) {
+        const char* a = sA + buf * (BM * 128);
+        const char* b = sB + buf * (BN * 128);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 fw[MT], fx[PT];
@@ -208,9 +210,70 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
                 for (int j = 0; j < PT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
+    };
+
+    if constexpr (A_F32) {
+        // f32 activations (gradients, the raw residual stream): register staging with the bf16 conversion on the
+        // way into LDS (guide T14): loads of tile k+1 are issued before tile k is multiplied, written after.
+        Stage S0;
+        load_tile(S0, kt_begin);
+        store_tile(S0, 0);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = (kt + 1 < kt_end);
+            if (more) load_tile(S0, kt + 1);
+            compute(cur);
+            if (more) store_tile(S0, cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // bf16 activations: LDS-DMA (global_load_lds_dwordx4) straight into the swizzled tile image -- no staging
+        // registers and no ds_write traffic (register staging of a 128x160x64 tile needs 115 B/clk of ds_write
+        // against ~80 B/clk available, so it caps the MFMA pipe at ~2/3).  The LDS destination of one wave
+        // instruction is linear (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk
+        // (guide rule 21); out-of-image / out-of-range lanes read a zero block instead.
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int rsw = (lane >> 3) & 7;                 // (row & 7) of every row this lane stages
+        const int lchunk = (lane & 7) ^ rsw;             // logical 16-B chunk whose data lands in physical chunk lane&7
+        // buffer descriptors (wave-uniform): an out-of-range offset makes the hardware deliver zeros, which is the
+        // conv's zero padding, the ragged last pixel/channel tile and the Cin tail -- no branch, one DMA per row group
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
+        constexpr unsigned OOB = 0x80000000u;
+        auto stage = [&](int buf, int kt) {
+            int tap = kt / p.ktiles_per_tap;
+            int c = (kt - tap * p.ktiles_per_tap) * BK + lchunk * 8;
+            int ky = tap / p.KW, kx = tap - ky * p.KW;
+            bool cok = c < p.Cin;
+            char* abase = sA + buf * (BM * 128) + wv * 1024;
+            char* bbase = sB + buf * (BN * 128) + wv * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                bool ok = cok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;
+                if (p.up == 2) ok = ok && !((iy | ix) & 1);
+                if (p.up) { iy >>= 1; ix >>= 1; }
+                unsigned voff = ok ? (unsigned)(((a_boff[i] + iy * p.Win + ix) * (int)p.ldx + c) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * 4096), 16, voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                int n = n0 + srow + 32 * i;
+                unsigned voff = (cok && n < p.Cout) ? (unsigned)(((tap * p.Cout + n) * p.Cin + c) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * 4096), 16, voff, 0, 0, 0);
+            }
+        };
+        stage(0, kt_begin);
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile kt has landed
+            __syncthreads();                                      // ... everyone's has, and compute(kt-1) is over
+            if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
+            compute(cur);
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
@@ -325,7 +388,7 @@ static int choose_bn(int Cout) {
 static int choose_ksplit(long M, int Cout, int ktiles_total) {
     int bn = choose_bn(Cout);
     long blocks = ((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
-    if (blocks >= 384) return 1;
+    if (blocks >= 384 || ktiles_total < 24) return 1;     // short-K layers: the reduce pass would cost more than it saves
     int ks = (int)((512 + blocks - 1) / blocks);
     int cap = ktiles_total / 4;
     if (ks > cap) ks = cap;
@@ -395,6 +458,14 @@ extern "C" int adap_conv2d_nhwc(
     ADAP_REQUIRE(p.ksplit == 1 || (splitk_ws && nbatch == 1 && ((uintptr_t)splitk_ws % 16) == 0), ADAP_ERR_SHAPE,
                  "conv2d: split-K needs a workspace (adap_conv2d_workspace_floats) and nbatch == 1");
     p.ws = splitk_ws;
+    {
+        long xb = ((long)B * Hin * Win - 1) * ldx + Cin, wb = (long)KH * KW * Cout * Cin;
+        xb *= (x_dtype == 0 ? 4 : 2);
+        wb *= 2;
+        ADAP_REQUIRE(xb < (1L << 31) && wb < (1L << 31), ADAP_ERR_SHAPE, "conv2d: operand larger than 2 GiB");
+        p.x_bytes = (unsigned)xb;
+        p.w_bytes = (unsigned)wb;
+    }
     p.ntiles_m = (int)((M + BM - 1) / BM);
     p.alpha = alpha;
     p.batch_stride_x = bs_x; p.batch_stride_w = bs_w; p.batch_stride_y32 = bs_y32; p.batch_stride_y16 = bs_y16;

@@ -15,6 +15,8 @@
 
 #define GN_G 32
 #define GN_MAXSLOT 3     // C <= 3072
+#define GN_UNR 4         // pixel rows in flight per thread
+#define GN_UNRB 2        // ... in the backward (two input streams)
 
 struct GnGeom {
     int Q;        // float4 quads per pixel row (C/4)
@@ -73,19 +75,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         for (int e = 0; e < 4; ++e) { s[k][e] = 0.f; ss[k][e] = 0.f; }
     if (r0 < g.rpp) {
         const float* xb = x + (size_t)b * HW * ldx;
-        for (int r = row_begin + r0; r < row_end; r += g.rpp) {
-            const float* xr = xb + (size_t)r * ldx;
+        // GN_UNR rows in flight per thread: the kernel is a pure HBM stream, memory-level parallelism is the lever
+        for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNR) {
+            float4 v[GN_UNR][GN_MAXSLOT];
 #pragma unroll
-            for (int k = 0; k < GN_MAXSLOT; ++k) {
-                int q = lir + k * g.TPR;
-                if (k < g.nslots && q < g.Q) {
-                    float4 v = *(const float4*)(xr + 4 * q);
-                    s[k][0] += v.x; ss[k][0] += v.x * v.x;
-                    s[k][1] += v.y; ss[k][1] += v.y * v.y;
-                    s[k][2] += v.z; ss[k][2] += v.z * v.z;
-                    s[k][3] += v.w; ss[k][3] += v.w * v.w;
+            for (int u = 0; u < GN_UNR; ++u) {
+                const int rr = r + u * g.rpp;
+#pragma unroll
+                for (int k = 0; k < GN_MAXSLOT; ++k) {
+                    int q = lir + k * g.TPR;
+                    v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rr < row_end && k < g.nslots && q < g.Q) v[u][k] = *(const float4*)(xb + (size_t)rr * ldx + 4 * q);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < GN_UNR; ++u)
+#pragma unroll
+                for (int k = 0; k < GN_MAXSLOT; ++k) {
+                    s[k][0] += v[u][k].x; ss[k][0] += v[u][k].x * v[u][k].x;
+                    s[k][1] += v[u][k].y; ss[k][1] += v[u][k].y * v[u][k].y;
+                    s[k][2] += v[u][k].z; ss[k][2] += v[u][k].z * v[u][k].z;
+                    s[k][3] += v[u][k].w; ss[k][3] += v[u][k].w * v[u][k].w;
+                }
         }
     }
     gn_park(smA, s, tid);
@@ -151,25 +162,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int row_begin = chunk * rows_per_chunk;
     const int row_end = min(HW, row_begin + rows_per_chunk);
     const size_t boff = (size_t)b * HW;
-    for (int r = row_begin + r0; r < row_end; r += g.rpp) {
-        const float* xr = x + (boff + r) * ldx;
+    for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNR) {
+        float4 v[GN_UNR][GN_MAXSLOT];
 #pragma unroll
-        for (int k = 0; k < GN_MAXSLOT; ++k) {
-            int q = lir + k * g.TPR;
-            if (k < g.nslots && q < g.Q) {
-                float4 v = *(const float4*)(xr + 4 * q);
-                float o[4] = {v.x * sc[k][0] + sh[k][0], v.y * sc[k][1] + sh[k][1], v.z * sc[k][2] + sh[k][2],
-                              v.w * sc[k][3] + sh[k][3]};
-                if (act) {
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int rr = r + u * g.rpp;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
-                }
-                if (y32) *(float4*)(y32 + (boff + r) * ldy32 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
-                if (y16) {
-                    uint2 w;
-                    w.x = pack_bf16x2(o[0], o[1]);
-                    w.y = pack_bf16x2(o[2], o[3]);
-                    *(uint2*)(y16 + (boff + r) * ldy16 + 4 * q) = w;
+            for (int k = 0; k < GN_MAXSLOT; ++k) {
+                int q = lir + k * g.TPR;
+                if (rr < row_end && k < g.nslots && q < g.Q) v[u][k] = *(const float4*)(x + (boff + rr) * ldx + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int rr = r + u * g.rpp;
+#pragma unroll
+            for (int k = 0; k < GN_MAXSLOT; ++k) {
+                int q = lir + k * g.TPR;
+                if (rr < row_end && k < g.nslots && q < g.Q) {
+                    float o[4] = {v[u][k].x * sc[k][0] + sh[k][0], v[u][k].y * sc[k][1] + sh[k][1],
+                                  v[u][k].z * sc[k][2] + sh[k][2], v[u][k].w * sc[k][3] + sh[k][3]};
+                    if (act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+                    }
+                    if (y32) *(float4*)(y32 + (boff + rr) * ldy32 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (y16) {
+                        uint2 w;
+                        w.x = pack_bf16x2(o[0], o[1]);
+                        w.y = pack_bf16x2(o[2], o[3]);
+                        *(uint2*)(y16 + (boff + rr) * ldy16 + 4 * q) = w;
+                    }
                 }
             }
         }
@@ -270,23 +293,38 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
         const int row_begin = chunk * rows_per_chunk;
         const int row_end = min(HW, row_begin + rows_per_chunk);
         const size_t boff = (size_t)b * HW;
-        for (int r = row_begin + r0; r < row_end; r += g.rpp) {
+        for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNRB) {
+            float4 xv[GN_UNRB][GN_MAXSLOT];
+            float d[GN_UNRB][GN_MAXSLOT][4];
 #pragma unroll
-            for (int k = 0; k < GN_MAXSLOT; ++k) {
-                int q = lir + k * g.TPR;
-                if (k < g.nslots && q < g.Q) {
-                    float4 xv = *(const float4*)(x + (boff + r) * ldx + 4 * q);
-                    float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                    float d[4];
-                    load_dy4<DY_BF16>(dy, (boff + r) * lddy + 4 * q, d);
+            for (int u = 0; u < GN_UNRB; ++u) {
+                const int rr = r + u * g.rpp;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float xh = xs[e] * sc[k][e] + sh[k][e];
-                        float dz = d[e];
-                        if (act) dz *= dsilu_f(xh * ga[k][e] + be[k][e]);
-                        float dyh = dz * ga[k][e];
-                        sA[k][e] += dyh;
-                        sB[k][e] += dyh * xh;
+                for (int k = 0; k < GN_MAXSLOT; ++k) {
+                    int q = lir + k * g.TPR;
+                    if (rr < row_end && k < g.nslots && q < g.Q) {
+                        xv[u][k] = *(const float4*)(x + (boff + rr) * ldx + 4 * q);
+                        load_dy4<DY_BF16>(dy, (boff + rr) * lddy + 4 * q, d[u][k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GN_UNRB; ++u) {
+                const int rr = r + u * g.rpp;
+#pragma unroll
+                for (int k = 0; k < GN_MAXSLOT; ++k) {
+                    int q = lir + k * g.TPR;
+                    if (rr < row_end && k < g.nslots && q < g.Q) {
+                        float xs[4] = {xv[u][k].x, xv[u][k].y, xv[u][k].z, xv[u][k].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float xh = xs[e] * sc[k][e] + sh[k][e];
+                            float dz = d[u][k][e];
+                            if (act) dz *= dsilu_f(xh * ga[k][e] + be[k][e]);
+                            float dyh = dz * ga[k][e];
+                            sA[k][e] += dyh;
+                            sB[k][e] += dyh * xh;
+                        }
                     }
                 }
             }
@@ -347,36 +385,52 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
     const int row_begin = chunk * rows_per_chunk;
     const int row_end = min(HW, row_begin + rows_per_chunk);
     const size_t boff = (size_t)b * HW;
-    for (int r = row_begin + r0; r < row_end; r += g.rpp) {
+    for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNRB) {
+        float4 xv[GN_UNRB][GN_MAXSLOT], acc4[GN_UNRB][GN_MAXSLOT];
+        float d[GN_UNRB][GN_MAXSLOT][4];
 #pragma unroll
-        for (int k = 0; k < GN_MAXSLOT; ++k) {
-            int q = lir + k * g.TPR;
-            if (k < g.nslots && q < g.Q) {
-                float4 xv = *(const float4*)(x + (boff + r) * ldx + 4 * q);
-                float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                float d[4], o[4];
-                load_dy4<DY_BF16>(dy, (boff + r) * lddy + 4 * q, d);
+        for (int u = 0; u < GN_UNRB; ++u) {
+            const int rr = r + u * g.rpp;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float xh = xs[e] * sc[k][e] + sh[k][e];
-                    float dz = d[e];
-                    if (act) dz *= dsilu_f(xh * ga[k][e] + be[k][e]);
-                    float dyh = dz * ga[k][e];
-                    o[e] = sc[k][e] * (dyh - mA[k][e] - xh * mB[k][e]);
+            for (int k = 0; k < GN_MAXSLOT; ++k) {
+                int q = lir + k * g.TPR;
+                if (rr < row_end && k < g.nslots && q < g.Q) {
+                    xv[u][k] = *(const float4*)(x + (boff + rr) * ldx + 4 * q);
+                    load_dy4<DY_BF16>(dy, (boff + rr) * lddy + 4 * q, d[u][k]);
+                    if (dx32 && accumulate) acc4[u][k] = *(const float4*)(dx32 + (boff + rr) * lddx32 + 4 * q);
                 }
-                if (dx32) {
-                    float* dst = dx32 + (boff + r) * lddx32 + 4 * q;
-                    if (accumulate) {
-                        float4 t = *(const float4*)dst;
-                        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNRB; ++u) {
+            const int rr = r + u * g.rpp;
+#pragma unroll
+            for (int k = 0; k < GN_MAXSLOT; ++k) {
+                int q = lir + k * g.TPR;
+                if (rr < row_end && k < g.nslots && q < g.Q) {
+                    float xs[4] = {xv[u][k].x, xv[u][k].y, xv[u][k].z, xv[u][k].w};
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float xh = xs[e] * sc[k][e] + sh[k][e];
+                        float dz = d[u][k][e];
+                        if (act) dz *= dsilu_f(xh * ga[k][e] + be[k][e]);
+                        float dyh = dz * ga[k][e];
+                        o[e] = sc[k][e] * (dyh - mA[k][e] - xh * mB[k][e]);
                     }
-                    *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-                }
-                if (dx16) {
-                    uint2 w;
-                    w.x = pack_bf16x2(o[0], o[1]);
-                    w.y = pack_bf16x2(o[2], o[3]);
-                    *(uint2*)(dx16 + (boff + r) * lddx16 + 4 * q) = w;
+                    if (dx32) {
+                        float* dst = dx32 + (boff + rr) * lddx32 + 4 * q;
+                        if (accumulate) {
+                            o[0] += acc4[u][k].x; o[1] += acc4[u][k].y; o[2] += acc4[u][k].z; o[3] += acc4[u][k].w;
+                        }
+                        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                    if (dx16) {
+                        uint2 w;
+                        w.x = pack_bf16x2(o[0], o[1]);
+                        w.y = pack_bf16x2(o[2], o[3]);
+                        *(uint2*)(dx16 + (boff + rr) * lddx16 + 4 * q) = w;
+                    }
                 }
             }
         }

@@ -29,15 +29,26 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, family, work, e0):
+    def stop(self, family, work, e0, tag=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((family, work, e0, e1))
+        self.records.append((family, work, e0, e1, tag))
+
+    def by_tag(self):
+        """{(family, tag): {launches, work, ms}} -- per-shape view for tuning."""
+        torch.cuda.synchronize()
+        out = {}
+        for fam, work, e0, e1, tag in self.records:
+            d = out.setdefault((fam, tag), {"launches": 0, "work": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["work"] += work
+            d["ms"] += e0.elapsed_time(e1)
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for fam, work, e0, e1 in self.records:
+        for fam, work, e0, e1, _tag in self.records:
             d = out.setdefault(fam, {"launches": 0, "work": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["work"] += work
@@ -171,7 +182,8 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
               up, float(alpha), ksplit, _ptr(ws), 1, 0, 0, 0, 0, _stream())
     if e0 is not None:
         # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
-        TIMER.stop("conv_gemm", 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0)
+        TIMER.stop("conv_gemm", 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0,
+                   f"M={B * Ho * Wo} N={Cout} K={Cin}x{KH * KH} s{stride} up{up} {'f32' if x.dtype == F32 else 'bf16'}")
     return y32, y16
 
 
@@ -291,7 +303,7 @@ def attention_fwd(q, k, v, heads, key_mask=None):
               _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d, float(d) ** -0.5,
               _stream())
     if e0 is not None:
-        TIMER.stop("attention_fwd", 4.0 * B * heads * N * M * d, e0)      # QK^T + PV, SURVEY.md 8d
+        TIMER.stop("attention_fwd", 4.0 * B * heads * N * M * d, e0, f"N={N} M={M} d={d}")      # QK^T + PV, SURVEY.md 8d
     return out, lse
 
 
