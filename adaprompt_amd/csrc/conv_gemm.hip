@@ -242,19 +242,63 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, p.x_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
         constexpr unsigned OOB = 0x80000000u;
+        // Address generation is hoisted out of the K loop: per staged row one byte offset of the tap-(0,0) source
+        // pixel and a 9-bit mask of the taps that fall inside the image; per K step the tap contributes a
+        // wave-uniform scalar offset.  (The naive per-tap decode cost ~35 VALU per DMA -- more issue cycles than
+        // the MFMAs of the step.)
+        unsigned a_base[4], a_mask[4], b_base[BROWS], b_kill[BROWS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a_base[i] = (unsigned)(((a_boff[i] + a_iy0[i] * p.Win + a_ix0[i]) * (int)p.ldx + lchunk * 8) * 2);
+            unsigned mk = 0;
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                int ky = t / p.KW, kx = t - ky * p.KW;
+                int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                if (iy >= 0 && iy < Heff && ix >= 0 && ix < Weff) mk |= 1u << t;
+            }
+            a_mask[i] = mk;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int n = n0 + srow + 32 * i;
+            b_kill[i] = n < p.Cout ? 0u : OOB;
+            b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
+        }
         auto stage = [&](int buf, int kt) {
             int tap = kt / p.ktiles_per_tap;
-            int c = (kt - tap * p.ktiles_per_tap) * BK + lchunk * 8;
+            int c0 = (kt - tap * p.ktiles_per_tap) * BK;
             int ky = tap / p.KW, kx = tap - ky * p.KW;
-            bool cok = c < p.Cin;
+            bool cok = c0 + lchunk * 8 < p.Cin;
             char* abase = sA + buf * (BM * 128) + wv * 1024;
             char* bbase = sB + buf * (BN * 128) + wv * 1024;
+            if (p.up == 0) {
+                // branch-free: an invalid lane gets bit 31 OR-ed into its offset (>= num_records -> hardware zeros),
+                // so every wave issues exactly the same number of DMA instructions per stage
+                const unsigned tapoff = (unsigned)(((ky * p.Win + kx) * (int)p.ldx + c0) * 2);
+                const unsigned tapw = (unsigned)((tap * p.Cout * p.Cin + c0) * 2);
+                unsigned kill = cok ? 0u : OOB;
+                asm volatile("" : "+v"(kill));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned inval = ((a_mask[i] >> tap) & 1u) - 1u;           // 0 if the tap is inside the image
+                    unsigned voff = (a_base[i] + tapoff) | (inval & OOB) | kill;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * 4096), 16, voff, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < BROWS; ++i) {
+                    unsigned voff = (b_base[i] + tapw) | b_kill[i] | kill;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * 4096), 16, voff, 0, 0, 0);
+                }
+                return;
+            }
+            // upsample / zero-insert gathers (3 + 3 layers): generic per-tap decode
+            int c = c0 + lchunk * 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
                 bool ok = cok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;
                 if (p.up == 2) ok = ok && !((iy | ix) & 1);
-                if (p.up) { iy >>= 1; ix >>= 1; }
+                iy >>= 1; ix >>= 1;
                 unsigned voff = ok ? (unsigned)(((a_boff[i] + iy * p.Win + ix) * (int)p.ldx + c) * 2) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * 4096), 16, voff, 0, 0, 0);
             }
@@ -355,6 +399,482 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p, int M,
     }
 }
 
+
+// =============================================================================================
+// Large-problem variant: 256 pixels x BN channels per workgroup, 8 waves (4 pixel quarters x 2 channel halves),
+// bf16 activations only, THREE LDS stages filled by LDS-DMA with the prefetch two K steps ahead: the wait
+// before a step is a COUNTED s_waitcnt vmcnt(loads of one stage) and the barrier is a raw s_barrier, so the
+// DMA of the next tile stays in flight across it (guide section 5 "Pipelining across barriers", T3/T4).
+// A 128 x 128 tile needs 64 B/clk/CU of operand traffic at the full MFMA rate -- the whole L2 bandwidth; the
+// 256-wide tile halves that, and the two-step prefetch covers ~2 x 640 MFMA cycles of memory latency.
+// =============================================================================================
+#define BMB 256
+template <int BN>
+__global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
+    constexpr int WN = BN / 2;
+    constexpr int MT = WN / 16;
+    constexpr int PT = 4;
+    constexpr int NST = 3;
+    constexpr int A_STAGE = BMB * 128, B_STAGE = BN * 128;
+    constexpr int BPASS = (BN + 63) / 64;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + NST * A_STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wv & 3, wn = wv >> 2;
+
+    const int nwg = p.ntiles_m * p.ntiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tn = bid % p.ntiles_n;
+    const int tm = bid / p.ntiles_n;
+    const int m0 = tm * BMB, n0 = tn * BN;
+    const int HWo = p.Hout * p.Wout;
+    const int M = p.B * HWo;
+
+    int kt_begin = 0, kt_end = p.ktiles_total;
+    if (p.ksplit > 1) {
+        int per = (p.ktiles_total + p.ksplit - 1) / p.ksplit;
+        kt_begin = blockIdx.z * per;
+        kt_end = min(p.ktiles_total, kt_begin + per);
+    }
+
+    const int srow = tid >> 3;                        // 0..63
+    const int rsw = (lane >> 3) & 7;
+    const int lchunk = (lane & 7) ^ rsw;
+    int a_iy0[4], a_ix0[4], a_boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + srow + 64 * i;
+        if (m < M) {
+            int b = m / HWo, r = m - b * HWo;
+            int oy = r / p.Wout, ox = r - oy * p.Wout;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_boff[i] = b * p.Hin * p.Win;
+        } else {
+            a_iy0[i] = -(1 << 28);
+            a_ix0[i] = 0;
+            a_boff[i] = 0;
+        }
+    }
+    const int Heff = p.up ? 2 * p.Hin : p.Hin;
+    const int Weff = p.up ? 2 * p.Win : p.Win;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // weight-row passes this wave takes part in (a pass = 64 rows, a wave = 8 of them): 4 A + nB B loads per stage
+    int nB = 0;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) nB += (64 * i + 8 * wv < BN) ? 1 : 0;
+
+    // hoisted address generation (see conv_gemm_kernel): per row a base offset + a tap-validity mask
+    unsigned a_base[4], a_mask[4], b_base[BPASS], b_kill[BPASS];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_base[i] = (unsigned)(((a_boff[i] + a_iy0[i] * p.Win + a_ix0[i]) * (int)p.ldx + lchunk * 8) * 2);
+        unsigned mk = 0;
+        for (int t = 0; t < p.KH * p.KW; ++t) {
+            int ky = t / p.KW, kx = t - ky * p.KW;
+            int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            if (iy >= 0 && iy < Heff && ix >= 0 && ix < Weff) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        int n = n0 + srow + 64 * i;
+        b_kill[i] = n < p.Cout ? 0u : OOB;
+        b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
+    }
+    auto stage = [&](int buf, int kt) {
+        int tap = kt / p.ktiles_per_tap;
+        int c0 = (kt - tap * p.ktiles_per_tap) * BK;
+        int ky = tap / p.KW, kx = tap - ky * p.KW;
+        bool cok = c0 + lchunk * 8 < p.Cin;
+        char* abase = sA + buf * A_STAGE + wv * 1024;
+        char* bbase = sB + buf * B_STAGE + wv * 1024;
+        {
+            // branch-free (see conv_gemm_kernel): the counted vmcnt below relies on every wave issuing exactly
+            // 4 + nB DMA instructions per stage
+            const unsigned tapoff = (unsigned)(((ky * p.Win + kx) * (int)p.ldx + c0) * 2);
+            const unsigned tapw = (unsigned)((tap * p.Cout * p.Cin + c0) * 2);
+            unsigned kill = cok ? 0u : OOB;
+            asm volatile("" : "+v"(kill));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned inval = ((a_mask[i] >> tap) & 1u) - 1u;
+                unsigned voff = (a_base[i] + tapoff) | (inval & OOB) | kill;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * 8192), 16, voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                if (64 * i + 8 * wv < BN) {               // wave-uniform
+                    unsigned voff = (b_base[i] + tapw) | b_kill[i] | kill;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * 8192), 16, voff, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT][PT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+
+    auto compute = [&](int buf) {
+        const char* a = sA + buf * A_STAGE;
+        const char* b = sB + buf * B_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fw[MT], fx[PT];
+            const int cc = 4 * s + fchunk;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int r = wn * WN + i * 16 + frow;
+                fw[i] = *(const bf16x8*)(b + r * 128 + ((cc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                int r = wm * 64 + j * 16 + frow;
+                fx[j] = *(const bf16x8*)(a + r * 128 + ((cc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int ntl = kt_end - kt_begin;
+    if (ntl > 0) stage(0, kt_begin);
+    if (ntl > 1) stage(1, kt_begin + 1);
+    int buf = 0;
+    for (int t = 0; t < ntl; ++t) {
+        // tile t has landed once at most the loads of tile t+1 (one stage = 4 + nB per wave) are outstanding
+        if (t + 1 < ntl) {
+            if (nB == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (nB == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();          // tile t visible to every wave; every wave is done with tile t-1
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntl) {
+            int nb = buf + 2;
+            if (nb >= NST) nb -= NST;
+            stage(nb, kt_begin + t + 2);       // refills the buffer tile t-1 was multiplied from
+        }
+        compute(buf);
+        if (++buf == NST) buf = 0;
+    }
+
+    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        if (m >= M) continue;
+        const int b = m / HWo;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
+            if (c0 >= p.Cout) continue;
+            if (slab) {
+                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                continue;
+            }
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (p.bias) {
+                float4 t = *(const float4*)(p.bias + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.chan_add) {
+                float4 t = *(const float4*)(p.chan_add + (size_t)b * p.ld_ca + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.residual) {
+                float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.y16) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
+            }
+        }
+    }
+}
+
+static void launch_reduce(const ConvParams& p, hipStream_t stream) {
+    const int M = p.B * p.Hout * p.Wout;
+    long total = (long)M * (p.Cout >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, M, p.Hout * p.Wout);
+}
+
+template <int BN>
+static int launch_big(const ConvParams& p, hipStream_t stream) {
+    size_t lds = 3 * BMB * 128 + 3 * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_gemm_big_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(p.ntiles_m * p.ntiles_n, 1, p.ksplit);
+    hipLaunchKernelGGL((conv_gemm_big_kernel<BN>), grid, dim3(512), lds, stream, p);
+    if (p.ksplit > 1) launch_reduce(p, stream);
+    return adap_check_launch("conv_gemm_big");
+}
+
+
+// =============================================================================================
+// 3x3 / stride 1 / pad 1 convolution with an LDS-staged STENCIL WINDOW (the ResBlock and VAE ResnetBlock convs,
+// i.e. ~95 % of the conv FLOPs).  A workgroup owns an 8 x 32 pixel patch of one image and BN output channels.  Per
+// 64-channel slice of Cin it DMAs the (8+2) x (32+2) halo window ONCE into LDS and runs all nine taps out of it --
+// each tap is a 1x1 contraction whose pixel operand is the same window read at a shifted position -- while the nine
+// [BN x 64] weight slices stream through a 3-deep ring.  Compared with gathering one tap per K step this cuts the
+// activation traffic L2 -> LDS from 9x to 1.33x; the gather variant was bound by exactly that feed rate (measured:
+// 2600-4300 cycles per K step against 1024 of MFMA, HBM traffic already compulsory-only).
+// =============================================================================================
+#define HALO_TH 8
+#define HALO_TW 32
+#define HALO_W (HALO_TW + 2)
+#define HALO_SLOTS ((HALO_TH + 2) * HALO_W)      // 340
+#define HALO_PASSES 6                            // 6 x 64 slots >= 340
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
+    constexpr int WN = BN / 2;
+    constexpr int MT = WN / 16;
+    constexpr int PT = 4;
+    constexpr int A_STAGE = HALO_PASSES * 64 * 128;      // 48 KB
+    constexpr int B_STAGE = BN * 128;
+    constexpr int BPASS = (BN + 63) / 64;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                       // [2][384 slots][128 B]
+    char* sB = smem + 2 * A_STAGE;         // [3][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 3, wn = wv >> 2;
+
+    const int tiles_x = p.Win / HALO_TW, tiles_y = p.Hin / HALO_TH;
+    const int nwg = p.ntiles_m * p.ntiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tn = bid % p.ntiles_n;
+    int tm = bid / p.ntiles_n;
+    const int tx = tm % tiles_x;
+    tm /= tiles_x;
+    const int ty = tm % tiles_y;
+    const int bimg = tm / tiles_y;
+    const int y0 = ty * HALO_TH, x0 = tx * HALO_TW;
+    const int n0 = tn * BN;
+
+    const int nchunks_total = p.ktiles_per_tap;        // 64-channel slices of Cin
+    int ch_begin = 0, ch_end = nchunks_total;
+    if (p.ksplit > 1) {
+        int per = (nchunks_total + p.ksplit - 1) / p.ksplit;
+        ch_begin = blockIdx.z * per;
+        ch_end = min(nchunks_total, ch_begin + per);
+    }
+    const int nch = ch_end - ch_begin;
+
+    const int srow = tid >> 3;                          // 0..63
+    const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
+    // halo slots staged by this thread: s = 64*i + srow -> window pixel (s / 34, s % 34)
+    unsigned a_base[HALO_PASSES], a_kill[HALO_PASSES];
+#pragma unroll
+    for (int i = 0; i < HALO_PASSES; ++i) {
+        int sidx = 64 * i + srow;
+        int hr = sidx / HALO_W, hc = sidx - hr * HALO_W;
+        int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+        bool ok = sidx < HALO_SLOTS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        a_base[i] = (unsigned)((((bimg * p.Hin + iy) * p.Win + ix) * (int)p.ldx + lchunk * 8) * 2);
+        a_kill[i] = ok ? 0u : OOB;
+    }
+    unsigned b_base[BPASS], b_kill[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        int n = n0 + srow + 64 * i;
+        b_kill[i] = n < p.Cout ? 0u : OOB;
+        b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
+    }
+    int nB = 0;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) nB += (64 * i + 8 * wv < BN) ? 1 : 0;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    auto stage_a = [&](int buf, int chunk) {             // HALO_PASSES DMA instructions per wave
+        const int c0 = chunk * BK;
+        unsigned kill = (c0 + lchunk * 8 < p.Cin) ? 0u : OOB;
+        asm volatile("" : "+v"(kill));
+        char* base = sA + buf * A_STAGE + wv * 1024;
+#pragma unroll
+        for (int i = 0; i < HALO_PASSES; ++i) {
+            unsigned voff = (a_base[i] + (unsigned)(c0 * 2)) | a_kill[i] | kill;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(base + i * 8192), 16, voff, 0, 0, 0);
+        }
+    };
+    auto stage_b = [&](int buf, int chunk, int tap) {    // nB DMA instructions per wave
+        const int c0 = chunk * BK;
+        unsigned kill = (c0 + lchunk * 8 < p.Cin) ? 0u : OOB;
+        asm volatile("" : "+v"(kill));
+        const unsigned tapw = (unsigned)((tap * p.Cout * p.Cin + c0) * 2);
+        char* base = sB + buf * B_STAGE + wv * 1024;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i) {
+            if (64 * i + 8 * wv < BN) {
+                unsigned voff = (b_base[i] + tapw) | b_kill[i] | kill;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(base + i * 8192), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[MT][PT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+    // window slot of this lane's pixel in fragment j at tap (0,0): patch row 2*wm + (j>>1), column (j&1)*16 + frow
+    int sbase[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) sbase[j] = (2 * wm + (j >> 1)) * HALO_W + (j & 1) * 16 + frow;
+
+    auto compute = [&](int abuf, int bbuf, int tap) {
+        const char* a = sA + abuf * A_STAGE;
+        const char* b = sB + bbuf * B_STAGE;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int shift = ky * HALO_W + kx;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fw[MT], fx[PT];
+            const int cc = 4 * s + fchunk;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int r = wn * WN + i * 16 + frow;
+                fw[i] = *(const bf16x8*)(b + r * 128 + ((cc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                int sl = sbase[j] + shift;
+                fx[j] = *(const bf16x8*)(a + sl * 128 + ((cc ^ (sl & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline: step t = (chunk t/9, tap t%9).  B(t+2) is issued at step t; A(chunk+1) at tap 0, after B(t+2).
+    const int T = nch * 9;
+    if (nch > 0) {
+        stage_a(0, ch_begin);
+        stage_b(0, ch_begin, 0);
+        stage_b(1, ch_begin, 1);
+    }
+    int bbuf = 0;
+    for (int t = 0; t < T; ++t) {
+        const int ci = t / 9, tap = t - 9 * ci;
+        // DMA instructions that may still be in flight while tile t is complete: B(t+1), and A(ci+1) during taps 1-2
+        int allow = (t + 1 < T) ? nB : 0;
+        if ((tap == 1 || tap == 2) && ci + 1 < nch) allow += HALO_PASSES;
+        switch (allow) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < T) {
+            int t2 = t + 2, c2 = t2 / 9;
+            int nb = bbuf + 2;
+            if (nb >= 3) nb -= 3;
+            stage_b(nb, ch_begin + c2, t2 - 9 * c2);
+        }
+        if (tap == 0 && ci + 1 < nch) stage_a((ci + 1) & 1, ch_begin + ci + 1);
+        compute(ci & 1, bbuf, tap);
+        if (++bbuf == 3) bbuf = 0;
+    }
+
+    const int M = p.B * p.Hin * p.Win;
+    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int yy = y0 + 2 * wm + (j >> 1), xx = x0 + (j & 1) * 16 + frow;
+        const int m = (bimg * p.Hin + yy) * p.Win + xx;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
+            if (c0 >= p.Cout) continue;
+            if (slab) {
+                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                continue;
+            }
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (p.bias) {
+                float4 t = *(const float4*)(p.bias + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.chan_add) {
+                float4 t = *(const float4*)(p.chan_add + (size_t)bimg * p.ld_ca + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.residual) {
+                float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.y16) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
+            }
+        }
+    }
+}
+
+template <int BN>
+static int launch_halo(const ConvParams& p, hipStream_t stream) {
+    size_t lds = 2 * HALO_PASSES * 64 * 128 + 3 * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(p.ntiles_m * p.ntiles_n, 1, p.ksplit);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN>), grid, dim3(512), lds, stream, p);
+    if (p.ksplit > 1) launch_reduce(p, stream);
+    return adap_check_launch("conv3x3_halo");
+}
+
 template <int BN, bool A_F32>
 static int launch(const ConvParams& p, int nbatch, hipStream_t stream) {
     size_t lds = 2 * BM * 128 + 2 * BN * 128;
@@ -366,13 +886,7 @@ static int launch(const ConvParams& p, int nbatch, hipStream_t stream) {
     }
     dim3 grid(p.ntiles_m * p.ntiles_n, nbatch, p.ksplit);
     hipLaunchKernelGGL((conv_gemm_kernel<BN, A_F32>), grid, dim3(256), lds, stream, p);
-    if (p.ksplit > 1) {
-        const int M = p.B * p.Hout * p.Wout;
-        long total = (long)M * (p.Cout >> 2);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, M, p.Hout * p.Wout);
-    }
+    if (p.ksplit > 1) launch_reduce(p, stream);
     return adap_check_launch("conv_gemm");
 }
 
@@ -383,24 +897,56 @@ static int choose_bn(int Cout) {
     return 128;
 }
 
-// split-K plan: a launch needs >> 256 workgroups to fill the chip; the UNet's 32x32 .. 8x8 levels have few pixel
-// tiles but very long K (up to 9*2560), so split K until there are ~2 workgroups per CU.
-static int choose_ksplit(long M, int Cout, int ktiles_total) {
+// the 256-pixel, 3-stage variant: bf16 activations, one problem, enough pixels and K steps to fill its pipeline
+static bool choose_big(long M, int Cout, int ktiles_total, int x_dtype, int nbatch, int up) {
+    return up == 0 && x_dtype == 1 && nbatch == 1 && Cout > 64 && M >= 4096 && ktiles_total >= 5;
+}
+
+// the stencil-window variant: 3x3 / stride 1 / pad 1 on bf16 activations whose image tiles into 8 x 32 patches
+static bool choose_halo(int Hin, int Win, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int stride, int pad, int up,
+                        int x_dtype, int nbatch) {
+    return KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 0 && x_dtype == 1 && nbatch == 1 && Hout == Hin &&
+           Wout == Win && Hin % HALO_TH == 0 && Win % HALO_TW == 0 && Cout > 64 && Cin >= 64;
+}
+
+static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
     int bn = choose_bn(Cout);
-    long blocks = ((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
-    if (blocks >= 384 || ktiles_total < 24) return 1;     // short-K layers: the reduce pass would cost more than it saves
-    int ks = (int)((512 + blocks - 1) / blocks);
+    long blocks = (long)B * (H / HALO_TH) * (W / HALO_TW) * ((Cout + bn - 1) / bn);
+    int nchunks = (Cin + BK - 1) / BK;
+    if (blocks >= 200 || nchunks < 2) return 1;
+    int ks = (int)((256 + blocks - 1) / blocks);
+    if (ks > nchunks) ks = nchunks;
+    if (ks > 16) ks = 16;
+    return ks < 1 ? 1 : ks;
+}
+
+// split-K plan: a launch needs >> 256 workgroups to fill the chip; the UNet's 32x32 .. 8x8 levels have few pixel
+// tiles but very long K (up to 9*2560), so split K until there are ~2 workgroups per CU (1 per CU for the big tile).
+static int choose_ksplit(long M, int Cout, int ktiles_total, bool big) {
+    int bn = choose_bn(Cout);
+    int bm = big ? BMB : BM;
+    long blocks = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    long enough = big ? 200 : 384, target = big ? 256 : 512;
+    if (blocks >= enough || ktiles_total < 24) return 1;     // short-K layers: the reduce pass would cost more than it saves
+    int ks = (int)((target + blocks - 1) / blocks);
     int cap = ktiles_total / 4;
     if (ks > cap) ks = cap;
     if (ks > 16) ks = 16;
     return ks < 1 ? 1 : ks;
 }
 
-// floats of split-K workspace adap_conv2d_nhwc needs for this problem with ksplit = 0 (auto); 0 = none
+// floats of split-K workspace adap_conv2d_nhwc needs for this problem with ksplit = 0 (auto); 0 = none.
+// (sized for either activation dtype: the larger of the two plans)
 extern "C" long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW) {
     long M = (long)B * Hout * Wout;
     int kt = KH * KW * ((Cin + BK - 1) / BK);
-    int ks = choose_ksplit(M, Cout, kt);
+    int ks0 = choose_ksplit(M, Cout, kt, false);
+    int ks1 = choose_big(M, Cout, kt, 1, 1, 0) ? choose_ksplit(M, Cout, kt, true) : 1;
+    int ks = ks0 > ks1 ? ks0 : ks1;
+    if (KH == 3 && KW == 3 && Hout % HALO_TH == 0 && Wout % HALO_TW == 0 && Cout > 64 && Cin >= 64) {
+        int ks2 = choose_ksplit_halo(B, Hout, Wout, Cin, Cout);
+        if (ks2 > ks) ks = ks2;
+    }
     return ks > 1 ? (long)ks * M * Cout : 0;
 }
 
@@ -449,11 +995,17 @@ extern "C" int adap_conv2d_nhwc(
     p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.up = up;
     p.ktiles_per_tap = (Cin + BK - 1) / BK;
     p.ktiles_total = KH * KW * p.ktiles_per_tap;
-    if (ksplit == 0) ksplit = (nbatch == 1 && splitk_ws) ? choose_ksplit(M, Cout, p.ktiles_total) : 1;
-    p.ksplit = ksplit < p.ktiles_total ? ksplit : p.ktiles_total;
-    {   // every split must own at least one K tile (an empty split would leave its slab unwritten)
-        int per = (p.ktiles_total + p.ksplit - 1) / p.ksplit;
-        p.ksplit = (p.ktiles_total + per - 1) / per;
+    const bool halo = choose_halo(Hin, Win, Hout, Wout, Cin, Cout, KH, KW, stride, pad, up, x_dtype, nbatch);
+    const bool big = !halo && choose_big(M, Cout, p.ktiles_total, x_dtype, nbatch, up);
+    const int ksplit_units = halo ? p.ktiles_per_tap : p.ktiles_total;      // the halo kernel splits over Cin slices
+    if (ksplit == 0) {
+        if (!(nbatch == 1 && splitk_ws)) ksplit = 1;
+        else ksplit = halo ? choose_ksplit_halo(B, Hin, Win, Cin, Cout) : choose_ksplit(M, Cout, p.ktiles_total, big);
+    }
+    p.ksplit = ksplit < ksplit_units ? ksplit : ksplit_units;
+    {   // every split must own at least one unit (an empty split would leave its slab unwritten)
+        int per = (ksplit_units + p.ksplit - 1) / p.ksplit;
+        p.ksplit = (ksplit_units + per - 1) / per;
     }
     ADAP_REQUIRE(p.ksplit == 1 || (splitk_ws && nbatch == 1 && ((uintptr_t)splitk_ws % 16) == 0), ADAP_ERR_SHAPE,
                  "conv2d: split-K needs a workspace (adap_conv2d_workspace_floats) and nbatch == 1");
@@ -466,13 +1018,22 @@ extern "C" int adap_conv2d_nhwc(
         p.x_bytes = (unsigned)xb;
         p.w_bytes = (unsigned)wb;
     }
-    p.ntiles_m = (int)((M + BM - 1) / BM);
+    p.ntiles_m = (int)((M + (big ? BMB : BM) - 1) / (big ? BMB : BM));
     p.alpha = alpha;
     p.batch_stride_x = bs_x; p.batch_stride_w = bs_w; p.batch_stride_y32 = bs_y32; p.batch_stride_y16 = bs_y16;
     hipStream_t s = (hipStream_t)stream;
 
     const int bn = choose_bn(Cout);
     p.ntiles_n = (Cout + bn - 1) / bn;
+    if (halo) {
+        p.ntiles_m = B * (Hin / HALO_TH) * (Win / HALO_TW);
+        if (bn == 160) return launch_halo<160>(p, s);
+        return launch_halo<128>(p, s);
+    }
+    if (big) {
+        if (bn == 160) return launch_big<160>(p, s);
+        return launch_big<128>(p, s);
+    }
     if (x_dtype == 0) {
         if (bn == 160) return launch<160, true>(p, nbatch, s);
         if (bn == 128) return launch<128, true>(p, nbatch, s);

@@ -30,9 +30,9 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("ADAP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():           # "nccl" IS RCCL on ROCm
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

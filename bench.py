@@ -142,7 +142,7 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _lib.load()
 

@@ -56,6 +56,14 @@ CONV_CASES = [
     (2, 320, 320, 8, 8, 3, 1, 1, 1, False),        # nearest x2 upsample fused
     (2, 960, 640, 8, 8, 1, 1, 0, 0, False),        # 1x1 skip
     (1, 2560, 1280, 8, 8, 3, 1, 1, 0, True),       # long K
+    # the 256-pixel, 3-stage LDS-DMA variant (bf16 activations, M >= 4096)
+    (2, 320, 320, 64, 64, 3, 1, 1, 0, True),       # UNet 64x64 level, split-K 2
+    (1, 128, 128, 128, 128, 3, 1, 1, 0, True),     # VAE-like, Cout tile 128
+    (1, 64, 256, 70, 66, 3, 1, 1, 0, True),        # ragged pixel tile (4620 pixels), short K
+    (4, 640, 640, 32, 32, 3, 1, 1, 0, True),       # 32x32 level: split-K 4
+    (2, 320, 2560, 64, 64, 1, 1, 0, 0, True),      # GEGLU projection shape
+    (4, 128, 128, 64, 64, 3, 2, 0, 0, True),       # stride 2, asymmetric pad, big tile
+    (2, 320, 320, 32, 32, 3, 1, 1, 1, True),       # fused nearest x2 upsample, big tile
 ]
 
 
