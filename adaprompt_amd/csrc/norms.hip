@@ -4,63 +4,125 @@
 // (sample, group); eps 1e-5 in the UNet ResBlocks / out, 1e-6 in SpatialTransformer.norm and in
 // all VAE norms (attention.py:71-72, model.py:39-40) -- eps is an argument.  In the pixel-major
 // layout a group is a run of C/32 consecutive channels of every pixel, so a block streams a slab
-// of whole pixel rows with fully coalesced 16-byte loads and every thread owns fixed channel
-// quads; group sums are combined through LDS, per-slab partials go to a small workspace
-// ([B][nchunks][32][2] floats) and the apply pass finishes the reduction deterministically (no
-// float atomics in HBM).  Output is bf16 (operand of the following contraction) and/or f32.
+// of whole pixel rows with fully coalesced accesses; every thread owns fixed 8-channel "octs"
+// (32 B of f32 or 16 B of bf16 per access), group sums are combined through LDS in a fixed
+// order, per-slab partials go to a small workspace ([B][nchunks][32][2] floats) and the apply
+// pass finishes the reduction in fp64 -- no float atomics anywhere, results are bit-reproducible.
+// The input may be f32 (the residual stream) or bf16 (block-internal tensors such as the output
+// of a ResBlock's first conv, which only this norm and its backward ever read); the output is
+// bf16 (operand of the following contraction) and/or f32.
 //
-// Algorithmic bytes per element: forward 4 (stats read) + 4 (apply read) + 2 (bf16
-// write); the second read hits the Infinity Cache for the UNet's tensors (<= 84 MB at bs=4).
+// Algorithmic bytes per element: forward = read x once + write y
+// (f32 -> bf16: 6 B, bf16 -> bf16: 4 B); the kernels read x twice (statistics, then apply), the
+// second read is served by the 256 MB Infinity Cache for the UNet's tensors (<= 84 MB at bs=4).
 #include "common.h"
 
 #define GN_G 32
-#define GN_MAXSLOT 3     // C <= 3072
-#define GN_UNR 4         // pixel rows in flight per thread
+#define GN_MAXSLOT 2     // 8-channel octs per thread: C <= 4096
+#define GN_UNR 4         // pixel rows in flight per thread (forward)
 #define GN_UNRB 2        // ... in the backward (two input streams)
 
 struct GnGeom {
-    int Q;        // float4 quads per pixel row (C/4)
+    int Q;        // octs per pixel row (C/8)
     int TPR;      // threads per row
     int rpp;      // rows per pass
-    int nslots;   // quads per thread
+    int nslots;   // octs per thread
 };
 
 __device__ __forceinline__ GnGeom gn_geom(int C) {
     GnGeom g;
-    g.Q = C >> 2;
+    g.Q = C >> 3;
     g.TPR = g.Q < 256 ? g.Q : 256;
     g.rpp = 256 / g.TPR;
     g.nslots = (g.Q + g.TPR - 1) / g.TPR;
     return g;
 }
 
-// Deterministic block reduction of per-thread channel sums into the 32 group sums: every thread parks its
-// (slot, e) partials in LDS, then thread g < 32 adds the contributions of group g's channels in a fixed order
-// (no float atomics, so results are bit-reproducible run to run).  sm: [GN_MAXSLOT*4][256] floats.
-__device__ __forceinline__ float gn_group_sum(const float* sm, const GnGeom& g, int cpg, int grp) {
-    float acc = 0.f;
-    for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) {
-        int q = c >> 2, e = c & 3;
-        int slot = q / g.TPR, lir = q - slot * g.TPR;
-        const float* col = sm + (slot * 4 + e) * 256 + lir;
-        for (int r0 = 0; r0 < g.rpp; ++r0) acc += col[r0 * g.TPR];
+template <bool BF16>
+__device__ __forceinline__ void gn_load8(const void* base, size_t off, float* o) {
+    if (BF16) {
+        uint4 v = *(const uint4*)((const uint16_t*)base + off);
+        unpack_bf16x8(v, o);
+    } else {
+        const float4* p = (const float4*)((const float*)base + off);
+        float4 a = p[0], b = p[1];
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+        o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     }
+}
+
+__device__ __forceinline__ void gn_store8_f32(float* p, const float* o) {
+    *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
+    *(float4*)(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+}
+
+// Deterministic block reduction of per-thread channel sums into the 32 group sums, two levels, fixed order:
+// every thread parks its (slot, e) partials in LDS [GN_MAXSLOT*8][256]; then each thread folds the rows-per-pass
+// partials of one channel (all 256 threads busy), and thread g < 32 adds group g's channel sums.
+__device__ __forceinline__ void gn_fold_channels(const float* sm, float* chs, const GnGeom& g, int C, int tid) {
+    for (int c = tid; c < C; c += 256) {
+        int q = c >> 3, e = c & 7;
+        int slot = q / g.TPR, lir = q - slot * g.TPR;
+        const float* col = sm + (slot * 8 + e) * 256 + lir;
+        float acc = 0.f;
+        for (int r0 = 0; r0 < g.rpp; ++r0) acc += col[r0 * g.TPR];
+        chs[c] = acc;
+    }
+}
+
+__device__ __forceinline__ float gn_group_sum(const float* chs, int cpg, int grp) {
+    float acc = 0.f;
+    for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) acc += chs[c];
     return acc;
 }
 
-__device__ __forceinline__ void gn_park(float* sm, const float (*v)[4], int tid) {
+// park -> fold -> group sum, with the barriers; returns group tid's sum in threads tid < 32 (others 0)
+__device__ __forceinline__ float gn_block_reduce(float* sm, float* ch, const float (*v)[8], const GnGeom& g, int C, int cpg,
+                                                 int tid);
+
+// sum of the per-slab partials of (b, group) in fp64, 8 threads per group (tid>>3 = group), fixed order
+__device__ __forceinline__ void gn_finish_partials(const float* partial, int b, int nchunks, int tid, double* su, double* sq) {
+    const int grp = tid >> 3, part = tid & 7;
+    double a = 0.0, c2 = 0.0;
+    const float* pp = partial + ((size_t)b * nchunks * GN_G + grp) * 2;
+    for (int c = part; c < nchunks; c += 8) {
+        float2 v = *(const float2*)(pp + (size_t)c * GN_G * 2);
+        a += v.x; c2 += v.y;
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 8);
+        c2 += __shfl_down(c2, o, 8);
+    }
+    *su = a;
+    *sq = c2;
+}
+
+__device__ __forceinline__ void gn_park(float* sm, const float (*v)[8], int tid) {
 #pragma unroll
     for (int k = 0; k < GN_MAXSLOT; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sm[(k * 4 + e) * 256 + tid] = v[k][e];
+        for (int e = 0; e < 8; ++e) sm[(k * 8 + e) * 256 + tid] = v[k][e];
+}
+
+__device__ __forceinline__ float gn_block_reduce(float* sm, float* ch, const float (*v)[8], const GnGeom& g, int C, int cpg,
+                                                 int tid) {
+    gn_park(sm, v, tid);
+    __syncthreads();
+    gn_fold_channels(sm, ch, g, C, tid);
+    __syncthreads();
+    float r = tid < GN_G ? gn_group_sum(ch, cpg, tid) : 0.f;
+    __syncthreads();
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward pass 1: per-slab partial sums.  grid (nchunks, B), block 256.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long ldx, int HW, int C,
+template <bool XB>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ x, long ldx, int HW, int C,
                                                        int rows_per_chunk, float* __restrict__ partial) {
-    __shared__ float smA[GN_MAXSLOT * 4 * 256], smB[GN_MAXSLOT * 4 * 256];
+    __shared__ float smA[GN_MAXSLOT * 8 * 256], chA[GN_MAXSLOT * 8 * 256];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const GnGeom g = gn_geom(C);
@@ -68,51 +130,50 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     const int lir = tid % g.TPR, r0 = tid / g.TPR;
     const int row_begin = chunk * rows_per_chunk;
     const int row_end = min(HW, row_begin + rows_per_chunk);
-    float s[GN_MAXSLOT][4], ss[GN_MAXSLOT][4];
+    float s[GN_MAXSLOT][8], ss[GN_MAXSLOT][8];
 #pragma unroll
     for (int k = 0; k < GN_MAXSLOT; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[k][e] = 0.f; ss[k][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { s[k][e] = 0.f; ss[k][e] = 0.f; }
     if (r0 < g.rpp) {
-        const float* xb = x + (size_t)b * HW * ldx;
-        // GN_UNR rows in flight per thread: the kernel is a pure HBM stream, memory-level parallelism is the lever
+        const size_t boff = (size_t)b * HW;
+        // GN_UNR rows in flight per thread: a pure HBM stream, memory-level parallelism is the lever
         for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNR) {
-            float4 v[GN_UNR][GN_MAXSLOT];
+            float v[GN_UNR][GN_MAXSLOT][8];
 #pragma unroll
             for (int u = 0; u < GN_UNR; ++u) {
                 const int rr = r + u * g.rpp;
 #pragma unroll
                 for (int k = 0; k < GN_MAXSLOT; ++k) {
                     int q = lir + k * g.TPR;
-                    v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rr < row_end && k < g.nslots && q < g.Q) v[u][k] = *(const float4*)(xb + (size_t)rr * ldx + 4 * q);
+                    if (rr < row_end && k < g.nslots && q < g.Q) gn_load8<XB>(x, (boff + rr) * ldx + 8 * q, v[u][k]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[u][k][e] = 0.f;
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < GN_UNR; ++u)
 #pragma unroll
-                for (int k = 0; k < GN_MAXSLOT; ++k) {
-                    s[k][0] += v[u][k].x; ss[k][0] += v[u][k].x * v[u][k].x;
-                    s[k][1] += v[u][k].y; ss[k][1] += v[u][k].y * v[u][k].y;
-                    s[k][2] += v[u][k].z; ss[k][2] += v[u][k].z * v[u][k].z;
-                    s[k][3] += v[u][k].w; ss[k][3] += v[u][k].w * v[u][k].w;
-                }
+                for (int k = 0; k < GN_MAXSLOT; ++k)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s[k][e] += v[u][k][e];
+                        ss[k][e] += v[u][k][e] * v[u][k][e];
+                    }
         }
     }
-    gn_park(smA, s, tid);
-    gn_park(smB, ss, tid);
-    __syncthreads();
-    if (tid < GN_G) {
-        float2 o = make_float2(gn_group_sum(smA, g, cpg, tid), gn_group_sum(smB, g, cpg, tid));
-        *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = o;
-    }
+    const float ra = gn_block_reduce(smA, chA, s, g, C, cpg, tid);
+    const float rb = gn_block_reduce(smA, chA, ss, g, C, cpg, tid);
+    if (tid < GN_G) *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = make_float2(ra, rb);
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward pass 2: finish the reduction, normalise, affine, optional SiLU, write bf16 / f32.
-// grid (nchunks_apply, B).  stats_chunks = grid.x of the stats launch.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long ldx, int HW, int C,
+template <bool XB>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, long ldx, int HW, int C,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ partial, int stats_chunks, float eps, int act,
                                                        int rows_per_chunk, float* __restrict__ y32, long ldy32,
@@ -122,37 +183,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cpg = C / GN_G;
-    if (tid < GN_G) {
-        double su = 0.0, sq = 0.0;
-        const float* pp = partial + ((size_t)b * stats_chunks * GN_G + tid) * 2;
-        for (int c = 0; c < stats_chunks; ++c) {
-            float2 v = *(const float2*)(pp + (size_t)c * GN_G * 2);
-            su += v.x; sq += v.y;
-        }
-        double n = (double)cpg * HW;
-        double mean = su / n;
-        double var = sq / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        lmean[tid] = (float)mean;
-        lrstd[tid] = rstd;
-        if (chunk == 0) {
-            mean_out[b * GN_G + tid] = (float)mean;
-            rstd_out[b * GN_G + tid] = rstd;
+    {
+        double su, sq;
+        gn_finish_partials(partial, b, stats_chunks, tid, &su, &sq);
+        if ((tid & 7) == 0) {
+            const int grp = tid >> 3;
+            double n = (double)cpg * HW;
+            double mean = su / n;
+            double var = sq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            lmean[grp] = (float)mean;
+            lrstd[grp] = rstd;
+            if (chunk == 0) {
+                mean_out[b * GN_G + grp] = (float)mean;
+                rstd_out[b * GN_G + grp] = rstd;
+            }
         }
     }
     __syncthreads();
     const GnGeom g = gn_geom(C);
     const int lir = tid % g.TPR, r0 = tid / g.TPR;
     if (r0 >= g.rpp) return;
-    float sc[GN_MAXSLOT][4], sh[GN_MAXSLOT][4];
+    float sc[GN_MAXSLOT][8], sh[GN_MAXSLOT][8];
 #pragma unroll
     for (int k = 0; k < GN_MAXSLOT; ++k) {
         int q = lir + k * g.TPR;
         if (k < g.nslots && q < g.Q) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int c = 4 * q + e, grp = c / cpg;
+            for (int e = 0; e < 8; ++e) {
+                int c = 8 * q + e, grp = c / cpg;
                 float a = lrstd[grp] * gamma[c];
                 sc[k][e] = a;
                 sh[k][e] = beta[c] - lmean[grp] * a;
@@ -163,14 +223,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int row_end = min(HW, row_begin + rows_per_chunk);
     const size_t boff = (size_t)b * HW;
     for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNR) {
-        float4 v[GN_UNR][GN_MAXSLOT];
+        float v[GN_UNR][GN_MAXSLOT][8];
 #pragma unroll
         for (int u = 0; u < GN_UNR; ++u) {
             const int rr = r + u * g.rpp;
 #pragma unroll
             for (int k = 0; k < GN_MAXSLOT; ++k) {
                 int q = lir + k * g.TPR;
-                if (rr < row_end && k < g.nslots && q < g.Q) v[u][k] = *(const float4*)(x + (boff + rr) * ldx + 4 * q);
+                if (rr < row_end && k < g.nslots && q < g.Q) gn_load8<XB>(x, (boff + rr) * ldx + 8 * q, v[u][k]);
             }
         }
 #pragma unroll
@@ -180,19 +240,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             for (int k = 0; k < GN_MAXSLOT; ++k) {
                 int q = lir + k * g.TPR;
                 if (rr < row_end && k < g.nslots && q < g.Q) {
-                    float o[4] = {v[u][k].x * sc[k][0] + sh[k][0], v[u][k].y * sc[k][1] + sh[k][1],
-                                  v[u][k].z * sc[k][2] + sh[k][2], v[u][k].w * sc[k][3] + sh[k][3]};
-                    if (act) {
+                    float o[8];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = v[u][k][e] * sc[k][e] + sh[k][e];
+                        if (act) o[e] = silu_f(o[e]);
                     }
-                    if (y32) *(float4*)(y32 + (boff + rr) * ldy32 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (y16) {
-                        uint2 w;
-                        w.x = pack_bf16x2(o[0], o[1]);
-                        w.y = pack_bf16x2(o[2], o[3]);
-                        *(uint2*)(y16 + (boff + rr) * ldy16 + 4 * q) = w;
-                    }
+                    if (y32) gn_store8_f32(y32 + (boff + rr) * ldy32 + 8 * q, o);
+                    if (y16) *(uint4*)(y16 + (boff + rr) * ldy16 + 8 * q) = pack_bf16x8(o);
                 }
             }
         }
@@ -201,7 +256,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 
 static void gn_chunks(int HW, int C, int* nchunks, int* rows_per_chunk) {
     long elems = (long)HW * C;
-    int n = (int)(elems / 16384);
+    int n = (int)(elems / 32768);
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     if (n > HW) n = HW;
@@ -217,22 +272,29 @@ extern "C" long adap_groupnorm_workspace_floats(int B, int HW, int C) {
     return (long)B * n * GN_G * 2;
 }
 
-extern "C" int adap_groupnorm_fwd(const float* x, long ldx, const float* gamma, const float* beta,
+extern "C" int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta,
                                   float* y32, long ldy32, void* y16, long ldy16,
                                   float* mean, float* rstd, float* workspace,
                                   int B, int HW, int C, float eps, int act, void* stream) {
     ADAP_REQUIRE(x && gamma && beta && mean && rstd && workspace && (y32 || y16), ADAP_ERR_SHAPE, "groupnorm_fwd: null pointer");
-    ADAP_REQUIRE(C % GN_G == 0 && C % 4 == 0 && C <= 256 * 4 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_fwd: C=%d", C);
-    ADAP_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, ADAP_ERR_ALIGN, "groupnorm_fwd: x alignment");
+    ADAP_REQUIRE(x_dtype == 0 || x_dtype == 1, ADAP_ERR_UNSUPPORTED, "groupnorm_fwd: x_dtype %d", x_dtype);
+    ADAP_REQUIRE(C % GN_G == 0 && C % 8 == 0 && C <= 256 * 8 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_fwd: C=%d", C);
+    ADAP_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, ADAP_ERR_ALIGN, "groupnorm_fwd: x alignment (ld %% 8, 16-byte base)");
     ADAP_REQUIRE(!y32 || (ldy32 % 4 == 0 && ((uintptr_t)y32 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd: y32 alignment");
-    ADAP_REQUIRE(!y16 || (ldy16 % 4 == 0 && ((uintptr_t)y16 % 8) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd: y16 alignment");
+    ADAP_REQUIRE(!y16 || (ldy16 % 8 == 0 && ((uintptr_t)y16 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd: y16 alignment");
     ADAP_REQUIRE(B > 0 && HW > 0, ADAP_ERR_SHAPE, "groupnorm_fwd: empty");
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, rpc, workspace);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, gamma, beta, workspace, n, eps, act,
-                       rpc, y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd);
+    if (x_dtype == 1) {
+        hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, rpc, workspace);
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, gamma, beta, workspace, n, eps, act,
+                           rpc, y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, rpc, workspace);
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, gamma, beta, workspace, n, eps, act,
+                           rpc, y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd);
+    }
     return adap_check_launch("groupnorm_fwd");
 }
 
@@ -240,48 +302,34 @@ extern "C" int adap_groupnorm_fwd(const float* x, long ldx, const float* gamma, 
 // backward (data gradient).  y = act(xhat*gamma + beta), xhat = (x - mean)*rstd
 //   dz  = dy * act'(z)            dyh = dz * gamma
 //   dx  = rstd * (dyh - mean_g(dyh) - xhat * mean_g(dyh * xhat))
-// pass 1 accumulates per (b, g) the two sums; pass 2 applies.  dy may be f32 or bf16.
+// pass 1 accumulates per (b, g) the two sums; pass 2 applies.  x and dy may each be f32 or bf16.
 // ---------------------------------------------------------------------------------------------
-template <bool DY_BF16>
-__device__ __forceinline__ void load_dy4(const void* dy, size_t off, float* o) {
-    if (DY_BF16) {
-        uint2 v = *(const uint2*)((const uint16_t*)dy + off);
-        o[0] = __builtin_bit_cast(float, v.x << 16);
-        o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
-        o[2] = __builtin_bit_cast(float, v.y << 16);
-        o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
-    } else {
-        float4 v = *(const float4*)((const float*)dy + off);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    }
-}
-
-template <bool DY_BF16>
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
+template <bool XB, bool DYB>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restrict__ dy, long lddy, const void* __restrict__ x,
                                                            long ldx, int HW, int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int act, int rows_per_chunk,
                                                            float* __restrict__ partial) {
-    __shared__ float smA[GN_MAXSLOT * 4 * 256], smB[GN_MAXSLOT * 4 * 256];
+    __shared__ float smA[GN_MAXSLOT * 8 * 256], chA[GN_MAXSLOT * 8 * 256];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
     const GnGeom g = gn_geom(C);
     const int cpg = C / GN_G;
     const int lir = tid % g.TPR, r0 = tid / g.TPR;
-    float sA[GN_MAXSLOT][4], sB[GN_MAXSLOT][4];
+    float sA[GN_MAXSLOT][8], sB[GN_MAXSLOT][8];
 #pragma unroll
     for (int k = 0; k < GN_MAXSLOT; ++k)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sA[k][e] = 0.f; sB[k][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { sA[k][e] = 0.f; sB[k][e] = 0.f; }
     if (r0 < g.rpp) {
-        float sc[GN_MAXSLOT][4], sh[GN_MAXSLOT][4], ga[GN_MAXSLOT][4], be[GN_MAXSLOT][4];
+        float sc[GN_MAXSLOT][8], sh[GN_MAXSLOT][8], ga[GN_MAXSLOT][8], be[GN_MAXSLOT][8];
 #pragma unroll
         for (int k = 0; k < GN_MAXSLOT; ++k) {
             int q = lir + k * g.TPR;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 if (k < g.nslots && q < g.Q) {
-                    int c = 4 * q + e, grp = c / cpg;
+                    int c = 8 * q + e, grp = c / cpg;
                     float rs = rstd[b * GN_G + grp];
                     sc[k][e] = rs;
                     sh[k][e] = -mean[b * GN_G + grp] * rs;
@@ -294,8 +342,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
         const int row_end = min(HW, row_begin + rows_per_chunk);
         const size_t boff = (size_t)b * HW;
         for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNRB) {
-            float4 xv[GN_UNRB][GN_MAXSLOT];
-            float d[GN_UNRB][GN_MAXSLOT][4];
+            float xv[GN_UNRB][GN_MAXSLOT][8], d[GN_UNRB][GN_MAXSLOT][8];
 #pragma unroll
             for (int u = 0; u < GN_UNRB; ++u) {
                 const int rr = r + u * g.rpp;
@@ -303,8 +350,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
                 for (int k = 0; k < GN_MAXSLOT; ++k) {
                     int q = lir + k * g.TPR;
                     if (rr < row_end && k < g.nslots && q < g.Q) {
-                        xv[u][k] = *(const float4*)(x + (boff + rr) * ldx + 4 * q);
-                        load_dy4<DY_BF16>(dy, (boff + rr) * lddy + 4 * q, d[u][k]);
+                        gn_load8<XB>(x, (boff + rr) * ldx + 8 * q, xv[u][k]);
+                        gn_load8<DYB>(dy, (boff + rr) * lddy + 8 * q, d[u][k]);
                     }
                 }
             }
@@ -315,10 +362,9 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
                 for (int k = 0; k < GN_MAXSLOT; ++k) {
                     int q = lir + k * g.TPR;
                     if (rr < row_end && k < g.nslots && q < g.Q) {
-                        float xs[4] = {xv[u][k].x, xv[u][k].y, xv[u][k].z, xv[u][k].w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float xh = xs[e] * sc[k][e] + sh[k][e];
+                        for (int e = 0; e < 8; ++e) {
+                            float xh = xv[u][k][e] * sc[k][e] + sh[k][e];
                             float dz = d[u][k][e];
                             if (act) dz *= dsilu_f(xh * ga[k][e] + be[k][e]);
                             float dyh = dz * ga[k][e];
@@ -330,15 +376,13 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const void* __restric
             }
         }
     }
-    gn_park(smA, sA, tid);
-    gn_park(smB, sB, tid);
-    __syncthreads();
-    if (tid < GN_G)
-        *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = make_float2(gn_group_sum(smA, g, cpg, tid), gn_group_sum(smB, g, cpg, tid));
+    const float ra = gn_block_reduce(smA, chA, sA, g, C, cpg, tid);
+    const float rb = gn_block_reduce(smA, chA, sB, g, C, cpg, tid);
+    if (tid < GN_G) *(float2*)(partial + (((size_t)b * nchunks + chunk) * GN_G + tid) * 2) = make_float2(ra, rb);
 }
 
-template <bool DY_BF16>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ dy, long lddy, const float* __restrict__ x,
+template <bool XB, bool DYB>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restrict__ dy, long lddy, const void* __restrict__ x,
                                                            long ldx, int HW, int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int act,
@@ -349,29 +393,27 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cpg = C / GN_G;
-    if (tid < GN_G) {
-        double a = 0.0, bb = 0.0;
-        const float* pp = partial + ((size_t)b * stats_chunks * GN_G + tid) * 2;
-        for (int c = 0; c < stats_chunks; ++c) {
-            float2 v = *(const float2*)(pp + (size_t)c * GN_G * 2);
-            a += v.x; bb += v.y;
+    {
+        double a, bb;
+        gn_finish_partials(partial, b, stats_chunks, tid, &a, &bb);
+        if ((tid & 7) == 0) {
+            double n = (double)cpg * HW;
+            lA[tid >> 3] = (float)(a / n);
+            lB[tid >> 3] = (float)(bb / n);
         }
-        double n = (double)cpg * HW;
-        lA[tid] = (float)(a / n);
-        lB[tid] = (float)(bb / n);
     }
     __syncthreads();
     const GnGeom g = gn_geom(C);
     const int lir = tid % g.TPR, r0 = tid / g.TPR;
     if (r0 >= g.rpp) return;
-    float sc[GN_MAXSLOT][4], sh[GN_MAXSLOT][4], ga[GN_MAXSLOT][4], be[GN_MAXSLOT][4], mA[GN_MAXSLOT][4], mB[GN_MAXSLOT][4];
+    float sc[GN_MAXSLOT][8], sh[GN_MAXSLOT][8], ga[GN_MAXSLOT][8], be[GN_MAXSLOT][8], mA[GN_MAXSLOT][8], mB[GN_MAXSLOT][8];
 #pragma unroll
     for (int k = 0; k < GN_MAXSLOT; ++k) {
         int q = lir + k * g.TPR;
         if (k < g.nslots && q < g.Q) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int c = 4 * q + e, grp = c / cpg;
+            for (int e = 0; e < 8; ++e) {
+                int c = 8 * q + e, grp = c / cpg;
                 float rs = rstd[b * GN_G + grp];
                 sc[k][e] = rs;
                 sh[k][e] = -mean[b * GN_G + grp] * rs;
@@ -386,8 +428,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
     const int row_end = min(HW, row_begin + rows_per_chunk);
     const size_t boff = (size_t)b * HW;
     for (int r = row_begin + r0; r < row_end; r += g.rpp * GN_UNRB) {
-        float4 xv[GN_UNRB][GN_MAXSLOT], acc4[GN_UNRB][GN_MAXSLOT];
-        float d[GN_UNRB][GN_MAXSLOT][4];
+        float xv[GN_UNRB][GN_MAXSLOT][8], d[GN_UNRB][GN_MAXSLOT][8], ac[GN_UNRB][GN_MAXSLOT][8];
 #pragma unroll
         for (int u = 0; u < GN_UNRB; ++u) {
             const int rr = r + u * g.rpp;
@@ -395,9 +436,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
             for (int k = 0; k < GN_MAXSLOT; ++k) {
                 int q = lir + k * g.TPR;
                 if (rr < row_end && k < g.nslots && q < g.Q) {
-                    xv[u][k] = *(const float4*)(x + (boff + rr) * ldx + 4 * q);
-                    load_dy4<DY_BF16>(dy, (boff + rr) * lddy + 4 * q, d[u][k]);
-                    if (dx32 && accumulate) acc4[u][k] = *(const float4*)(dx32 + (boff + rr) * lddx32 + 4 * q);
+                    gn_load8<XB>(x, (boff + rr) * ldx + 8 * q, xv[u][k]);
+                    gn_load8<DYB>(dy, (boff + rr) * lddy + 8 * q, d[u][k]);
+                    if (dx32 && accumulate) gn_load8<false>(dx32, (boff + rr) * lddx32 + 8 * q, ac[u][k]);
                 }
             }
         }
@@ -408,57 +449,55 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
             for (int k = 0; k < GN_MAXSLOT; ++k) {
                 int q = lir + k * g.TPR;
                 if (rr < row_end && k < g.nslots && q < g.Q) {
-                    float xs[4] = {xv[u][k].x, xv[u][k].y, xv[u][k].z, xv[u][k].w};
-                    float o[4];
+                    float o[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float xh = xs[e] * sc[k][e] + sh[k][e];
+                    for (int e = 0; e < 8; ++e) {
+                        float xh = xv[u][k][e] * sc[k][e] + sh[k][e];
                         float dz = d[u][k][e];
                         if (act) dz *= dsilu_f(xh * ga[k][e] + be[k][e]);
                         float dyh = dz * ga[k][e];
                         o[e] = sc[k][e] * (dyh - mA[k][e] - xh * mB[k][e]);
+                        if (dx32 && accumulate) o[e] += ac[u][k][e];
                     }
-                    if (dx32) {
-                        float* dst = dx32 + (boff + rr) * lddx32 + 4 * q;
-                        if (accumulate) {
-                            o[0] += acc4[u][k].x; o[1] += acc4[u][k].y; o[2] += acc4[u][k].z; o[3] += acc4[u][k].w;
-                        }
-                        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                    if (dx16) {
-                        uint2 w;
-                        w.x = pack_bf16x2(o[0], o[1]);
-                        w.y = pack_bf16x2(o[2], o[3]);
-                        *(uint2*)(dx16 + (boff + rr) * lddx16 + 4 * q) = w;
-                    }
+                    if (dx32) gn_store8_f32(dx32 + (boff + rr) * lddx32 + 8 * q, o);
+                    if (dx16) *(uint4*)(dx16 + (boff + rr) * lddx16 + 8 * q) = pack_bf16x8(o);
                 }
             }
         }
     }
 }
 
-extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const float* x, long ldx,
+template <bool XB, bool DYB>
+static void gn_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, float* dx32, long lddx32, int accumulate, void* dx16,
+                          long lddx16, float* workspace, int B, int HW, int C, int act, int n, int rpc, hipStream_t s) {
+    hipLaunchKernelGGL((gn_bwd_stats_kernel<XB, DYB>), dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
+                       rstd, act, rpc, workspace);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<XB, DYB>), dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
+                       rstd, act, workspace, n, rpc, dx32, lddx32, accumulate, (uint16_t*)dx16, lddx16);
+}
+
+extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
                                   float* workspace, int B, int HW, int C, int act, void* stream) {
     ADAP_REQUIRE(dy && x && gamma && beta && mean && rstd && workspace && (dx32 || dx16), ADAP_ERR_SHAPE, "groupnorm_bwd: null pointer");
-    ADAP_REQUIRE(C % GN_G == 0 && C % 4 == 0 && C <= 256 * 4 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_bwd: C=%d", C);
-    ADAP_REQUIRE(dy_dtype == 0 || dy_dtype == 1, ADAP_ERR_UNSUPPORTED, "groupnorm_bwd: dy_dtype");
-    ADAP_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0, ADAP_ERR_ALIGN, "groupnorm_bwd: ld alignment");
+    ADAP_REQUIRE(C % GN_G == 0 && C % 8 == 0 && C <= 256 * 8 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_bwd: C=%d", C);
+    ADAP_REQUIRE((dy_dtype == 0 || dy_dtype == 1) && (x_dtype == 0 || x_dtype == 1), ADAP_ERR_UNSUPPORTED, "groupnorm_bwd: dtype");
+    ADAP_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, ADAP_ERR_ALIGN,
+                 "groupnorm_bwd: x / dy alignment");
+    ADAP_REQUIRE(!dx32 || (lddx32 % 4 == 0 && ((uintptr_t)dx32 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_bwd: dx32 alignment");
+    ADAP_REQUIRE(!dx16 || (lddx16 % 8 == 0 && ((uintptr_t)dx16 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_bwd: dx16 alignment");
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
     hipStream_t s = (hipStream_t)stream;
-    if (dy_dtype == 1) {
-        hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
-                           rstd, act, rpc, workspace);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
-                           rstd, act, workspace, n, rpc, dx32, lddx32, accumulate, (uint16_t*)dx16, lddx16);
-    } else {
-        hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
-                           rstd, act, rpc, workspace);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
-                           rstd, act, workspace, n, rpc, dx32, lddx32, accumulate, (uint16_t*)dx16, lddx16);
-    }
+#define GN_BWD(XB, DYB) gn_bwd_launch<XB, DYB>(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx32, lddx32, accumulate, dx16, lddx16, \
+                                              workspace, B, HW, C, act, n, rpc, s)
+    if (x_dtype == 1 && dy_dtype == 1) GN_BWD(true, true);
+    else if (x_dtype == 1) GN_BWD(true, false);
+    else if (dy_dtype == 1) GN_BWD(false, true);
+    else GN_BWD(false, false);
+#undef GN_BWD
     return adap_check_launch("groupnorm_bwd");
 }
 

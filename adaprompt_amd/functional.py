@@ -41,10 +41,11 @@ class WeightCache:
         self._packs.clear()
 
 
-def _conv_bwd_data(g, pk, K, pad):
-    """dX of a stride-1 conv: the same implicit GEMM with the flipped/transposed pack."""
-    gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], K, 1, K - 1 - pad)
-    return gx
+def _conv_bwd_data(g, pk, K, pad, bf16=False):
+    """dX of a stride-1 conv: the same implicit GEMM with the flipped/transposed pack.  ``bf16``: the result only
+    feeds a GroupNorm backward, so it is written as bf16 (half the traffic of both kernels)."""
+    gx32, gx16 = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], K, 1, K - 1 - pad, out_f32=not bf16, out_bf16=bf16)
+    return gx16 if bf16 else gx32
 
 
 def _lin_bwd(g, pk, out_f32=True, out_bf16=False):
@@ -64,7 +65,8 @@ class ResBlockFn(torch.autograd.Function):
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
         _, a1, m1, r1 = ops.groupnorm_fwd(x, g1w, g1b, 1e-5, 1)
-        h1, _ = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, chan_add=emb_out)
+        # h1 is block-internal (read only by the second norm and its backward): kept in bf16
+        _, h1 = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, chan_add=emb_out, out_f32=False, out_bf16=True)
         _, a2, m2, r2 = ops.groupnorm_fwd(h1, g2w, g2b, 1e-5, 1)
         if sk is None:
             skip = x
@@ -82,9 +84,9 @@ class ResBlockFn(torch.autograd.Function):
         g1w, g1b = P["gn1"]
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
-        ga2 = _conv_bwd_data(g, c2, 3, 1)                                        # f32
+        ga2 = _conv_bwd_data(g, c2, 3, 1, bf16=True)
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
-        ga1 = _conv_bwd_data(gh1, c1, 3, 1)
+        ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
         if sk is None:
             gx = g.clone(memory_format=torch.contiguous_format)
         else:
@@ -244,7 +246,7 @@ class OutHeadFn(torch.autograd.Function):
         h, m, r = ctx.saved_tensors
         pk = ctx.pk
         g16 = ops.pad_cast_bf16(g.contiguous(), pk.bwd.shape[2])          # 4 -> 8 channels for the K dim
-        ga = _conv_bwd_data(g16, pk, 3, 1)
+        ga = _conv_bwd_data(g16, pk, 3, 1, bf16=True)
         gh, _ = ops.groupnorm_bwd(ga, h, ctx.gn[0], ctx.gn[1], m, r, 1)
         return gh, None, None
 

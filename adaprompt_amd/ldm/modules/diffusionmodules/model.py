@@ -59,7 +59,8 @@ class ResnetBlock(nn.Module):
         c1 = wc.get("conv1", self.conv1.weight, self.conv1.bias)
         c2 = wc.get("conv2", self.conv2.weight, self.conv2.bias)
         _, a1, _, _ = ops.groupnorm_fwd(x, self.norm1.weight, self.norm1.bias, 1e-6, 1)
-        h, _ = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias)
+        # the tensor between conv1 and norm2 is block-internal: bf16
+        _, h = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, out_f32=False, out_bf16=True)
         _, a2, _, _ = ops.groupnorm_fwd(h, self.norm2.weight, self.norm2.bias, 1e-6, 1)
         if self.in_channels != self.out_channels:
             sk = wc.get("nin", self.nin_shortcut.weight, self.nin_shortcut.bias)

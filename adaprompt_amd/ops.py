@@ -218,8 +218,7 @@ def batched_matmul_nt(a, b, out_dtype=F32, alpha=1.0):
 # --------------------------------------------------------------------------------------------
 
 def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
-    """x f32 [B, ..., C] pixel-major -> (y32, y16, mean[B,32], rstd[B,32])"""
-    assert x.dtype == F32
+    """x f32 / bf16 [B, ..., C] pixel-major -> (y32, y16, mean[B,32], rstd[B,32])"""
     B, C = x.shape[0], x.shape[-1]
     rows, ldx = _rows_ld(x)
     HW = rows // B
@@ -229,16 +228,15 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     y32 = torch.empty(x.shape, device=x.device, dtype=F32) if out_f32 else None
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     e0 = TIMER.start() if TIMER is not None else None
-    _lib.call("adap_groupnorm_fwd", x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
+    _lib.call("adap_groupnorm_fwd", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
               mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), B, HW, C, float(eps), int(act), _stream())
     if e0 is not None:
         # algorithmic bytes: read x once (4 B) + write y (2 B bf16 / 4 B f32) per element
-        TIMER.stop("groupnorm_fwd", float(x.numel()) * (4 + (4 if out_f32 else 0) + (2 if out_bf16 else 0)), e0)
+        TIMER.stop("groupnorm_fwd", float(x.numel()) * (x.element_size() + (4 if out_f32 else 0) + (2 if out_bf16 else 0)), e0)
     return y32, y16, mean, rstd
 
 
 def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=False, accumulate_into=None):
-    assert x.dtype == F32
     B, C = x.shape[0], x.shape[-1]
     rows, ldx = _rows_ld(x)
     _, lddy = _rows_ld(dy)
@@ -252,7 +250,7 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=Fa
         dx32 = torch.empty(x.shape, device=x.device, dtype=F32)
     lddx32 = _rows_ld(dx32)[1] if dx32 is not None else 0
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
-    _lib.call("adap_groupnorm_bwd", dy.data_ptr(), _dt(dy), lddy, x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(),
+    _lib.call("adap_groupnorm_bwd", dy.data_ptr(), _dt(dy), lddy, x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
               mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, ws.data_ptr(), B, HW, C, int(act),
               _stream())
     return dx32, dx16

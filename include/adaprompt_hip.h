@@ -81,16 +81,17 @@ int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O, int I, int
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm(32) [+ SiLU]: GroupNorm32 util.py:217-219 (+ nn.SiLU), Normalize attention.py:71-72 and
- * model.py:39-40 (+ nonlinearity model.py:34-36).  x f32 [B][HW][C]; mean/rstd [B][32] are saved for
+ * model.py:39-40 (+ nonlinearity model.py:34-36).  x [B][HW][C] f32 (residual stream) or bf16 (block-internal
+ * tensors), C % 32 == 0; statistics in fp32/fp64; mean/rstd [B][32] are saved for
  * the backward; workspace holds adap_groupnorm_workspace_floats(B,HW,C) floats.  act: 0 none, 1 SiLU.
  */
 long adap_groupnorm_workspace_floats(int B, int HW, int C);
-int adap_groupnorm_fwd(const float* x, long ldx, const float* gamma, const float* beta,
+int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta,
                        float* y32, long ldy32, void* y16, long ldy16,
                        float* mean, float* rstd, float* workspace,
                        int B, int HW, int C, float eps, int act, void* stream);
 /* dx (f32, optionally accumulated into, and/or bf16) from dy (f32 or bf16). */
-int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const float* x, long ldx,
+int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
                        const float* gamma, const float* beta, const float* mean, const float* rstd,
                        float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
                        float* workspace, int B, int HW, int C, int act, void* stream);

@@ -170,6 +170,18 @@ def test_groupnorm_fwd_bwd(B, C, H, eps, act):
     dx32, dx16 = ops.groupnorm_bwd(nhwc(gy), nhwc(x.detach()), gamma, beta, mean, rstd, act, out_f32=True, out_bf16=True)
     assert rel(nchw(dx32), gx_ref) < 2e-5
     assert rel(nchw(dx16.float()), gx_ref) < 4e-3
+    # bf16 input tensor (block-internal activations): same statistics in fp32
+    xb = bf(x.detach()).requires_grad_(True)
+    refb = F.group_norm(xb, 32, gamma, beta, eps)
+    if act:
+        refb = F.silu(refb)
+    yb32, yb16, meanb, rstdb = ops.groupnorm_fwd(nhwc(xb.detach()).to(torch.bfloat16), gamma, beta, eps, act, out_f32=True,
+                                                 out_bf16=True)
+    assert rel(nchw(yb32), refb) < 1e-5 and rel(nchw(yb16.float()), refb) < 4e-3
+    (gxb_ref,) = torch.autograd.grad(refb, xb, gy)
+    _, dxb16 = ops.groupnorm_bwd(nhwc(gy).to(torch.bfloat16), nhwc(xb.detach()).to(torch.bfloat16), gamma, beta, meanb, rstdb,
+                                 act, out_f32=False, out_bf16=True)
+    assert rel(nchw(dxb16.float()), gxb_ref) < 6e-3
     base = rnd(B, H, H, C, seed=9)
     acc = base.clone()
     ops.groupnorm_bwd(nhwc(gy).to(torch.bfloat16), nhwc(x.detach()), gamma, beta, mean, rstd, act, accumulate_into=acc)
