@@ -119,65 +119,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     const int Heff = p.up ? 2 * p.Hin : p.Hin;
     const int Weff = p.up ? 2 * p.Win : p.Win;
 
-    // One staged K tile in registers.  f32 activations stay raw until the LDS write (converting at load time
-    // would put the load's s_waitcnt at the issue point and serialise the pipeline).
-    struct Stage {
-        float4 af[4][2];
-        uint4 b[BROWS];
-    };
-
-    auto load_tile = [&](Stage& st, int kt) {
-        int tap = kt / p.ktiles_per_tap;
-        int c = (kt - tap * p.ktiles_per_tap) * BK + chunk * 8;
-        int ky = tap / p.KW, kx = tap - ky * p.KW;
-        bool cok = c < p.Cin;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-            bool ok = cok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;
-            if (p.up == 2) ok = ok && !((iy | ix) & 1);
-            if (p.up) { iy >>= 1; ix >>= 1; }
-            size_t off = ok ? (size_t)(a_boff[i] + iy * p.Win + ix) * p.ldx + c : 0;
-            float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
-            if (ok) {
-                const float4* src = (const float4*)(xbase + off * 4);
-                f0 = src[0];
-                f1 = src[1];
-            }
-            st.af[i][0] = f0;
-            st.af[i][1] = f1;
-        }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            int n = n0 + srow + 32 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (cok && n < p.Cout)
-                v = *(const uint4*)(wbase + ((size_t)tap * p.Cout + n) * p.Cin + c);
-            st.b[i] = v;
-        }
-    };
-
-    auto store_tile = [&](Stage& st, int buf) {
-        char* a = sA + buf * (BM * 128);
-        char* b = sB + buf * (BN * 128);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = srow + 32 * i;
-            uint4 v;
-            const float4 f0 = st.af[i][0], f1 = st.af[i][1];
-            v.x = pack_bf16x2(f0.x, f0.y);
-            v.y = pack_bf16x2(f0.z, f0.w);
-            v.z = pack_bf16x2(f1.x, f1.y);
-            v.w = pack_bf16x2(f1.z, f1.w);
-            *(uint4*)(a + r * 128 + ((chunk ^ (r & 7)) << 4)) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            int r = srow + 32 * i;
-            *(uint4*)(b + r * 128 + ((chunk ^ (r & 7)) << 4)) = st.b[i];
-        }
-    };
-
     f32x4 acc[MT][PT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -213,18 +154,106 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     };
 
     if constexpr (A_F32) {
-        // f32 activations (gradients, the raw residual stream): register staging with the bf16 conversion on the
-        // way into LDS (guide T14): loads of tile k+1 are issued before tile k is multiplied, written after.
-        Stage S0;
-        load_tile(S0, kt_begin);
-        store_tile(S0, 0);
+        // f32 activations (gradients, the raw residual stream): the pixel operand is register-staged with the bf16
+        // conversion on the way into LDS (guide T14: loads of tile k+1 are issued before tile k is multiplied,
+        // converted and written after); the bf16 weights go by LDS-DMA, which keeps more than half of the tile
+        // bytes off the ds_write path.  Address generation is hoisted as in the LDS-DMA branch.
+        constexpr unsigned OOB = 0x80000000u;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
+        int a_off[4];
+        unsigned a_mask[4], b_base[BROWS], b_kill[BROWS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a_off[i] = (a_boff[i] + a_iy0[i] * p.Win + a_ix0[i]) * (int)p.ldx + chunk * 8;
+            unsigned mk = 0;
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                int ky = t / p.KW, kx = t - ky * p.KW;
+                int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                if (iy >= 0 && iy < Heff && ix >= 0 && ix < Weff) mk |= 1u << t;
+            }
+            a_mask[i] = mk;
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            int n = n0 + srow + 32 * i;
+            b_kill[i] = n < p.Cout ? 0u : OOB;
+            b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
+        }
+        const float* xf = (const float*)xbase;
+        float4 af[4][2];
+        auto load_a = [&](int kt) {
+            int tap = kt / p.ktiles_per_tap;
+            int c0 = (kt - tap * p.ktiles_per_tap) * BK;
+            int ky = tap / p.KW, kx = tap - ky * p.KW;
+            bool cok = c0 + chunk * 8 < p.Cin;
+            const int tapoff = (ky * p.Win + kx) * (int)p.ldx + c0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bool ok;
+                int off;
+                if (p.up == 0) {
+                    ok = cok && ((a_mask[i] >> tap) & 1u);
+                    off = a_off[i] + tapoff;
+                } else {
+                    int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                    ok = cok && iy >= 0 && iy < Heff && ix >= 0 && ix < Weff;
+                    if (p.up == 2) ok = ok && !((iy | ix) & 1);
+                    iy >>= 1; ix >>= 1;
+                    off = (a_boff[i] + iy * p.Win + ix) * (int)p.ldx + c0 + chunk * 8;
+                }
+                float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+                if (ok) {
+                    const float4* src = (const float4*)(xf + off);
+                    f0 = src[0];
+                    f1 = src[1];
+                }
+                af[i][0] = f0;
+                af[i][1] = f1;
+            }
+        };
+        auto store_a = [&](int buf) {
+            char* a = sA + buf * (BM * 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r = srow + 32 * i;
+                uint4 v;
+                v.x = pack_bf16x2(af[i][0].x, af[i][0].y);
+                v.y = pack_bf16x2(af[i][0].z, af[i][0].w);
+                v.z = pack_bf16x2(af[i][1].x, af[i][1].y);
+                v.w = pack_bf16x2(af[i][1].z, af[i][1].w);
+                *(uint4*)(a + r * 128 + ((chunk ^ (r & 7)) << 4)) = v;
+            }
+        };
+        auto stage_b = [&](int buf, int kt) {
+            int tap = kt / p.ktiles_per_tap;
+            int c0 = (kt - tap * p.ktiles_per_tap) * BK;
+            unsigned kill = (c0 + lchunk * 8 < p.Cin) ? 0u : OOB;
+            asm volatile("" : "+v"(kill));
+            const unsigned tapw = (unsigned)((tap * p.Cout * p.Cin + c0) * 2);
+            char* bbase = sB + buf * (BN * 128) + wv * 1024;
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                unsigned voff = (b_base[i] + tapw) | b_kill[i] | kill;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * 4096), 16, voff, 0, 0, 0);
+            }
+        };
+        load_a(kt_begin);
+        stage_b(0, kt_begin);
+        store_a(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1 < kt_end);
-            if (more) load_tile(S0, kt + 1);
+            if (more) {
+                load_a(kt + 1);
+                stage_b(cur ^ 1, kt + 1);
+            }
             compute(cur);
-            if (more) store_tile(S0, cur ^ 1);
+            if (more) store_a(cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur ^= 1;
         }

@@ -565,7 +565,7 @@ extern "C" int adap_layernorm_fwd(const float* x, long ldx, const float* gamma, 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx, long lddx,
-                                                     int accumulate, long rows, int D) {
+                                                     int accumulate, uint16_t* __restrict__ dx16, long lddx16, long rows, int D) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -605,17 +605,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
             }
             *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+            if (dx16) {      // bf16 copy of the (accumulated) residual-stream gradient: operand of the next data-gradient GEMM
+                uint2 w;
+                w.x = pack_bf16x2(o[0], o[1]);
+                w.y = pack_bf16x2(o[2], o[3]);
+                *(uint2*)(dx16 + row * lddx16 + 4 * q) = w;
+            }
         }
     }
 }
 
 extern "C" int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
                                   const float* mean, const float* rstd, float* dx, long lddx, int accumulate,
-                                  long rows, int D, void* stream) {
+                                  void* dx16, long lddx16, long rows, int D, void* stream) {
     ADAP_REQUIRE(dy && x && gamma && mean && rstd && dx, ADAP_ERR_SHAPE, "layernorm_bwd: null pointer");
     ADAP_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV, ADAP_ERR_SHAPE, "layernorm_bwd: D=%d", D);
     if (rows == 0) return ADAP_OK;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
-                       gamma, mean, rstd, dx, lddx, accumulate, rows, D);
+                       gamma, mean, rstd, dx, lddx, accumulate, (uint16_t*)dx16, lddx16, rows, D);
     return adap_check_launch("layernorm_bwd");
 }

@@ -161,21 +161,23 @@ class SpatialTransformerFn(torch.autograd.Function):
         B, H, W, C = x.shape
         N = H * W
         g = g.reshape(B, N, C) if g.is_contiguous() else g.contiguous().view(B, N, C)
-        gt3, _ = _lin_bwd(g, P["proj_out"])                                       # f32 [B,N,C]
+        # every f32 residual-stream gradient also gets a bf16 copy from the kernel that produces it, so the next
+        # data-gradient contraction reads bf16 (LDS-DMA path) instead of converting f32 on the fly
+        gt3, gt3h = _lin_bwd(g, P["proj_out"], out_f32=True, out_bf16=True)       # [B,N,C]
         # feed-forward
-        _, ggg = _lin_bwd(gt3, P["ff2"], out_f32=False, out_bf16=True)           # bf16 [B,N,4C]
-        ghh = ops.geglu_bwd(ggg, hh)                                              # bf16 [B,N,8C]
+        _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)           # bf16 [B,N,4C]
+        ghh = ops.geglu_bwd(ggg, hh)                                               # bf16 [B,N,8C]
         gn3, _ = _lin_bwd(ghh, P["ff1"])
-        gt2 = ops.layernorm_bwd(gn3, t2, P["norm3"][0], l3m, l3r, accumulate_into=gt3)
+        gt2, gt2h = ops.layernorm_bwd(gn3, t2, P["norm3"][0], l3m, l3r, accumulate_into=gt3, want_bf16=True)
         # cross attention
-        _, go2 = _lin_bwd(gt2, P["to_out2"], out_f32=False, out_bf16=True)
+        _, go2 = _lin_bwd(gt2h, P["to_out2"], out_f32=False, out_bf16=True)
         M = kv2.shape[1]
         dq2 = torch.empty(B, N, C, device=x.device, dtype=BF16)
         dkv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
         ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
                           dv=dkv2[..., C:])
         gn2, _ = _lin_bwd(dq2, P["q2"])
-        gt1 = ops.layernorm_bwd(gn2, t1, P["norm2"][0], l2m, l2r, accumulate_into=gt2)
+        gt1, gt1h = ops.layernorm_bwd(gn2, t1, P["norm2"][0], l2m, l2r, accumulate_into=gt2, want_bf16=True)
         g_ck = g_cv = None
         if ctx.same_ctx:
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
@@ -186,14 +188,14 @@ class SpatialTransformerFn(torch.autograd.Function):
             if ctx.needs_input_grad[2]:
                 g_cv, _ = _lin_bwd(dkv2[..., C:], P["v2"])
         # self attention
-        _, go1 = _lin_bwd(gt1, P["to_out1"], out_f32=False, out_bf16=True)
+        _, go1 = _lin_bwd(gt1h, P["to_out1"], out_f32=False, out_bf16=True)
         dqkv1 = torch.empty(B, N, 3 * C, device=x.device, dtype=BF16)
         ops.attention_bwd(qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:], o1, go1, lse1, heads, ctx.key_mask,
                           dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:])
         gn1, _ = _lin_bwd(dqkv1, P["qkv1"])
-        gt0 = ops.layernorm_bwd(gn1, t0, P["norm1"][0], l1m, l1r, accumulate_into=gt1)
+        gt0, gt0h = ops.layernorm_bwd(gn1, t0, P["norm1"][0], l1m, l1r, accumulate_into=gt1, want_bf16=True)
         # proj_in, GroupNorm
-        _, gxn = _lin_bwd(gt0, P["proj_in"], out_f32=False, out_bf16=True)
+        _, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=False, out_bf16=True)
         gx = g.clone(memory_format=torch.contiguous_format).view(B, H, W, C)
         gnw, gnb = P["norm"]
         ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, accumulate_into=gx)

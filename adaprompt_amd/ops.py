@@ -268,7 +268,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None, want_bf16=False):
+    """-> dx f32 (accumulated into ``accumulate_into`` when given) [, bf16 copy of the final dx]"""
     assert dy.dtype == F32 and x.dtype == F32
     rows, ldx = _rows_ld(x)
     _, lddy = _rows_ld(dy)
@@ -277,9 +278,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None):
         dx, acc = torch.empty(x.shape, device=x.device, dtype=F32), 0
     else:
         dx, acc = accumulate_into, 1
+    dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     _lib.call("adap_layernorm_bwd", dy.data_ptr(), lddy, x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
-              rstd.data_ptr(), dx.data_ptr(), _rows_ld(dx)[1], acc, rows, D, _stream())
-    return dx
+              rstd.data_ptr(), dx.data_ptr(), _rows_ld(dx)[1], acc, _ptr(dx16), D, rows, D, _stream())
+    return (dx, dx16) if want_bf16 else dx
 
 
 # --------------------------------------------------------------------------------------------

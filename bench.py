@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per micro-batch (reference: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the micro-batch as two hipGraphs (fwd, bwd) instead of launching eagerly; measured "
+                         "45.1 vs 44.3 ms/step on MI355X -- the step is GPU-bound, not launch-bound, so eager is the default")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -154,16 +157,69 @@ def main():
     batches = [synthetic_batch(B, device, 1234 + rank * 100 + i) for i in range(2)]
     gen = torch.Generator(device=device).manual_seed(99 + rank)
 
-    def step(i):
+    # ---- hipGraph capture of the launch-bound part (~1400 kernel launches per micro-batch): forward and backward
+    # are two graphs, so the previous micro-batch's gradient all-reduce can be awaited between them.  Inputs live in
+    # static buffers; RNG draws, the collective, clip and the optimizer step stay outside the graphs.
+    static = {k: v.clone() for k, v in batches[0].items()}
+    st_t = torch.zeros(B, device=device, dtype=torch.int64)
+    st_noise = torch.zeros(B, 4, 64, 64, device=device)
+    st_pn = torch.zeros(B, 4, 64, 64, device=device)
+    graphs = None
+
+    def draw(i):
         batch = batches[i % 2]
-        t = torch.randint(0, 1000, (B,), device=device, generator=gen)
-        noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
-        pn = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+        for k in static:
+            static[k].copy_(batch[k])
+        st_t.copy_(torch.randint(0, 1000, (B,), device=device, generator=gen))
+        st_noise.copy_(torch.randn(B, 4, 64, 64, device=device, generator=gen))
+        st_pn.copy_(torch.randn(B, 4, 64, 64, device=device, generator=gen))
+
+    def fwd():
         # the all-reduce issued by the previous micro-batch overlaps this VAE encode + UNet forward and is
         # awaited just before this micro-batch's backward writes into the gradient buffer
-        loss, grad, out, aux = ld.shared_step(batch, t=t, noise=noise, post_noise=pn)
-        reducer.wait()
-        out.backward(grad)
+        return ld.shared_step(static, t=st_t, noise=st_noise, post_noise=st_pn)
+
+    def capture():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(2):                    # warm-up on the capture stream (weight packs, workspaces, BLAS handles)
+                draw(i)
+                loss, grad, out, aux = fwd()
+                out.backward(grad)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        reducer.zero()
+        g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_f):
+            loss, grad, out, aux = fwd()
+        with torch.cuda.graph(g_b, pool=g_f.pool()):
+            out.backward(grad)
+        torch.cuda.synchronize()
+        reducer.zero()
+        return g_f, g_b, loss
+
+    if args.graph:
+        try:
+            graphs = capture()
+        except Exception as e:          # noqa: BLE001 -- report and run eagerly; the result line says which mode ran
+            if rank == 0:
+                print(f"warning: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+            reducer.zero()
+
+    def step(i):
+        draw(i)
+        if graphs is not None:
+            g_f, g_b, loss = graphs
+            g_f.replay()
+            reducer.wait()
+            g_b.replay()
+        else:
+            loss, grad, out, aux = fwd()
+            reducer.wait()
+            out.backward(grad)
         reducer.reduce()
         ld.batch_idx += 1
         if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
@@ -197,8 +253,10 @@ def main():
     if not args.no_roofline:
         # live HIP-event timing of the dominant kernel family on the same workload (2 extra, separately run steps)
         ops.TIMER = ops.KernelTimer()
+        saved_graphs, graphs = graphs, None          # per-launch events need eager launches
         for i in range(2):
             step(i)
+        graphs = saved_graphs
         summ = ops.TIMER.summary()
         ops.TIMER = None
         c = summ["conv_gemm"]
@@ -228,7 +286,7 @@ def main():
             "metric": "SD-1.5 UNet training images/sec @512px bs=4/GPU",
             "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None,
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
                                    "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, "
                                    "hook stand-in with 149M trainable fp32 params, clip+AdamW step every 2nd micro-batch",

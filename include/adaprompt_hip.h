@@ -96,12 +96,13 @@ int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const void* x, i
                        float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
                        float* workspace, int B, int HW, int C, int act, void* stream);
 
-/* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3, attention.py:267-269,275-285. */
+/* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3, attention.py:267-269,275-285.
+ * bwd: dx (f32, optionally accumulated into) and optionally dx16, a bf16 copy of the final dx. */
 int adap_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y16, long ldy,
                        float* mean, float* rstd, long rows, int D, float eps, void* stream);
 int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
                        const float* mean, const float* rstd, float* dx, long lddx, int accumulate,
-                       long rows, int D, void* stream);
+                       void* dx16, long lddx16, long rows, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CrossAttention core, attention.py:195-243: softmax((q k^T) * scale [+ key mask]) v, fused.

@@ -200,8 +200,9 @@ def test_layernorm_fwd_bwd(rows, D):
     dx = ops.layernorm_bwd(gy, x.detach(), gamma, mean, rstd)
     assert rel(dx, gx_ref) < 2e-5
     acc = torch.ones_like(dx)
-    ops.layernorm_bwd(gy, x.detach(), gamma, mean, rstd, accumulate_into=acc)
-    assert rel(acc - 1, gx_ref) < 2e-5
+    acc2, acc16 = ops.layernorm_bwd(gy, x.detach(), gamma, mean, rstd, accumulate_into=acc, want_bf16=True)
+    assert acc2 is acc and rel(acc - 1, gx_ref) < 2e-5
+    assert torch.equal(acc16, acc.to(torch.bfloat16))
 
 
 # ---------------------------------------------------------------------------------------------
