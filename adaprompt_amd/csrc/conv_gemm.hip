@@ -438,14 +438,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p, int M,
 // 256-wide tile halves that, and the two-step prefetch covers ~2 x 640 MFMA cycles of memory latency.
 // =============================================================================================
 #define BMB 256
-template <int BN>
-__global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
+#define WAIT_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform; the immediate must be a literal
+    switch (n) {
+        WAIT_VMCNT_CASE(0) WAIT_VMCNT_CASE(1) WAIT_VMCNT_CASE(2) WAIT_VMCNT_CASE(3) WAIT_VMCNT_CASE(4) WAIT_VMCNT_CASE(5)
+        WAIT_VMCNT_CASE(6) WAIT_VMCNT_CASE(7) WAIT_VMCNT_CASE(8) WAIT_VMCNT_CASE(9) WAIT_VMCNT_CASE(10) WAIT_VMCNT_CASE(11)
+        WAIT_VMCNT_CASE(12) WAIT_VMCNT_CASE(13) WAIT_VMCNT_CASE(14) WAIT_VMCNT_CASE(15) WAIT_VMCNT_CASE(16) WAIT_VMCNT_CASE(17)
+        WAIT_VMCNT_CASE(18) WAIT_VMCNT_CASE(19) WAIT_VMCNT_CASE(20) WAIT_VMCNT_CASE(21) WAIT_VMCNT_CASE(22) WAIT_VMCNT_CASE(23)
+        WAIT_VMCNT_CASE(24) WAIT_VMCNT_CASE(25) WAIT_VMCNT_CASE(26) WAIT_VMCNT_CASE(27)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// BMT = 256 (8 waves, NST = 3: the large-problem variant above) or 128 (4 waves, NST = 4: problems with fewer
+// workgroups than CUs, where occupancy is moot and the latency of one workgroup's K loop is everything -- three K
+// steps of DMA in flight instead of one).
+template <int BMT, int BN, int NST>
+__global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
     constexpr int WN = BN / 2;
     constexpr int MT = WN / 16;
     constexpr int PT = 4;
-    constexpr int NST = 3;
-    constexpr int A_STAGE = BMB * 128, B_STAGE = BN * 128;
-    constexpr int BPASS = (BN + 63) / 64;
+    constexpr int RP = BMT / 4;                       // rows staged per pass (threads / 8)
+    constexpr int A_STAGE = BMT * 128, B_STAGE = BN * 128;
+    constexpr int BPASS = (BN + RP - 1) / RP;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -455,13 +470,14 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wv & 3, wn = wv >> 2;
+    const int wm = (BMT == 256) ? (wv & 3) : (wv & 1);
+    const int wn = (BMT == 256) ? (wv >> 2) : (wv >> 1);
 
     const int nwg = p.ntiles_m * p.ntiles_n;
     const int bid = xcd_remap(blockIdx.x, nwg);
     const int tn = bid % p.ntiles_n;
     const int tm = bid / p.ntiles_n;
-    const int m0 = tm * BMB, n0 = tn * BN;
+    const int m0 = tm * BMT, n0 = tn * BN;
     const int HWo = p.Hout * p.Wout;
     const int M = p.B * HWo;
 
@@ -472,13 +488,13 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
         kt_end = min(p.ktiles_total, kt_begin + per);
     }
 
-    const int srow = tid >> 3;                        // 0..63
+    const int srow = tid >> 3;                        // 0..RP-1
     const int rsw = (lane >> 3) & 7;
     const int lchunk = (lane & 7) ^ rsw;
     int a_iy0[4], a_ix0[4], a_boff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int m = m0 + srow + 64 * i;
+        int m = m0 + srow + RP * i;
         if (m < M) {
             int b = m / HWo, r = m - b * HWo;
             int oy = r / p.Wout, ox = r - oy * p.Wout;
@@ -499,7 +515,7 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
     // weight-row passes this wave takes part in (a pass = 64 rows, a wave = 8 of them): 4 A + nB B loads per stage
     int nB = 0;
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) nB += (64 * i + 8 * wv < BN) ? 1 : 0;
+    for (int i = 0; i < BPASS; ++i) nB += (RP * i + 8 * wv < BN) ? 1 : 0;
 
     // hoisted address generation (see conv_gemm_kernel): per row a base offset + a tap-validity mask
     unsigned a_base[4], a_mask[4], b_base[BPASS], b_kill[BPASS];
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-        int n = n0 + srow + 64 * i;
+        int n = n0 + srow + RP * i;
         b_kill[i] = n < p.Cout ? 0u : OOB;
         b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
     }
@@ -538,13 +554,13 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
             for (int i = 0; i < 4; ++i) {
                 unsigned inval = ((a_mask[i] >> tap) & 1u) - 1u;
                 unsigned voff = (a_base[i] + tapoff) | (inval & OOB) | kill;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * 8192), 16, voff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * (RP * 128)), 16, voff, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < BPASS; ++i) {
-                if (64 * i + 8 * wv < BN) {               // wave-uniform
+                if (RP * i + 8 * wv < BN) {               // wave-uniform
                     unsigned voff = (b_base[i] + tapw) | b_kill[i] | kill;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * 8192), 16, voff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * (RP * 128)), 16, voff, 0, 0, 0);
                 }
             }
         }
@@ -584,24 +600,22 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvParams p) {
     };
 
     const int ntl = kt_end - kt_begin;
-    if (ntl > 0) stage(0, kt_begin);
-    if (ntl > 1) stage(1, kt_begin + 1);
+    const int L = 4 + nB;                               // DMA instructions this wave issues per stage
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+        if (i < ntl) stage(i, kt_begin + i);
     int buf = 0;
     for (int t = 0; t < ntl; ++t) {
-        // tile t has landed once at most the loads of tile t+1 (one stage = 4 + nB per wave) are outstanding
-        if (t + 1 < ntl) {
-            if (nB == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else if (nB == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // tile t has landed once only the stages issued after it (tiles t+1 .. t+NST-2) can still be in flight
+        int ahead = ntl - 1 - t;
+        if (ahead > NST - 2) ahead = NST - 2;
+        wait_vmcnt(ahead * L);
         __builtin_amdgcn_s_barrier();          // tile t visible to every wave; every wave is done with tile t-1
         asm volatile("" ::: "memory");
-        if (t + 2 < ntl) {
-            int nb = buf + 2;
+        if (t + NST - 1 < ntl) {
+            int nb = buf + NST - 1;
             if (nb >= NST) nb -= NST;
-            stage(nb, kt_begin + t + 2);       // refills the buffer tile t-1 was multiplied from
+            stage(nb, kt_begin + t + NST - 1); // refills the buffer tile t-1 was multiplied from
         }
         compute(buf);
         if (++buf == NST) buf = 0;
@@ -655,20 +669,20 @@ static void launch_reduce(const ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, M, p.Hout * p.Wout);
 }
 
-template <int BN>
-static int launch_big(const ConvParams& p, hipStream_t stream) {
-    size_t lds = 3 * BMB * 128 + 3 * BN * 128;
+template <int BMT, int BN, int NST>
+static int launch_ring(const ConvParams& p, hipStream_t stream) {
+    size_t lds = (size_t)NST * (BMT + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_gemm_big_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<BMT, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
         attr_set = true;
     }
     dim3 grid(p.ntiles_m * p.ntiles_n, 1, p.ksplit);
-    hipLaunchKernelGGL((conv_gemm_big_kernel<BN>), grid, dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((conv_gemm_ring_kernel<BMT, BN, NST>), grid, dim3(BMT * 2), lds, stream, p);
     if (p.ksplit > 1) launch_reduce(p, stream);
-    return adap_check_launch("conv_gemm_big");
+    return adap_check_launch("conv_gemm_ring");
 }
-
 
 // =============================================================================================
 // 3x3 / stride 1 / pad 1 convolution with an LDS-staged STENCIL WINDOW (the ResBlock and VAE ResnetBlock convs,
@@ -956,7 +970,10 @@ static int choose_ksplit(long M, int Cout, int ktiles_total, bool big) {
     int bm = big ? BMB : BM;
     long blocks = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     long enough = big ? 200 : 384, target = big ? 256 : 512;
-    if (blocks >= enough || ktiles_total < 24) return 1;     // short-K layers: the reduce pass would cost more than it saves
+    // Few workgroups: besides idle CUs, every workgroup then streams a large slice of (cold, HBM-resident) weights
+    // through ONE CU's ~10 B/clk fetch path.  Spread the K loop over more workgroups -- but only for long-K layers:
+    // for short K the slab reduce pass costs what the split saves (measured both ways on the UNet's 1x1 layers).
+    if (blocks >= enough || ktiles_total < 24) return 1;
     int ks = (int)((target + blocks - 1) / blocks);
     int cap = ktiles_total / 4;
     if (ks > cap) ks = cap;
@@ -1060,8 +1077,15 @@ extern "C" int adap_conv2d_nhwc(
         return launch_halo<128>(p, s);
     }
     if (big) {
-        if (bn == 160) return launch_big<160>(p, s);
-        return launch_big<128>(p, s);
+        if (bn == 160) return launch_ring<256, 160, 3>(p, s);
+        return launch_ring<256, 128, 3>(p, s);
+    }
+    // few workgroups (< 1.2 per CU): the 4-deep LDS-DMA ring hides the K-loop latency that occupancy cannot
+    if (x_dtype == 1 && nbatch == 1 && up == 0 && p.ktiles_total >= 4 &&
+        (long)p.ntiles_m * p.ntiles_n * p.ksplit <= 300) {
+        if (bn == 160) return launch_ring<128, 160, 4>(p, s);
+        if (bn == 128) return launch_ring<128, 128, 4>(p, s);
+        return launch_ring<128, 64, 4>(p, s);
     }
     if (x_dtype == 0) {
         if (bn == 160) return launch<160, true>(p, nbatch, s);
