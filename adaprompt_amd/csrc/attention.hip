@@ -196,39 +196,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[t], 0, 0, 0);
             }
         }
-        // scale, bias, running max
+        // scale, (bias), running max.  Only the last key tile (ragged M) and masked self-attention need the per-key
+        // bias; the common tile does max on the raw scores and folds the scale into the exponent's FMA.
+        const bool tile_bias = (p.kmask != nullptr) || (kt * 64 + 64 > p.M);     // wave-uniform
         float mx = -INFINITY;
+        if (tile_bias) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
-                float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                for (int g = 0; g < 4; ++g) {
+                    float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
+                    float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sv = S[t][4 * g + e] * cs + bb[e];
-                    S[t][4 * g + e] = sv;
-                    mx = fmaxf(mx, sv);
+                    for (int e = 0; e < 4; ++e) {
+                        float sv = S[t][4 * g + e] * cs + bb[e];
+                        S[t][4 * g + e] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
                 }
-            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
+            mx *= cs;
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(m, mx);
-        const float alpha = exp2f(m - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        const bool moved = __any(mnew != m);           // wave-uniform: skip the accumulator rescale when no row's max grew
         m = mnew;
         float psum = 0.f;
+        if (tile_bias) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = exp2f(S[t][r] - mnew);
-                S[t][r] = pv;
-                psum += pv;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(S[t][r] - mnew);
+                    S[t][r] = pv;
+                    psum += pv;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][r], cs, -mnew));
+                    S[t][r] = pv;
+                    psum += pv;
+                }
+        }
         l = l * alpha + psum;
+        if (moved) {
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt)
+            for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[vt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[vt][r] *= alpha;
+        }
         // O^T += V^T P^T
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
                 float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pv = exp2f(S[4 * g + e] * cs + bb[e] - lse2);
+                    float pv = __builtin_amdgcn_exp2f(S[4 * g + e] * cs + bb[e] - lse2);
                     S[4 * g + e] = pv * (dP[4 * g + e] - dl);      // dS^T
                 }
             }
@@ -524,7 +548,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
                 float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pv = exp2f(S[4 * g + e] * cs + bias - ll[e]);
+                    float pv = __builtin_amdgcn_exp2f(S[4 * g + e] * cs + bias - ll[e]);
                     S[4 * g + e] = pv;                                   // P
                     dP[4 * g + e] = pv * (dP[4 * g + e] - dd[e]);        // dS
                 }
@@ -680,14 +704,17 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
                                                            float* __restrict__ qout, int B, int H, int N, int M, int d,
                                                            float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sKT = (float*)smem;            // [d][Mp]  (Mp = M rounded up to 64, +1 pad)
-    const int Mp = ((M + 63) / 64) * 64 + 1;
-    float* sQ = sKT + d * Mp;             // [4][d]
+    const int dp = d + 4;                  // padded row: float4 reads of consecutive keys land on different banks
+    float* sK = (float*)smem;              // [M][dp]
+    float* sQ = sK + M * dp;               // [4 waves][d]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
-    for (int idx = tid; idx < M * d; idx += 256) {
-        int key = idx / d, dd = idx - key * d;
-        sKT[dd * Mp + key] = bf16_to_f32(k[((size_t)b * M + key) * ldk + head * d + dd]);
+    for (int idx = tid; idx < M * (d / 4); idx += 256) {
+        int key = idx / (d / 4), c4 = idx - key * (d / 4);
+        uint2 raw = *(const uint2*)(k + ((size_t)b * M + key) * ldk + head * d + 4 * c4);
+        float4 v = make_float4(__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xffff0000u),
+                               __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xffff0000u));
+        *(float4*)(sK + key * dp + 4 * c4) = v;
     }
     __syncthreads();
     const float qs = sqrtf(scale);
@@ -700,7 +727,7 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
             sQ[w * d + dd] = qv;
             if (qout) qout[(((size_t)b * H + head) * N + n) * d + dd] = qv * qs;
         }
-        __builtin_amdgcn_s_waitcnt(0);    // LDS writes of this wave visible to itself (single wave uses sQ[w])
+        __builtin_amdgcn_s_waitcnt(0);    // this wave's LDS writes are visible to its own later reads
         __builtin_amdgcn_wave_barrier();
         float sv[3];
         float mx = -INFINITY;
@@ -709,9 +736,14 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
             int key = lane + 64 * kk;
             float acc = -INFINITY;
             if (key < M) {
-                acc = 0.f;
-                for (int dd = 0; dd < d; ++dd) acc += sQ[w * d + dd] * sKT[dd * Mp + key];
-                acc *= scale;
+                const float4* kr = (const float4*)(sK + key * dp);
+                const float4* qr = (const float4*)(sQ + w * d);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int c4 = 0; c4 < d / 4; ++c4) {
+                    float4 kv = kr[c4], qv = qr[c4];
+                    a0 += kv.x * qv.x; a1 += kv.y * qv.y; a2 += kv.z * qv.z; a3 += kv.w * qv.w;
+                }
+                acc = ((a0 + a1) + (a2 + a3)) * scale;
             }
             sv[kk] = acc;
             mx = fmaxf(mx, acc);
@@ -739,8 +771,8 @@ extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, lo
     ADAP_REQUIRE(q && k && (attnscore || attn || q_scaled), ADAP_ERR_SHAPE, "attention_capture: null pointer");
     ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture: M=%d (cross-attention only, <= 192)", M);
     ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture: d=%d", d);
-    int Mp = ((M + 63) / 64) * 64 + 1;
-    size_t lds = ((size_t)d * Mp + 4 * d) * 4;
+    ADAP_REQUIRE(d % 4 == 0, ADAP_ERR_UNSUPPORTED, "attention_capture: d must be a multiple of 4");
+    size_t lds = ((size_t)M * (d + 4) + 4 * d) * 4;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void*)attn_capture_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -996,6 +996,12 @@ extern "C" long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin,
     return ks > 1 ? (long)ks * M * Cout : 0;
 }
 
+// which kernel the last adap_conv2d_nhwc call of this thread dispatched to (bench.py's per-kernel roofline):
+// 1000*variant + BN, variant 0 = conv_gemm_kernel f32 activations, 1 = conv_gemm_kernel bf16, 2 = conv_gemm_ring_kernel<256,.,3>,
+// 3 = conv_gemm_ring_kernel<128,.,4>, 4 = conv3x3_halo_kernel
+static thread_local int g_last_variant = -1;
+extern "C" int adap_conv2d_last_variant(void) { return g_last_variant; }
+
 extern "C" int adap_conv2d_nhwc(
     const void* x, int x_dtype, long ldx,
     const void* w_packed,
@@ -1072,21 +1078,25 @@ extern "C" int adap_conv2d_nhwc(
     const int bn = choose_bn(Cout);
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (halo) {
+        g_last_variant = 4000 + bn;
         p.ntiles_m = B * (Hin / HALO_TH) * (Win / HALO_TW);
         if (bn == 160) return launch_halo<160>(p, s);
         return launch_halo<128>(p, s);
     }
     if (big) {
+        g_last_variant = 2000 + bn;
         if (bn == 160) return launch_ring<256, 160, 3>(p, s);
         return launch_ring<256, 128, 3>(p, s);
     }
     // few workgroups (< 1.2 per CU): the 4-deep LDS-DMA ring hides the K-loop latency that occupancy cannot
     if (x_dtype == 1 && nbatch == 1 && up == 0 && p.ktiles_total >= 4 &&
         (long)p.ntiles_m * p.ntiles_n * p.ksplit <= 300) {
+        g_last_variant = 3000 + bn;
         if (bn == 160) return launch_ring<128, 160, 4>(p, s);
         if (bn == 128) return launch_ring<128, 128, 4>(p, s);
         return launch_ring<128, 64, 4>(p, s);
     }
+    g_last_variant = (x_dtype == 0 ? 0 : 1000) + bn;
     if (x_dtype == 0) {
         if (bn == 160) return launch<160, true>(p, nbatch, s);
         if (bn == 128) return launch<128, true>(p, nbatch, s);

@@ -182,7 +182,10 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
               up, float(alpha), ksplit, _ptr(ws), 1, 0, 0, 0, 0, _stream())
     if e0 is not None:
         # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
-        TIMER.stop("conv_gemm", 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0,
+        v = _lib.call_long("adap_conv2d_last_variant")
+        kname = {0: "conv_gemm_kernel<{bn}, true>", 1: "conv_gemm_kernel<{bn}, false>", 2: "conv_gemm_ring_kernel<256, {bn}, 3>",
+                 3: "conv_gemm_ring_kernel<128, {bn}, 4>", 4: "conv3x3_halo_kernel<{bn}>"}[v // 1000].format(bn=v % 1000)
+        TIMER.stop(kname, 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0,
                    f"M={B * Ho * Wo} N={Cout} K={Cin}x{KH * KH} s{stride} up{up} {'f32' if x.dtype == F32 else 'bf16'}")
     return y32, y16
 

@@ -72,6 +72,8 @@ int adap_conv2d_nhwc(const void* x, int x_dtype, long ldx, const void* w_packed,
                      void* stream);
 
 long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW);
+/* which kernel variant the calling thread's last adap_conv2d_nhwc dispatched to (1000*variant + channel tile; profiling aid) */
+int adap_conv2d_last_variant(void);
 
 /* OIHW f32 (checkpoint layout, ddpm.py:321-344) -> bf16 [KH*KW][rows][cols].
  * mode 0 (forward): rows >= O, cols >= I, out[t][o][i] = w[o][i][ky][kx] (zero padded).
