@@ -189,8 +189,11 @@ class LatentDiffusion(DDPM):
         return loss, grad.permute(0, 3, 1, 2)
 
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
-    def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None):
-        x_start, mask = self.get_input(batch, post_noise)
+    def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None):
+        """``x_start``: a latent already encoded for this batch (e.g. by ``LatentPrefetcher`` on a side stream while
+        the previous micro-batch's UNet pass was running); otherwise the batch is encoded here."""
+        if x_start is None:
+            x_start, _mask = self.get_input(batch, post_noise)
         B = x_start.shape[0]
         if t is None:
             t = torch.randint(0, self.num_timesteps, (B,), device=x_start.device).long()
@@ -210,6 +213,9 @@ class LatentDiffusion(DDPM):
         loss, grad = self.calc_recon_loss(model_output, noise, img_mask, fg_mask, 1.0, self.bg_pixel_weight)
         return loss, grad, model_output, {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
 
+    def make_prefetcher(self):
+        return LatentPrefetcher(self)
+
     def training_step(self, batch, optimizer=None, reducer=None, **step_kwargs):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
         the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync)."""
@@ -228,3 +234,36 @@ class LatentDiffusion(DDPM):
             optimizer.step()
             optimizer.zero_grad(set_to_none=False)
         return loss, aux
+
+
+class LatentPrefetcher:
+    """Software pipelining of the no-grad first stage: the VAE encode of micro-batch i+1 is issued on a second HIP
+    stream while micro-batch i's UNet forward/backward runs on the main stream.  The UNet's 32x32 .. 8x8 levels launch
+    only 16-128 workgroups, so most of the 256 CUs idle during them; the encoder's large grids fill those CUs.  The
+    work per step is unchanged (one encode + one UNet pass); only the issue order across streams changes.
+
+        pf = model.make_prefetcher(); pf.submit(batch0, noise0)
+        for i: x_start = pf.get(); pf.submit(batch[i+1], noise[i+1]); model.shared_step(batch[i], x_start=x_start, ...)
+    """
+
+    def __init__(self, model):
+        self.model = model
+        self.stream = torch.cuda.Stream()
+        self._pending = None
+
+    def submit(self, batch, post_noise=None):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)                 # inputs written on the main stream are visible
+        with torch.cuda.stream(self.stream):
+            x_start, _ = self.model.get_input(batch, post_noise)
+            x_start = x_start.contiguous()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._pending = (x_start, ev)
+
+    def get(self):
+        x_start, ev = self._pending
+        self._pending = None
+        torch.cuda.current_stream().wait_event(ev)
+        x_start.record_stream(torch.cuda.current_stream())
+        return x_start
