@@ -93,7 +93,8 @@ __device__ __forceinline__ void stage_tile(char* dst, int stride, int nch, const
 }
 
 // Register-staged prefetch of a [64 x NCH*8] bf16 tile: the global loads of tile t+1 are issued before tile t is
-// multiplied and written to LDS after it (guide T14), so HBM/L2 latency hides under the MFMA phase.
+// multiplied and written to LDS after it (guide T14), so HBM/L2 latency hides under the MFMA phase.  The chunk ->
+// (row, column) decode is done once per kernel (TileMap), not per tile.
 template <int NCH>
 struct TileRegs {
     static constexpr int CPT = (64 * NCH + 255) / 256;
@@ -101,25 +102,39 @@ struct TileRegs {
 };
 
 template <int NCH>
-__device__ __forceinline__ void tile_load(TileRegs<NCH>& r, const uint16_t* src, long ld, int nvalid, int d, int tid) {
+struct TileMap {
+    static constexpr int CPT = (64 * NCH + 255) / 256;
+    int row[CPT];       // tile row of chunk i, or 64 (never valid)
+    int goff[CPT];      // element offset in the global tile
+    int loff[CPT];      // byte offset in the LDS image, or -1
+    __device__ __forceinline__ void init(long ld, int stride, int d, int tid) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            int idx = tid + 256 * i;
+            int r = idx / NCH, ch = idx - r * NCH;
+            bool in = idx < 64 * NCH;
+            row[i] = (in && ch * 8 < d) ? r : 64;
+            goff[i] = (int)(r * ld) + ch * 8;
+            loff[i] = in ? r * stride + ch * 16 : -1;
+        }
+    }
+};
+
+template <int NCH>
+__device__ __forceinline__ void tile_load(TileRegs<NCH>& r, const TileMap<NCH>& mp, const uint16_t* src, int nvalid) {
 #pragma unroll
     for (int i = 0; i < TileRegs<NCH>::CPT; ++i) {
-        int idx = tid + 256 * i;
-        int row = idx / NCH, ch = idx - row * NCH;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (idx < 64 * NCH && row < nvalid && ch * 8 < d) v = *(const uint4*)(src + (size_t)row * ld + ch * 8);
+        if (mp.row[i] < nvalid) v = *(const uint4*)(src + mp.goff[i]);
         r.v[i] = v;
     }
 }
 
 template <int NCH>
-__device__ __forceinline__ void tile_store(const TileRegs<NCH>& r, char* dst, int stride, int tid) {
+__device__ __forceinline__ void tile_store(const TileRegs<NCH>& r, const TileMap<NCH>& mp, char* dst) {
 #pragma unroll
-    for (int i = 0; i < TileRegs<NCH>::CPT; ++i) {
-        int idx = tid + 256 * i;
-        int row = idx / NCH, ch = idx - row * NCH;
-        if (idx < 64 * NCH) *(uint4*)(dst + row * stride + ch * 16) = r.v[i];
-    }
+    for (int i = 0; i < TileRegs<NCH>::CPT; ++i)
+        if (mp.loff[i] >= 0) *(uint4*)(dst + mp.loff[i]) = r.v[i];
 }
 
 // =============================================================================================
@@ -142,6 +157,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
 
+    // Q fragments stay exactly the caller's bf16 values: scale*log2(e) is applied in f32 inside the exponent's fma
+    // (pre-multiplying Q would round q*cs to bf16 again and cost ~2e-4 of LSE accuracy for ~1% of a step)
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -157,11 +174,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[vt][r] = 0.f;
     float m = -INFINITY, l = 0.f;
+    // When the V tile has a spare column (32*VT > d) it is set to 1.0, so row d of O^T accumulates sum_k p -- the
+    // softmax denominator comes out of the PV MFMA for free (d = 40, 80; not 160).
+    const bool ones_col = 32 * VT > d;
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
     const int ntiles = (p.M + 63) / 64;
     TileRegs<G::NCH> rK, rV;
+    TileMap<G::NCH> mapK, mapV;
+    mapK.init(p.ldk, KSTRIDE, d, tid);
+    mapV.init(p.ldv, VSTRIDE, d, tid);
+    // per-key additive bias of a tile (ragged last tile: -inf, masked keys: -FLT_MAX) and whether the tile has any
     auto key_bias = [&](int key0) {
         if (tid < 64) {
             int key = key0 + tid;
@@ -169,22 +193,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             if (key >= p.M) bias = -INFINITY;
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
+            unsigned long long any = __ballot(bias != 0.f);
+            if (tid == 0) sBias[64] = any ? 1.f : 0.f;
+            if (ones_col) *(uint16_t*)(sV + tid * VSTRIDE + d * 2) = 0x3F80;      // bf16 1.0 (after tile_store)
         }
     };
-    tile_load(rK, kb, p.ldk, min(64, p.M), d, tid);
-    tile_load(rV, vb, p.ldv, min(64, p.M), d, tid);
-    tile_store(rK, sK, KSTRIDE, tid);
-    tile_store(rV, sV, VSTRIDE, tid);
+    tile_load(rK, mapK, kb, min(64, p.M));
+    tile_load(rV, mapV, vb, min(64, p.M));
+    tile_store(rK, mapK, sK);
+    tile_store(rV, mapV, sV);
+    __syncthreads();
     key_bias(0);
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
         const bool more = kt + 1 < ntiles;
         if (more) {
             const int key1 = (kt + 1) * 64;
-            tile_load(rK, kb + (size_t)key1 * p.ldk, p.ldk, min(64, p.M - key1), d, tid);
-            tile_load(rV, vb + (size_t)key1 * p.ldv, p.ldv, min(64, p.M - key1), d, tid);
+            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, p.M - key1));
+            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, p.M - key1));
         }
-
         f32x16 S[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -196,62 +223,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[t], 0, 0, 0);
             }
         }
-        // scale, (bias), running max.  Only the last key tile (ragged M) and masked self-attention need the per-key
-        // bias; the common tile does max on the raw scores and folds the scale into the exponent's FMA.
-        const bool tile_bias = (p.kmask != nullptr) || (kt * 64 + 64 > p.M);     // wave-uniform
-        float mx = -INFINITY;
-        if (tile_bias) {
+        if (sBias[64] != 0.f) {                         // wave-uniform: ragged / masked tile
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
-                    float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float sv = S[t][4 * g + e] * cs + bb[e];
-                        S[t][4 * g + e] = sv;
-                        mx = fmaxf(mx, sv);
-                    }
+                    S[t][4 * g] += bv.x; S[t][4 * g + 1] += bv.y; S[t][4 * g + 2] += bv.z; S[t][4 * g + 3] += bv.w;
                 }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
-            mx *= cs;
         }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        const bool moved = __any(mnew != m);           // wave-uniform: skip the accumulator rescale when no row's max grew
-        m = mnew;
-        float psum = 0.f;
-        if (tile_bias) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(S[t][r] - mnew);
-                    S[t][r] = pv;
-                    psum += pv;
-                }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(S[t][r], cs, -mnew));
-                    S[t][r] = pv;
-                    psum += pv;
-                }
-        }
-        l = l * alpha + psum;
-        if (moved) {
+        const float mnew = fmaxf(m, mx * cs);           // running max in the exp2 domain (cs > 0)
+        if (__any(mnew != m)) {                         // wave-uniform: skip the O rescale while no row's max moves
+            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) O[vt][r] *= alpha;
+            l *= alpha;
+            m = mnew;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[t][r] = __builtin_amdgcn_exp2f(fmaf(S[t][r], cs, -m));
+        float psum = 0.f;
+        if (!ones_col) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psum += S[t][r];
+            l += psum;
         }
         // O^T += V^T P^T
 #pragma unroll
@@ -267,13 +274,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             }
         __syncthreads();
         if (more) {
-            tile_store(rK, sK, KSTRIDE, tid);
-            tile_store(rV, sV, VSTRIDE, tid);
+            tile_store(rK, mapK, sK);
+            tile_store(rV, mapV, sV);
+            __syncthreads();
             key_bias((kt + 1) * 64);
             __syncthreads();
         }
     }
-    const float ltot = l + __shfl_xor(l, 32, 64);
+    float ltot;
+    if (ones_col) {
+        // row d of O^T lives in tile d/32, register (rin&3) + 4*(rin>>3) of the lane half (rin>>2)&1, rin = d%32
+        const int vt0 = d >> 5, rin = d & 31, hh = (rin >> 2) & 1, reg = (rin & 3) + 4 * (rin >> 3);
+        float lv = 0.f;
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (vt == vt0 && r == reg) lv = O[vt][r];
+        ltot = __shfl(lv, c + 32 * hh, 64);
+    } else {
+        ltot = l + __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / ltot;
     if (q < p.N) {
         uint16_t* orow = p.o + ((size_t)b * p.N + q) * p.ldo + head * d;
@@ -346,6 +367,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
 
+    // -delta rides in as the dP accumulator's initial value (exact in f32), so dS = P * dP' needs no subtraction
     bf16x8 qf[KS], dof[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -373,6 +395,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
     const int ntiles = (p.M + 63) / 64;
     TileRegs<G::NCH> rK, rV;
+    TileMap<G::NCH> mapK, mapV;
+    mapK.init(p.ldk, KSTRIDE, d, tid);
+    mapV.init(p.ldv, KSTRIDE, d, tid);
     auto key_bias = [&](int key0) {
         if (tid < 64) {
             int key = key0 + tid;
@@ -380,26 +405,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
             if (key >= p.M) bias = -INFINITY;
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
+            unsigned long long any = __ballot(bias != 0.f);
+            if (tid == 0) sBias[64] = any ? 1.f : 0.f;
         }
     };
-    tile_load(rK, kb, p.ldk, min(64, p.M), d, tid);
-    tile_load(rV, vb, p.ldv, min(64, p.M), d, tid);
-    tile_store(rK, sK, KSTRIDE, tid);
-    tile_store(rV, sV, KSTRIDE, tid);
+    tile_load(rK, mapK, kb, min(64, p.M));
+    tile_load(rV, mapV, vb, min(64, p.M));
+    tile_store(rK, mapK, sK);
+    tile_store(rV, mapV, sV);
     key_bias(0);
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
         const bool more = kt + 1 < ntiles;
         if (more) {
             const int key1 = (kt + 1) * 64;
-            tile_load(rK, kb + (size_t)key1 * p.ldk, p.ldk, min(64, p.M - key1), d, tid);
-            tile_load(rV, vb + (size_t)key1 * p.ldv, p.ldv, min(64, p.M - key1), d, tid);
+            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, p.M - key1));
+            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, p.M - key1));
         }
+        const bool biased = sBias[64] != 0.f;           // wave-uniform
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 S, dP;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = -dl; }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
@@ -407,16 +435,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
                 bf16x8 vf = *(const bf16x8*)(sV + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dP, 0, 0, 0);
             }
+            if (biased) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
-                float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pv = __builtin_amdgcn_exp2f(S[4 * g + e] * cs + bb[e] - lse2);
-                    S[4 * g + e] = pv * (dP[4 * g + e] - dl);      // dS^T
+                for (int g = 0; g < 4; ++g) {
+                    float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
+                    S[4 * g] += bv.x; S[4 * g + 1] += bv.y; S[4 * g + 2] += bv.z; S[4 * g + 3] += bv.w;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(fmaf(S[r], cs, -lse2)) * dP[r];      // dS^T
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 bf16x8 dsf = acc_to_frag(S, sh);
@@ -429,8 +456,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         }
         __syncthreads();
         if (more) {
-            tile_store(rK, sK, KSTRIDE, tid);
-            tile_store(rV, sV, KSTRIDE, tid);
+            tile_store(rK, mapK, sK);
+            tile_store(rV, mapV, sV);
             key_bias((kt + 1) * 64);
             __syncthreads();
         }
@@ -477,6 +504,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
 
+    // this wave's 32 keys as B operands
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -492,6 +520,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     float bias = 0.f;
     if (key >= p.M) bias = -INFINITY;
     else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
+    const bool biased = __any(bias != 0.f);              // wave-uniform
 
     f32x16 dK[VT], dV[VT];
 #pragma unroll
@@ -505,34 +534,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const float* dlb = p.delta + ((size_t)b * p.H + head) * p.N;
     const int ntiles = (p.N + 63) / 64;
     TileRegs<G::NCH> rQ, rDO;
+    TileMap<G::NCH> mapQ, mapDO;
+    mapQ.init(p.ldq, QSTRIDE, d, tid);
+    mapDO.init(p.lddo, QSTRIDE, d, tid);
     float rl = 0.f, rd = 0.f;
-    auto row_stats_load = [&](int q0) {
+    auto row_stats_load = [&](int q0) {        // stored negated: -lse2 is the fma addend, -delta the dP accumulator's initial value
         if (tid < 64) {
             bool ok = q0 + tid < p.N;
-            rl = ok ? lseb[q0 + tid] * 1.4426950408889634f : 0.f;
-            rd = ok ? dlb[q0 + tid] : 0.f;
+            rl = ok ? -lseb[q0 + tid] * 1.4426950408889634f : 0.f;
+            rd = ok ? -dlb[q0 + tid] : 0.f;
         }
     };
-    tile_load(rQ, qb, p.ldq, min(64, p.N), d, tid);
-    tile_load(rDO, dob, p.lddo, min(64, p.N), d, tid);
+    tile_load(rQ, mapQ, qb, min(64, p.N));
+    tile_load(rDO, mapDO, dob, min(64, p.N));
     row_stats_load(0);
-    tile_store(rQ, sQ, QSTRIDE, tid);
-    tile_store(rDO, sDO, QSTRIDE, tid);
+    tile_store(rQ, mapQ, sQ);
+    tile_store(rDO, mapDO, sDO);
     if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
     __syncthreads();
     for (int qt = 0; qt < ntiles; ++qt) {
         const bool more = qt + 1 < ntiles;
         if (more) {
             const int q1 = (qt + 1) * 64;
-            tile_load(rQ, qb + (size_t)q1 * p.ldq, p.ldq, min(64, p.N - q1), d, tid);
-            tile_load(rDO, dob + (size_t)q1 * p.lddo, p.lddo, min(64, p.N - q1), d, tid);
+            tile_load(rQ, mapQ, qb + (size_t)q1 * p.ldq, min(64, p.N - q1));
+            tile_load(rDO, mapDO, dob + (size_t)q1 * p.lddo, min(64, p.N - q1));
             row_stats_load(q1);
         }
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            f32x16 S, dP;
+            // rows of S / dP are queries 32qi + 8g + 4h + e, the column (lane) is this wave's key
+            f32x16 S, dP, nl;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+            for (int g = 0; g < 4; ++g) {
+                float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
+                float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
+                nl[4 * g] = lv.x; nl[4 * g + 1] = lv.y; nl[4 * g + 2] = lv.z; nl[4 * g + 3] = lv.w;
+                S[4 * g] = 0.f; S[4 * g + 1] = 0.f; S[4 * g + 2] = 0.f; S[4 * g + 3] = 0.f;
+                dP[4 * g] = dv.x; dP[4 * g + 1] = dv.y; dP[4 * g + 2] = dv.z; dP[4 * g + 3] = dv.w;
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 qrow = *(const bf16x8*)(sQ + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
@@ -540,18 +579,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
                 bf16x8 drow = *(const bf16x8*)(sDO + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP, 0, 0, 0);
             }
-            // rows of S / dP are queries 32qi + 8g + 4h + e, the column (lane) is this wave's key
+            if (biased) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
-                float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
-                float ll[4] = {lv.x, lv.y, lv.z, lv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+                for (int r = 0; r < 16; ++r) S[r] += bias;
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float pv = __builtin_amdgcn_exp2f(S[4 * g + e] * cs + bias - ll[e]);
-                    S[4 * g + e] = pv;                                   // P
-                    dP[4 * g + e] = pv * (dP[4 * g + e] - dd[e]);        // dS
-                }
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(fmaf(S[r], cs, nl[r]));
+                S[r] = pv;                 // P
+                dP[r] = pv * dP[r];        // dS
             }
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
@@ -568,8 +604,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         }
         __syncthreads();
         if (more) {
-            tile_store(rQ, sQ, QSTRIDE, tid);
-            tile_store(rDO, sDO, QSTRIDE, tid);
+            tile_store(rQ, mapQ, sQ);
+            tile_store(rDO, mapDO, sDO);
             if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
             __syncthreads();
         }
@@ -611,7 +647,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 // =============================================================================================
 template <int KS, int VT>
 static int launch_fwd(const AttnParams& p, hipStream_t s) {
-    size_t lds = 64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE + 64 * 4;
+    size_t lds = 64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE + 68 * 4;
     dim3 grid((p.N + 127) / 128, p.B * p.H);
     hipLaunchKernelGGL((attn_fwd_kernel<KS, VT>), grid, dim3(256), lds, s, p);
     return adap_check_launch("attn_fwd");
@@ -619,7 +655,7 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
 
 template <int KS, int VT>
 static int launch_bwd(const AttnParams& p, hipStream_t s) {
-    size_t lds1 = 2 * 64 * TileGeom<KS>::RSTRIDE + 64 * 4;
+    size_t lds1 = 2 * 64 * TileGeom<KS>::RSTRIDE + 68 * 4;
     dim3 g1((p.N + 127) / 128, p.B * p.H);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT>), g1, dim3(256), lds1, s, p);
     size_t lds2 = 2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4;
