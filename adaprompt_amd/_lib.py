@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "adaprompt_hip.h")
 LIB_PATH = os.path.join(HERE, "libadaprompt_hip.so")
 
-_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+_SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 def parse_header(path=HEADER):

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadaprompt_hip.so")
-SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip"]
+SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -42,7 +42,7 @@ def build(force=False, verbose=True):
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     if verbose:

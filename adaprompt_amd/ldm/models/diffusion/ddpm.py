@@ -216,7 +216,7 @@ class LatentDiffusion(DDPM):
     def make_prefetcher(self):
         return LatentPrefetcher(self)
 
-    def training_step(self, batch, optimizer=None, reducer=None, **step_kwargs):
+    def training_step(self, batch, optimizer=None, reducer=None, scheduler=None, **step_kwargs):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
         the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync)."""
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
@@ -228,11 +228,20 @@ class LatentDiffusion(DDPM):
         if optimizer is not None and self.batch_idx % self.manual_accumulate_grad_batches == 0:
             if reducer is not None:
                 reducer.wait()
-            params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
-            if self.grad_clip and params:
-                torch.nn.utils.clip_grad_norm_(params, self.grad_clip)
-            optimizer.step()
-            optimizer.zero_grad(set_to_none=False)
+            from ...prodigy import Prodigy
+            if isinstance(optimizer, Prodigy):                 # clip fused into the flat-buffer step
+                optimizer.step(clip_norm=self.grad_clip if self.grad_clip else None)
+            else:
+                params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+                if self.grad_clip and params:
+                    torch.nn.utils.clip_grad_norm_(params, self.grad_clip)
+                optimizer.step()
+            if reducer is not None:
+                reducer.zero()
+            else:
+                optimizer.zero_grad(set_to_none=False)
+            if scheduler is not None:
+                scheduler.step()                               # ddpm.py:629-633
         return loss, aux
 
 

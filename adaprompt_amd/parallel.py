@@ -44,18 +44,27 @@ class GradReducer:
     wait()    -- make the current stream wait for them (call before the next backward / the step)
     """
 
-    def __init__(self, params, process_group=None, bucket_bytes=256 << 20):
+    def __init__(self, params, process_group=None, bucket_bytes=256 << 20, flat=None):
+        """``flat``: an existing flat gradient buffer that every ``p.grad`` already views (e.g.
+        ``adaprompt_amd.ldm.prodigy.Prodigy.grad_buffer``) -- the exchange then runs on the optimiser's own buffer."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            assert p.dtype == torch.float32, "trainable parameters are fp32 in the reference (Trainer precision 32)"
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        if flat is not None:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+            for p in self.params:
+                assert p.grad is not None and lo <= p.grad.data_ptr() < hi, "flat= must hold every p.grad"
+            self.flat = flat
+            n = flat.numel()
+        else:
+            n = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+            off = 0
+            for p in self.params:
+                assert p.dtype == torch.float32, "trainable parameters are fp32 in the reference (Trainer precision 32)"
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
         per = max(1, bucket_bytes // 4)
         self.chunks = [self.flat[i:i + per] for i in range(0, n, per)]
         self._works = []

@@ -154,8 +154,13 @@ def main():
 
     ld, hook = build_model(device)
     params = list(hook.parameters())
-    reducer = GradReducer(params)
-    opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=0.0, foreach=True)
+    # the optimiser of the shipped config (v1-finetune-ada.yaml:59,74-84; ddpm.py:5207-5247): Prodigy lr=1, zero-shot
+    # betas (0.9, 0.999), d_coef 2, bias correction, weight decay 0, warm-up 500 then one linear cycle to 60000 steps
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    from adaprompt_amd.ldm.util import prodigy_linear_schedule
+    opt = Prodigy(params, lr=1.0, betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, weight_decay=0.0)
+    reducer = GradReducer(params, flat=opt.grad_buffer)      # the exchange runs on the optimiser's flat buffer
+    sched = prodigy_linear_schedule(opt, max_steps=60000, warm_up_steps=500, scheduler_cycles=1)
     B = args.batch
     batches = [synthetic_batch(B, device, 1234 + rank * 100 + i) for i in range(2)]
     gen = torch.Generator(device=device).manual_seed(99 + rank)
@@ -238,9 +243,9 @@ def main():
         ld.batch_idx += 1
         if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
             reducer.wait()
-            torch.nn.utils.clip_grad_norm_(params, ld.grad_clip)
-            opt.step()
+            opt.step(clip_norm=ld.grad_clip)               # clip 0.5 fused into the step (ddpm.py:606-633)
             reducer.zero()
+            sched.step()
         return loss
 
     def step(i):
@@ -260,9 +265,9 @@ def main():
         ld.batch_idx += 1
         if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
             reducer.wait()
-            torch.nn.utils.clip_grad_norm_(params, ld.grad_clip)
-            opt.step()
+            opt.step(clip_norm=ld.grad_clip)               # clip 0.5 fused into the step (ddpm.py:606-633)
             reducer.zero()
+            sched.step()
         return loss
 
     def sync():
@@ -326,7 +331,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
         threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
-        del ld, hook, reducer, opt
+        del ld, hook, reducer, opt, sched
         torch.cuda.empty_cache()
         cpu = cpu_baseline(threads)
 
@@ -340,7 +345,7 @@ def main():
             "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None, "vae_prefetch_stream": prefetch is not None,
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
                                    "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, "
-                                   "hook stand-in with 149M trainable fp32 params, clip+AdamW step every 2nd micro-batch",
+                                   "hook stand-in with 149M trainable fp32 params, clip 0.5 + Prodigy step + LR schedule every 2nd micro-batch",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": reducer_bytes(world)},
             "model_tflops_per_step": round(GFLOP_PER_IMAGE * B / 1e3, 2),

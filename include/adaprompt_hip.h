@@ -175,6 +175,37 @@ int adap_vae_softmax(const float* S, long lds, void* P, long ldp, const uint8_t*
 /* y += a * x (f32; n % 4 == 0). */
 int adap_axpy(const float* x, float* y, float a, long n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Optimiser step over flat fp32 buffers: Prodigy (ldm/prodigy.py:97-252) + the global gradient-norm clip that
+ * precedes it (Lightning clip_gradients(0.5, "norm") -> torch clip_grad_norm_, ddpm.py:606-633).
+ *
+ * The D-adaptation state lives in DEVICE memory, so a step needs no device->host sync (the reference does two
+ * .item() calls per parameter, prodigy.py:179,189):
+ *   state[16] doubles: [0] d  [1] d_max  [2] d_numerator  [3] d_denom  [4] d_hat  [5] k  [6] clip coefficient
+ *                      [7] gradient 2-norm  [8] 1.0 if the last step was skipped (d_denom == 0)  [9] d*lr*bias_corr
+ *   workspace: adap_optim_workspace_doubles(nslots) doubles (fp64 partial sums; fixed-order combine = deterministic)
+ * One step = adap_grad_clip_coef (optional; without it state[6] keeps its value, 1.0 after state_init)
+ *          -> adap_prodigy_moments once per contiguous range of parameters whose group has lr > 0 (slot = 0..nslots-1)
+ *          -> adap_prodigy_finish -> adap_prodigy_update over all parameters.
+ * The clipped gradient is consumed on the fly and NOT written back (the reference zeroes it right after the step). */
+long adap_optim_workspace_doubles(int nslots);
+int adap_prodigy_state_init(double* state, double d0, void* stream);
+/* state[7] = ||g||_2 (fp32, as torch), state[6] = min(1, max_norm / (||g|| + 1e-6)). g 16-byte aligned. */
+int adap_grad_clip_coef(const float* g, long n, double max_norm, double* state, double* workspace, void* stream);
+/* prodigy.py:160-192 for one range: exp_avg (m), exp_avg_sq (v), s updated in place from g * state[6]
+ * (+ weight_decay_coupled * p when decouple=False); partial sums of <g, p0 - p> and |s| go to the slot. */
+int adap_prodigy_moments(const float* p, const float* p0, const float* g, float* m, float* v, float* s, long n,
+                         const double* state, double* workspace, int slot, double lr, double beta1, double beta2,
+                         double beta3, double d0, double weight_decay_coupled, int use_bias_correction,
+                         int safeguard_warmup, void* stream);
+/* prodigy.py:194-229: d_numerator, d_denom, d_hat, d, d_max, k <- the nslots slots; a zero d_denom skips the step. */
+int adap_prodigy_finish(double* state, const double* workspace, int nslots, double lr, double beta1, double beta2,
+                        double beta3, double d0, double d_coef, double growth_rate, int use_bias_correction,
+                        void* stream);
+/* prodigy.py:231-248: p -= dlr * m / (sqrt(v) + d_new * eps), after p *= 1 - weight_decay_decoupled * dlr. */
+int adap_prodigy_update(float* p, const float* m, const float* v, long n, const double* state, double eps,
+                        double weight_decay_decoupled, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,29 @@ def subsample_act(key, ten):
 @pytest.fixture(scope="session")
 def has_gpu():
     return torch.cuda.is_available()
+
+
+# ---- Prodigy fixtures (tests/golden/make_golden.py: run_prodigy) -- shapes, configs and the seeded gradients by name
+PRODIGY_SHAPES = [(37, 19), (129,), (5, 3, 3, 3), (1,)]
+PRODIGY_CASES = {
+    "zs": dict(betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, safeguard_warmup=False, weight_decay=0.0),
+    "fast_wd": dict(betas=(0.985, 0.993), d_coef=5.0, use_bias_correction=True, safeguard_warmup=True,
+                    weight_decay=0.01),
+    "plain_growth": dict(betas=(0.9, 0.999), d_coef=1.0, use_bias_correction=False, safeguard_warmup=False,
+                         weight_decay=0.0, growth_rate=1.5),
+    "coupled_wd": dict(betas=(0.9, 0.99), d_coef=1.0, use_bias_correction=True, safeguard_warmup=False,
+                       weight_decay=0.02, decouple=False),
+}
+
+
+def prodigy_params(case):
+    from adaprompt_amd import synth
+    return [synth.synthetic_input(f"prodigy.{case}.p{i}", sh, 0, 0.3).clone() for i, sh in enumerate(PRODIGY_SHAPES)]
+
+
+def prodigy_grads(case, step):
+    from adaprompt_amd import synth
+    if step == 5:
+        return [torch.zeros(sh) for sh in PRODIGY_SHAPES]
+    return [synth.synthetic_input(f"prodigy.{case}.g{i}.s{step}", sh, 0, 1.0) * (0.01 if step != 3 else 3.0)
+            for i, sh in enumerate(PRODIGY_SHAPES)]

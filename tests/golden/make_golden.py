@@ -106,6 +106,71 @@ def subsample_act(key, ten):
     return ten[:, ::4, ::max(1, n // 32)]
 
 
+PRODIGY_SHAPES = [(37, 19), (129,), (5, 3, 3, 3), (1,)]
+PRODIGY_CASES = {
+    # the shipped zero-shot config: betas (0.9, 0.999), bias correction on, d_coef from the yaml (ddpm.py:5207-5217)
+    "zs": dict(betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, safeguard_warmup=False, weight_decay=0.0),
+    "fast_wd": dict(betas=(0.985, 0.993), d_coef=5.0, use_bias_correction=True, safeguard_warmup=True,
+                    weight_decay=0.01),
+    "plain_growth": dict(betas=(0.9, 0.999), d_coef=1.0, use_bias_correction=False, safeguard_warmup=False,
+                         weight_decay=0.0, growth_rate=1.5),
+    "coupled_wd": dict(betas=(0.9, 0.99), d_coef=1.0, use_bias_correction=True, safeguard_warmup=False,
+                       weight_decay=0.02, decouple=False),
+}
+
+
+def prodigy_grad(case, step, i, shape):
+    """seeded gradient of parameter i at optimiser step ``step`` (shared with the tests by name)."""
+    g = synth.synthetic_input(f"prodigy.{case}.g{i}.s{step}", shape, 0, 1.0)
+    return g * (0.01 if step != 3 else 3.0)       # step 3: a large gradient so that the 0.5 clip engages
+
+
+def run_prodigy():
+    from ldm.prodigy import Prodigy
+    from ldm.util import SequentialLR2
+    from torch.optim.lr_scheduler import ConstantLR, PolynomialLR
+    nsteps = 8
+    for case, kw in PRODIGY_CASES.items():
+        for clip in (0.0, 0.5):
+            ps = [torch.nn.Parameter(synth.synthetic_input(f"prodigy.{case}.p{i}", sh, 0, 0.3).clone())
+                  for i, sh in enumerate(PRODIGY_SHAPES)]
+            opt = Prodigy(ps, lr=1.0, **kw)
+            # ddpm.py:5219-5247 with max_steps=8, warm_up_steps=2, one Linear cycle
+            warm = ConstantLR(opt, factor=1.0, total_iters=2)
+            lin = PolynomialLR(opt, power=1, total_iters=(nsteps - 2) * 1.1)
+            sched = SequentialLR2(opt, schedulers=[warm, lin], milestones=[2])
+            traj, ds, lrs, norms = [], [], [], []
+            for step in range(nsteps):
+                for i, p in enumerate(ps):
+                    p.grad = prodigy_grad(case, step, i, p.shape).clone()
+                if step == 5:                           # an all-zero gradient step: d_denom == 0 only if s == 0,
+                    for p in ps:                        # so here it just decays the moments
+                        p.grad.zero_()
+                lrs.append(opt.param_groups[0]["lr"])
+                if clip > 0:
+                    norms.append(float(torch.nn.utils.clip_grad_norm_(ps, clip)))
+                opt.step()
+                sched.step()
+                g0 = opt.param_groups[0]
+                traj.append(torch.cat([p.detach().flatten() for p in ps]).clone())
+                ds.append([g0["d"], g0["d_max"], g0["d_numerator"], g0.get("d_denom", 0.0), g0.get("d_hat", 0.0),
+                           float(g0["k"])])
+            st = [opt.state[p] for p in ps]
+            save(f"prodigy_{case}_clip{int(clip * 10)}", case=case, clip=clip, nsteps=nsteps,
+                 params=torch.stack(traj), dstate=np.array(ds, dtype=np.float64), lrs=np.array(lrs, dtype=np.float64),
+                 grad_norms=np.array(norms, dtype=np.float64),
+                 exp_avg=torch.cat([s_["exp_avg"].flatten() for s_ in st]),
+                 exp_avg_sq=torch.cat([s_["exp_avg_sq"].flatten() for s_ in st]),
+                 s=torch.cat([s_["s"].flatten() for s_ in st]),
+                 p0=torch.cat([s_["p0"].flatten() for s_ in st]))
+    # a first step whose gradients are all zero returns before touching anything (prodigy.py:200-201)
+    ps = [torch.nn.Parameter(synth.synthetic_input("prodigy.zero.p0", (11,), 0, 0.3).clone())]
+    opt = Prodigy(ps, lr=1.0)
+    ps[0].grad = torch.zeros(11)
+    opt.step()
+    save("prodigy_zero_first_step", params=ps[0].detach(), k=opt.param_groups[0]["k"], d=opt.param_groups[0]["d"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -279,6 +344,9 @@ def main():
     vnarrow = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
     run_vae(vnarrow, 2, 64, "narrow_nomask", False)
     run_vae(vnarrow, 2, 64, "narrow_mask", True)
+
+    # ---------------- optimiser: Prodigy.step + grad-norm clip + LR schedule (ldm/prodigy.py, ldm/util.py:26-41) ------
+    run_prodigy()
 
     if args.full:
         run_unet(dict(synth.SD15_UNET), 1, 77, "sd15_recon", with_grad=True, subsample=True)

@@ -129,3 +129,38 @@ def test_hook_standin_contract():
     assert ctx.shape == (48, 77, 32) and extra["use_layerwise_context"] and extra["capture_distill_attn"]
     ctx.sum().backward()
     assert h.bases.grad is not None and h.bases.grad.abs().sum() > 0
+
+
+def test_prodigy_linear_schedule_matches_reference_lrs():
+    """SequentialLR2 + ConstantLR + PolynomialLR chain (reference util.py:26-41, ddpm.py:5219-5247) against the LR
+    sequence the reference's own classes produced (tests/golden/prodigy_zs_clip0.npz: lrs)."""
+    import torch
+    from conftest import load_golden
+    from ldm.util import prodigy_linear_schedule, SequentialLR2
+    g = load_golden("prodigy_zs_clip0")
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sched = prodigy_linear_schedule(opt, max_steps=8, warm_up_steps=2, scheduler_cycles=1)
+    assert isinstance(sched, SequentialLR2)
+    lrs = []
+    for _ in range(8):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    assert max(abs(a - float(b)) for a, b in zip(lrs, g["lrs"])) < 1e-12
+    assert lrs[0] == lrs[1] == lrs[2] == 1.0 and lrs[-1] < lrs[-2] < 1.0
+
+
+def test_prodigy_constructor_validation_matches_reference():
+    """same ValueErrors as ldm/prodigy.py:64-73; FSDP is refused instead of silently ignored."""
+    import pytest
+    import torch
+    from ldm.prodigy import Prodigy
+    p = [torch.nn.Parameter(torch.zeros(2))]
+    for bad in (dict(d0=0.0), dict(lr=0.0), dict(eps=0.0), dict(betas=(1.0, 0.9)), dict(betas=(0.9, 1.0))):
+        with pytest.raises(ValueError):
+            Prodigy(p, **bad)
+    with pytest.raises(NotImplementedError):
+        Prodigy(p, fsdp_in_use=True)
+    opt = Prodigy(p, d_coef=2.0, use_bias_correction=True)
+    g = opt.param_groups[0]
+    assert g["d"] == g["d0"] == g["d_max"] == 1e-6 and g["k"] == 0 and g["d_numerator"] == 0.0 and g["d_coef"] == 2.0

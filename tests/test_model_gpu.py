@@ -189,6 +189,85 @@ def test_training_step_matches_oracle():
     assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
 
 
+def test_training_loop_prodigy_two_optimizer_steps_vs_oracle():
+    """a1 end to end: four micro-batches through LatentDiffusion.training_step with the flat-buffer Prodigy, the
+    fused 0.5 clip, the GradReducer on the optimiser's buffer and the LR schedule -- gradients accumulate over two
+    micro-batches, then clip -> step -> zero -> scheduler (ddpm.py:583-633).  The oracle side runs the same loop
+    with the fp32 UNet restatement and ProdigyOracle.  Adam-normalised updates amplify the ~1e-2 bf16 gradient
+    error on near-zero components, so the parameter DELTAS are compared at 10 % and d at 10 %: plumbing mistakes
+    (missed accumulation, unclipped or doubly-stepped gradients, stale buffers) are O(1) errors."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    from adaprompt_amd.ldm.util import prodigy_linear_schedule
+    from adaprompt_amd.parallel import GradReducer
+    from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
+    from oracle import ldm_oracle as O
+    from oracle.prodigy_oracle import ProdigyOracle, clip_grad_norm, linear_schedule_lrs
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    torch.manual_seed(3)
+    hook_ref = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
+    with torch.no_grad():
+        hook_ref.bases.mul_(20.0)                       # context of unit scale so that the loss depends on it
+    hook = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
+    hook.load_state_dict(hook_ref.state_dict())
+    hook = hook.to(dev())
+    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                         {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
+                         cond_fn=make_cond_fn(hook, capture=False))
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    ld.load_state_dict(usd, strict=False)
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    kw = dict(betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, weight_decay=0.0)
+    params = list(hook.parameters())
+    init = [p.detach().cpu().clone() for p in params]
+    opt = Prodigy(params, lr=1.0, **kw)
+    red = GradReducer(params, flat=opt.grad_buffer)
+    sched = prodigy_linear_schedule(opt, max_steps=4, warm_up_steps=1, scheduler_cycles=1)
+    B = 2
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+    sch = O.make_schedule()
+    ref_params = list(hook_ref.parameters())
+    orc = ProdigyOracle([p.data for p in ref_params], lr=1.0, **kw)
+    lrs = linear_schedule_lrs(1.0, max_steps=4, warm_up_steps=1, scheduler_cycles=1, n=2)
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": False, "img_mask": im64}
+    losses = []
+    for mb in range(4):
+        x0 = synth.synthetic_input(f"loop.x0.{mb}", (B, 4, 64, 64))
+        noise = synth.synthetic_input(f"loop.noise.{mb}", (B, 4, 64, 64))
+        ids = synth.synthetic_input(f"loop.ids.{mb}", (B, 32))
+        t = torch.tensor([150 + 200 * mb, 900 - 100 * mb])
+        batch = {"zs_id_embs": ids.to(dev()), "fg_mask": fg64[:, 0].to(dev()), "aug_mask": im64[:, 0].to(dev())}
+        loss, _aux = ld.training_step(batch, optimizer=opt, reducer=red, scheduler=sched, t=t.to(dev()),
+                                      noise=noise.to(dev()), x_start=x0.to(dev()))
+        # ---- oracle side of the same micro-batch
+        ctx = hook_ref(ids)
+        eps = O.unet_forward(usd, ucfg, O.q_sample(sch, x0, t, noise), t, ctx, extra)
+        loss_ref, _ = O.calc_recon_loss(eps, noise, im64, fg64, 1.0, 0.1)
+        loss_ref.backward()                                   # accumulates into .grad, as manual_backward does
+        losses.append((float(loss), float(loss_ref)))
+        if (mb + 1) % 2 == 0:
+            grads = [p.grad for p in ref_params]
+            clip_grad_norm(grads, 0.5)
+            orc.lr = lrs[(mb + 1) // 2 - 1]
+            orc.step(grads)
+            for p in ref_params:
+                p.grad = None
+    for a, b in losses:
+        assert abs(a - b) / b < 5e-3, losses
+    ds = opt.device_state()
+    assert ds["k"] == orc.k == 2
+    assert abs(ds["d"] - orc.d) / orc.d < 0.1, (ds["d"], orc.d)
+    assert float(opt.grad_buffer.abs().max()) == 0.0          # zeroed after the step
+    assert abs(opt.param_groups[0]["lr"] - linear_schedule_lrs(1.0, 4, 1, 1, n=3)[2]) < 1e-12
+    for p, p_ref, p0 in zip(params, ref_params, init):
+        d_hip, d_ref = p.detach().cpu() - p0, p_ref.detach() - p0
+        assert float(d_ref.abs().max()) > 0
+        assert rel_err(d_hip, d_ref) < 0.1, rel_err(d_hip, d_ref)
+
+
 def test_cpu_tensor_fails_loudly():
     unet = build_unet(NARROW)
     with pytest.raises(RuntimeError):
