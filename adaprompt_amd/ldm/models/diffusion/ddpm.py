@@ -8,8 +8,10 @@ zero_grad every ``manual_accumulate_grad_batches``-th batch, loss not divided).
 
 What is deliberately NOT here (SURVEY.md section 2 "out of scope" / section 8f "next"): Lightning, the
 data pipeline, the CLIP text encoder + EmbeddingManager + SubjBasisGenerator internals (they stay
-the reference's own classes behind ``cond_fn``), the Arc2Face teacher, compositional
-distillation and its auxiliary losses, DDIM sampling.  ``cond_fn(batch) -> (c_static_emb
+the reference's own classes behind ``cond_fn``), the Arc2Face text encoder (the teacher's context is an input),
+compositional distillation and its auxiliary losses, DDIM sampling.  The Arc2Face teacher ROLLOUT and the
+multi-step distillation loss (ddpm.py:5432-5478, 2950-3039) are here: the teacher is an SD-1.5-topology UNet and
+runs on the same kernels (``Arc2FaceWrapper``).  ``cond_fn(batch) -> (c_static_emb
 [16*B, 77, 768], prompts, extra_info)`` is the embedding hook: whatever produced the context (the
 reference's ``get_learned_conditioning``) is called as-is and only its output enters the path.
 """
@@ -103,6 +105,7 @@ class LatentDiffusion(DDPM):
         self.bg_pixel_weight = bg_pixel_weight
         self.cond_fn = cond_fn
         self.batch_idx = 0
+        self.arc2face = None          # Arc2FaceWrapper, attached by set_arc2face_teacher (ddpm.py:903-907)
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path)
 
@@ -121,6 +124,11 @@ class LatentDiffusion(DDPM):
         missing, unexpected = target.load_state_dict(sd, strict=False)
         print(f"Restored from {path} with {len(missing)} missing and {len(unexpected)} unexpected keys")
         return missing, unexpected
+
+    def set_arc2face_teacher(self, teacher):
+        """attach the frozen teacher without registering its weights in this module's state dict (the reference
+        keeps it out of checkpoints the same way, ddpm.py:5393-5400)."""
+        object.__setattr__(self, "arc2face", teacher)
 
     def freeze_unet(self):
         """``unfreeze_model: False`` (yaml:26, ddpm.py:775-786)."""
@@ -188,12 +196,82 @@ class LatentDiffusion(DDPM):
         loss, grad = ops.masked_mse(mo.detach(), tg, im, fg, fg_pixel_weight, bg_pixel_weight)
         return loss, grad.permute(0, 3, 1, 2)
 
+    # ---- Arc2Face distillation: teacher rollout + multi-step student loss (ddpm.py:2950-3039) ------------------
+    MAX_ACCUMU_BATCH_SIZE = 7
+
+    def arc2face_distill_step(self, x_start, noise, t, cond, arc2face_prompt_emb, img_mask, fg_mask,
+                              num_denoising_steps=1, relative_ts=None, noises=None):
+        """The ``use_arc2face_as_target`` branch.  The teacher (``self.arc2face``) rolls ``num_denoising_steps`` out
+        without grad; the student re-denoises the teacher's predictions and is regressed on the teacher's eps with
+        bg_pixel_weight 0; the per-step losses are summed and divided by sqrt(ND).  The reference's indexing is kept
+        literally: student step s starts from ``pred_x0s[s-1]``, i.e. for s = 0 from the LAST teacher prediction
+        (ddpm.py:2978).  -> (loss, grads, model_outputs, aux): call ``torch.autograd.backward(model_outputs, grads)``."""
+        nd = int(num_denoising_steps)
+        teacher = self.arc2face(self, x_start, noise, t, arc2face_prompt_emb, num_denoising_steps=nd,
+                                relative_ts=relative_ts, noises=noises)
+        noise_preds, pred_x0s, noises_, ts = teacher
+        max_num_loss_steps = self.MAX_ACCUMU_BATCH_SIZE // x_start.shape[0]
+        loss_start_step = max(0, nd - max_num_loss_steps)
+        targets = noise_preds[loss_start_step:]
+        c_emb, c_in, extra_info = cond
+        extra_info = dict(extra_info)
+        extra_info["img_mask"] = img_mask
+        extra_info["capture_distill_attn"] = False                       # ddpm.py:2908
+        model_outputs = []
+        for s in range(loss_start_step, nd):
+            mo, _ = self.guided_denoise(pred_x0s[s - 1], noises_[s], ts[s], (c_emb, c_in, extra_info))
+            model_outputs.append(mo)
+        inv = 1.0 / float(np.sqrt(nd))                                    # ddpm.py:3035
+        loss, grads, step_losses = 0.0, [], []
+        for mo, tgt in zip(model_outputs, targets):
+            l, g = self.calc_recon_loss(mo, tgt, img_mask, fg_mask, 1.0, 0.0)
+            step_losses.append(l)
+            loss = loss + l * inv
+            grads.append(g * inv)
+        return loss, grads, model_outputs, {"teacher": teacher, "step_losses": step_losses,
+                                            "loss_start_step": loss_start_step}
+
+    @staticmethod
+    def half_batch_size(batch_size, num_denoising_steps):
+        """instances kept for a multi-step iteration: ``torch.arange(BS).chunk(ND)[0].shape[0]`` (ddpm.py:1857)."""
+        if num_denoising_steps <= 1:
+            return batch_size
+        return torch.arange(batch_size).chunk(int(num_denoising_steps))[0].shape[0]
+
+    @staticmethod
+    def draw_num_denoising_steps(max_num_denoising_steps=7, np_random=np.random):
+        """ddpm.py:1839-1850: ND in {1,3,5,7} with p = (.4,.3,.2,.1) renormalised over the allowed candidates."""
+        cand = [s for s in (1, 3, 5, 7) if s <= max_num_denoising_steps]
+        p = np.array([0.4, 0.3, 0.2, 0.1])[:len(cand)]
+        return int(np_random.choice(cand, p=p / np.sum(p)))
+
+    def shift_t_for_multistep(self, t, num_denoising_steps):
+        """ddpm.py:2858-2861: pull t towards num_timesteps so the later rollout steps stay in a sensible range."""
+        if num_denoising_steps > 1:
+            return (4 * t + (num_denoising_steps - 1) * self.num_timesteps) // (3 + num_denoising_steps)
+        return t
+
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
-    def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None):
+    def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
+                    num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
+                    trim_to_half_batch=True):
         """``x_start``: a latent already encoded for this batch (e.g. by ``LatentPrefetcher`` on a side stream while
-        the previous micro-batch's UNet pass was running); otherwise the batch is encoded here."""
+        the previous micro-batch's UNet pass was running); otherwise the batch is encoded here.
+
+        ``use_arc2face_as_target``: the distillation iteration (ddpm.py:1837-1876, 2950-3039): only the first
+        HALF_BS instances are kept when ``num_denoising_steps`` > 1, ``batch["arc2face_prompt_emb"]`` [B,21,768] is
+        the teacher's context; returns lists of model outputs / gradients.  ``trim_to_half_batch=False``: the caller
+        has already cut the batch (and ``cond`` / ``relative_ts`` / ``noises``) down to HALF_BS, as the reference's
+        ``forward`` does before ``p_losses`` runs."""
         if x_start is None:
             x_start, _mask = self.get_input(batch, post_noise)
+        nd = int(num_denoising_steps)
+        if use_arc2face_as_target and nd > 1 and trim_to_half_batch:
+            hb = self.half_batch_size(x_start.shape[0], nd)
+            x_start = x_start[:hb]
+            batch = {k: (v[:hb] if torch.is_tensor(v) and v.dim() > 0 else v) for k, v in batch.items()}
+            t = None if t is None else t[:hb]
+            noise = None if noise is None else noise[:hb]
         B = x_start.shape[0]
         if t is None:
             t = torch.randint(0, self.num_timesteps, (B,), device=x_start.device).long()
@@ -206,6 +284,12 @@ class LatentDiffusion(DDPM):
         aug = batch.get("aug_mask")
         img_mask = None if aug is None else torch.nn.functional.interpolate(aug[:, None].float(), size=hw, mode="nearest")
         fg_mask = None if fg is None else torch.nn.functional.interpolate(fg[:, None].float(), size=hw, mode="nearest")
+        if use_arc2face_as_target:
+            t = self.shift_t_for_multistep(t, nd)
+            loss, grads, outs, aux = self.arc2face_distill_step(
+                x_start, noise, t, cond, batch["arc2face_prompt_emb"], img_mask, fg_mask, nd, relative_ts, noises)
+            aux.update(x_start=x_start, t=t)
+            return loss, grads, outs, aux
         c_emb, c_in, extra_info = cond
         extra_info = dict(extra_info)
         extra_info["img_mask"] = img_mask                                  # ddpm.py:2876
@@ -220,7 +304,11 @@ class LatentDiffusion(DDPM):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
         the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync)."""
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
-        if model_output.requires_grad:
+        if isinstance(model_output, (list, tuple)):                        # multi-step distillation: one backward
+            live = [(o, g) for o, g in zip(model_output, grad) if o.requires_grad]
+            if live:
+                torch.autograd.backward([o for o, _ in live], [g for _, g in live])
+        elif model_output.requires_grad:
             model_output.backward(grad)                                    # == manual_backward(loss)
         if reducer is not None:
             reducer.reduce()
@@ -276,3 +364,53 @@ class LatentPrefetcher:
         torch.cuda.current_stream().wait_event(ev)
         x_start.record_stream(torch.cuda.current_stream())
         return x_start
+
+
+class Arc2FaceWrapper(nn.Module):
+    """The distillation teacher (reference ddpm.py:5402-5478).  There it is diffusers' ``UNet2DConditionModel`` under
+    fp16 autocast; its topology is exactly SD-1.5's, so here the same weights (``load_diffusers_state_dict`` maps the
+    diffusers key names onto the ldm names) run through this package's ``UNetModel`` -- bf16 MFMA operands, fp32
+    accumulation, fp32 residual stream -- with the [B,21,768] Arc2Face prompt embedding repeated over the 16
+    conditioned layers (a non-layerwise context IS the same context at every layer).  The Arc2Face text encoder /
+    tokenizer (``gen_arc2face_prompt_embs``) stay third-party: the context is an input."""
+
+    def __init__(self, unet_config=None, unet=None):
+        super().__init__()
+        self.unet = unet if unet is not None else instantiate_from_config(unet_config)
+        for p in self.unet.parameters():
+            p.requires_grad = False
+
+    def load_diffusers_state_dict(self, sd, strict=True):
+        from ...modules.diffusionmodules.openaimodel import diffusers_to_ldm_unet_state_dict
+        return self.unet.load_state_dict(diffusers_to_ldm_unet_state_dict(sd), strict=strict)
+
+    @staticmethod
+    def layerwise(context):
+        """[B, M, D] -> [16*B, M, D], the 16 layers of an instance contiguous (embedding_manager.py:1345-1349)."""
+        B, M, D = context.shape
+        return context[:, None].expand(B, 16, M, D).reshape(B * 16, M, D).contiguous()
+
+    @torch.no_grad()
+    def forward(self, ddpm_model, x_start, noise, t, context, num_denoising_steps=1, relative_ts=None, noises=None):
+        """-> (noise_preds, pred_x0s, noises, ts).  ``relative_ts[i]`` ([B] in U(0,1)) / ``noises[i+1]`` replace the
+        ``rand_like`` / ``randn_like`` draws of step i when given (parity tests)."""
+        assert num_denoising_steps <= 10
+        nd = int(num_denoising_steps)
+        x_starts, noises_, ts, noise_preds = [x_start], [noise], [t], []
+        ctx = self.layerwise(context.float())
+        extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "arc2face_teacher",
+                 "is_training": False, "capture_distill_attn": False, "img_mask": None}
+        for i in range(nd):
+            x0_i, t_i, n_i = x_starts[i], ts[i], noises_[i]
+            x_noisy = ddpm_model.q_sample(x0_i, t_i, n_i)
+            noise_pred = self.unet(x_noisy, t_i, context=ctx, extra_info=dict(extra))
+            noise_preds.append(noise_pred)
+            x_starts.append(ddpm_model.predict_start_from_noise(x_noisy, t_i, noise_pred))
+            if i < nd - 1:
+                rel = relative_ts[i] if relative_ts is not None else torch.rand_like(t_i.float())
+                # long * python float -> float32, as ``t * np.power(...)`` in the reference
+                t_lb = t_i * float(np.power(0.5, np.power(nd - 1, -0.3)))
+                t_ub = t_i * float(np.power(0.7, np.power(nd - 1, -0.3)))
+                ts.append(((t_ub - t_lb) * rel + t_lb).long())
+                noises_.append(noises[i + 1] if noises is not None else torch.randn_like(x0_i))
+        return noise_preds, x_starts[1:], noises_, ts

@@ -171,6 +171,26 @@ def run_prodigy():
     save("prodigy_zero_first_step", params=ps[0].detach(), k=opt.param_groups[0]["k"], d=opt.param_groups[0]["d"])
 
 
+def run_anneal():
+    """ldm/util.py:1468-1530 with seeded ``random`` / ``np.random`` (the restatement must consume them identically)."""
+    import random
+    from ldm.util import probably_anneal_t, anneal_value, anneal_array
+    cases, outs = [], []
+    for seed in range(12):
+        random.seed(100 + seed)
+        np.random.seed(200 + seed)
+        tp = [0.0, 0.13, 0.5, 0.97][seed % 4]
+        t = torch.tensor([[3, 250, 640, 999], [0, 998, 500, 77], [850, 851, 10, 420]][seed % 3])
+        rr, kp = [((1, 1.3), (0.4, 0.2)), ((0.8, 1.0), (0.5, 0.3))][seed % 2]
+        out = probably_anneal_t(t, tp, 1000, ratio_range=rr, keep_prob_range=kp)
+        cases.append([seed, tp, rr[0], rr[1], kp[0], kp[1]] + t.tolist())
+        outs.append(out.tolist())
+    av = [anneal_value(tp, fp, (0.2, 0.9)) for tp in (0.0, 0.3, 0.5, 1.0) for fp in (0.5, 1.0)]
+    aa = anneal_array(0.25, 0.5, [0.4, 0.3, 0.2, 0.1], [0.1, 0.2, 0.3, 0.4])
+    save("anneal_t", cases=np.array(cases, dtype=np.float64), outs=np.array(outs, dtype=np.int64),
+         anneal_values=np.array(av, dtype=np.float64), anneal_array=np.array(aa, dtype=np.float64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -347,6 +367,7 @@ def main():
 
     # ---------------- optimiser: Prodigy.step + grad-norm clip + LR schedule (ldm/prodigy.py, ldm/util.py:26-41) ------
     run_prodigy()
+    run_anneal()
 
     if args.full:
         run_unet(dict(synth.SD15_UNET), 1, 77, "sd15_recon", with_grad=True, subsample=True)

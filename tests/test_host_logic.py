@@ -164,3 +164,55 @@ def test_prodigy_constructor_validation_matches_reference():
     opt = Prodigy(p, d_coef=2.0, use_bias_correction=True)
     g = opt.param_groups[0]
     assert g["d"] == g["d0"] == g["d_max"] == 1e-6 and g["k"] == 0 and g["d_numerator"] == 0.0 and g["d_coef"] == 2.0
+
+
+def test_diffusers_key_map_is_a_bijection_onto_the_ldm_names():
+    from adaprompt_amd.synth import SD15_UNET, unet_param_shapes
+    from adaprompt_amd.ldm.modules.diffusionmodules.openaimodel import (ldm_to_diffusers_unet_key,
+                                                                        diffusers_to_ldm_unet_state_dict)
+    import torch
+    shapes = dict(unet_param_shapes(**dict(SD15_UNET)))
+    fwd = {k: ldm_to_diffusers_unet_key(k) for k in shapes}
+    assert len(fwd) == 686 and len(set(fwd.values())) == 686
+    known = {"input_blocks.0.0.weight": "conv_in.weight",
+             "time_embed.2.bias": "time_embedding.linear_2.bias",
+             "input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight":
+                 "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight",
+             "input_blocks.3.0.op.bias": "down_blocks.0.downsamplers.0.conv.bias",
+             "input_blocks.10.0.emb_layers.1.weight": "down_blocks.3.resnets.0.time_emb_proj.weight",
+             "middle_block.2.out_layers.3.weight": "mid_block.resnets.1.conv2.weight",
+             "output_blocks.2.1.conv.weight": "up_blocks.0.upsamplers.0.conv.weight",
+             "output_blocks.5.2.conv.weight": "up_blocks.1.upsamplers.0.conv.weight",
+             "output_blocks.11.0.skip_connection.weight": "up_blocks.3.resnets.2.conv_shortcut.weight",
+             "out.0.weight": "conv_norm_out.weight", "out.2.bias": "conv_out.bias"}
+    for k, v in known.items():
+        assert fwd[k] == v
+    # a diffusers-named dict (meta tensors, linear-projection form for one proj_in) comes back under ldm names/shapes
+    dsd = {fwd[k]: torch.empty(s, device="meta") for k, s in shapes.items()}
+    k = "input_blocks.1.1.proj_in.weight"
+    dsd[fwd[k]] = torch.empty(shapes[k][:2], device="meta")
+    back = diffusers_to_ldm_unet_state_dict(dsd)
+    assert set(back) == set(shapes) and all(tuple(back[n].shape) == tuple(shapes[n]) for n in shapes)
+    del dsd[fwd["out.2.bias"]]
+    import pytest
+    with pytest.raises(KeyError):
+        diffusers_to_ldm_unet_state_dict(dsd)
+
+
+def test_multistep_host_helpers_match_oracle():
+    import numpy as np
+    import torch
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion, Arc2FaceWrapper
+    from oracle import distill_oracle as D
+    for bs in (3, 4):
+        for nd in (1, 3, 5, 7):
+            assert LatentDiffusion.half_batch_size(bs, nd) == D.half_batch_size(bs, nd)
+    rs = np.random.RandomState(5)
+    draws = [LatentDiffusion.draw_num_denoising_steps(7, rs) for _ in range(4000)]
+    freq = [draws.count(s) / 4000 for s in (1, 3, 5, 7)]
+    assert max(abs(a - b) for a, b in zip(freq, (0.4, 0.3, 0.2, 0.1))) < 0.03
+    assert set(LatentDiffusion.draw_num_denoising_steps(3, rs) for _ in range(50)) == {1, 3}
+    ctx = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
+    lw = Arc2FaceWrapper.layerwise(ctx)
+    assert lw.shape == (32, 3, 4) and torch.equal(lw[0], ctx[0]) and torch.equal(lw[15], ctx[0]) \
+        and torch.equal(lw[16], ctx[1])

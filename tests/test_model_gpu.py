@@ -268,6 +268,90 @@ def test_training_loop_prodigy_two_optimizer_steps_vs_oracle():
         assert rel_err(d_hip, d_ref) < 0.1, rel_err(d_hip, d_ref)
 
 
+ROLLOUT_EPS_TOL = EPS_TOL  # teacher eps / x0 at every rollout step (measured 1e-2 / 4e-3: the feedback does not amplify)
+DISTILL_LOSS_TOL = LOSS_TOL  # sum over steps of masked MSE(student eps, teacher eps): the north-star bar (measured 2.6e-4)
+
+
+def test_arc2face_distill_step_vs_oracle():
+    """a9/a17: three-step teacher rollout (narrow SD-topology UNet with its own weights, [B,21,ctx] context repeated
+    over the layers) + student passes on the teacher's predictions + loss / sqrt(3) + gradient into the student's
+    context, against oracle/distill_oracle.py with the fp32 UNet restatement in both roles; rand / randn draws
+    supplied.  The timesteps the rollout visits are integer work and must be identical."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion, Arc2FaceWrapper
+    from oracle import ldm_oracle as O
+    from oracle import distill_oracle as D
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                         {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    ld.load_state_dict(usd, strict=False)
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    TP = "arc2face.unet."                                    # teacher weights: same shapes, different values
+    tsd = synth.synthetic_unet_state_dict(ucfg, prefix=TP)
+    teacher = Arc2FaceWrapper(unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                           "params": ucfg})
+    teacher.unet.load_state_dict({k[len(TP):]: v for k, v in tsd.items()}, strict=True)
+    ld.set_arc2face_teacher(teacher.to(dev()).eval())
+    assert not any(k.startswith("arc2face") for k in ld.state_dict())
+
+    B, nd = 2, 3
+    x0 = synth.synthetic_input("distill.x0", (B, 4, 64, 64))
+    noises = [synth.synthetic_input(f"distill.noise{i}", (B, 4, 64, 64)) for i in range(nd)]
+    rel = [synth.synthetic_input(f"distill.rel{i}", (B,)).sigmoid() for i in range(nd - 1)]     # in (0, 1)
+    t = torch.tensor([420, 640])
+    tctx = synth.synthetic_input("distill.tctx", (B, 21, ucfg["context_dim"]))
+    ctx = synth.synthetic_input("distill.ctx", (16 * B, 77, ucfg["context_dim"]))
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": True}
+
+    # ---- oracle
+    sch = O.make_schedule()
+    t_ref = D.shift_t_for_multistep(t, nd)
+    ex_t = dict(extra, capture_distill_attn=False, img_mask=None)
+
+    def teacher_fn(x_noisy, t_i, c):
+        c16 = c[:, None].expand(B, 16, 21, c.shape[-1]).reshape(16 * B, 21, c.shape[-1])
+        return O.unet_forward(tsd, ucfg, x_noisy, t_i, c16, ex_t, prefix=TP)
+
+    tout = D.arc2face_rollout(teacher_fn, sch, x0, noises[0], t_ref, tctx, nd, rel, noises)
+    ctx_ref = ctx.clone().requires_grad_(True)
+    ex_s = dict(extra, capture_distill_attn=False, img_mask=im64)
+    loss_ref, losses_ref, outs_ref, start = D.arc2face_distill_loss(
+        lambda xn, t2: O.unet_forward(usd, ucfg, xn, t2, ctx_ref, ex_s), sch, tout, im64, fg64, nd)
+    (g_ref,) = torch.autograd.grad(loss_ref, ctx_ref)
+
+    # ---- HIP
+    ctx_hip = ctx.to(dev()).clone().requires_grad_(True)
+    batch = {"fg_mask": fg64[:, 0].to(dev()), "aug_mask": im64[:, 0].to(dev()),
+             "arc2face_prompt_emb": tctx.to(dev())}
+    loss, grads, outs, aux = ld.shared_step(
+        batch, t=t.to(dev()), noise=noises[0].to(dev()), x_start=x0.to(dev()), cond=(ctx_hip, None, extra),
+        num_denoising_steps=nd, use_arc2face_as_target=True, relative_ts=[r.to(dev()) for r in rel],
+        noises=[n.to(dev()) for n in noises], trim_to_half_batch=False)     # B = 2 IS the HALF_BS of a batch of 4
+    torch.autograd.backward(outs, grads)
+    npred, px0, nz, ts = aux["teacher"]
+    assert aux["loss_start_step"] == start == 0 and len(outs) == nd
+    for a, b in zip(ts, tout[3]):
+        assert torch.equal(a.cpu(), b), (a, b)                       # integer work: identical
+    errs = []
+    for i in range(nd):
+        e_eps, e_x0 = rel_err(npred[i].cpu(), tout[0][i]), rel_err(px0[i].cpu(), tout[1][i])
+        errs.append((e_eps, e_x0))
+        assert e_eps < (EPS_TOL if i == 0 else ROLLOUT_EPS_TOL), (i, e_eps)
+        assert e_x0 < ROLLOUT_EPS_TOL, (i, e_x0)
+    for a, b in zip(outs, outs_ref):
+        assert rel_err(a.detach().cpu(), b.detach()) < ROLLOUT_EPS_TOL
+    lr_ = float(loss_ref)
+    print(f"[distill] teacher (eps, x0) rel err per step {[(round(a, 4), round(b, 4)) for a, b in errs]}  "
+          f"loss hip {float(loss):.6f} ref {lr_:.6f} rel {abs(float(loss) - lr_) / lr_:.2e}  "
+          f"grad rel {rel_err(ctx_hip.grad.cpu(), g_ref):.3e}")
+    assert abs(float(loss) - lr_) / lr_ < DISTILL_LOSS_TOL
+    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
+
+
 def test_cpu_tensor_fails_loudly():
     unet = build_unet(NARROW)
     with pytest.raises(RuntimeError):
