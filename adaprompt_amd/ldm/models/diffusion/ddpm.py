@@ -181,11 +181,28 @@ class LatentDiffusion(DDPM):
         """cond = (c_static_emb, c_in, extra_info)  (ddpm.py:2192-2297, the un-tiled branch :2292)."""
         return self.model(x_noisy, t, c_crossattn=[cond])
 
-    def guided_denoise(self, x_start, noise, t, cond, unet_has_grad=True):
+    def guided_denoise(self, x_start, noise, t, cond, unet_has_grad=True, do_pixel_recon=False, cfg_info=None):
+        """ddpm.py:2483-2532.  -> (model_output, x_noisy) on the recon path; with ``do_pixel_recon`` ->
+        (model_output, x_recon): the unconditional prediction is computed without grad on the FIRST half of the
+        batch only and repeated (the second half shares its initial conditions), combined by classifier-free
+        guidance ``eps * s - eps_uncond * (s - 1)`` with per-instance scales ``cfg_info['cfg_scales']`` (or no
+        guidance when None) and turned into x0 by ``predict_start_from_noise``."""
         x_noisy = self.q_sample(x_start=x_start, t=t, noise=noise)
         with torch.set_grad_enabled(unet_has_grad):
             model_output = self.apply_model(x_noisy, t, cond)
-        return model_output, x_noisy
+        if not do_pixel_recon:
+            return model_output, x_noisy
+        with torch.no_grad():
+            x_start_, noise_, t_ = x_start.chunk(2)[0], noise.chunk(2)[0], t.chunk(2)[0]
+            x_noisy_ = self.q_sample(x_start=x_start_.contiguous(), t=t_.contiguous(), noise=noise_.contiguous())
+            model_output_uncond = self.apply_model(x_noisy_, t_, cfg_info["uncond_context"]).repeat(2, 1, 1, 1)
+        if cfg_info.get("cfg_scales") is not None:
+            cfg_scales = cfg_info["cfg_scales"].view(-1, 1, 1, 1)
+            pred_noise = model_output * cfg_scales - model_output_uncond * (cfg_scales - 1)
+        else:
+            pred_noise = model_output
+        x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=pred_noise)
+        return model_output, x_recon
 
     def calc_recon_loss(self, model_output, target, img_mask, fg_mask, fg_pixel_weight=1, bg_pixel_weight=1):
         """returns (loss, d loss / d model_output); both NCHW-shaped."""

@@ -137,6 +137,8 @@ def main():
                     help="replay the micro-batch as two hipGraphs (fwd, bwd) instead of launching eagerly; measured "
                          "45.1 vs 44.3 ms/step on MI355X -- the step is GPU-bound, not launch-bound, so eager is the default")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-distill-mix", action="store_true",
+                    help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
     args = ap.parse_args()
 
     from adaprompt_amd import _lib, ops
@@ -327,6 +329,56 @@ def main():
                     "others": {**{k: fam(v, "TFLOP/s") for k, v in summ.items() if k != dom and (k.startswith("conv") or "attention" in k)},
                                **{k: fam(v, "GB/s") for k, v in summ.items() if k.startswith("groupnorm")}}}
 
+    # ---- extra leg, reported beside `value`: config 2's actual iteration mix -- VAE encode of 4, then the
+    # Arc2Face teacher rolls ND in {1,3,5,7} steps out on HALF_BS instances and the student is distilled on them
+    distill = None
+    if world == 1 and not args.no_distill_mix:
+        import numpy as np
+        from adaprompt_amd import synth
+        from adaprompt_amd.ldm.models.diffusion.ddpm import Arc2FaceWrapper, LatentDiffusion
+        with torch.device(device):
+            teacher = Arc2FaceWrapper(unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                                   "params": dict(synth.SD15_UNET)})
+        teacher.unet.load_state_dict(device_state_dict(synth.unet_param_shapes(**synth.SD15_UNET), "", device, 5))
+        ld.set_arc2face_teacher(teacher.to(device).eval())
+        rs = np.random.RandomState(0)
+        nd_seq = [LatentDiffusion.draw_num_denoising_steps(7, rs) for _ in range(12)]
+        tctx = torch.randn(B, 21, 768, device=device, generator=gen) * 0.05
+
+        def dstep(i, nd):
+            batch = dict(batches[i % 2])
+            batch["arc2face_prompt_emb"] = tctx
+            t = torch.randint(0, 1000, (B,), device=device, generator=gen)
+            noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+            loss, grads, outs, aux = ld.shared_step(batch, t=t, noise=noise, num_denoising_steps=nd,
+                                                    use_arc2face_as_target=True)
+            reducer.wait()
+            torch.autograd.backward(outs, grads)
+            reducer.reduce()
+            ld.batch_idx += 1
+            if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
+                reducer.wait()
+                opt.step(clip_norm=ld.grad_clip)
+                reducer.zero()
+                sched.step()
+            return len(outs)
+
+        for i, nd in enumerate((1, 3, 5, 7)):
+            dstep(i, nd)
+        sync()
+        t1 = time.perf_counter()
+        student_passes = sum(dstep(i, nd) for i, nd in enumerate(nd_seq))
+        sync()
+        dd = time.perf_counter() - t1
+        distill = {"workload": "config 2 iteration mix: VAE encode of 4 + Arc2Face teacher rollout (full SD-1.5 UNet on the "
+                               "same kernels, no grad) of ND steps on HALF_BS instances + student fwd/bwd on the teacher's "
+                               "predictions; ND drawn from {1,3,5,7} p=(.4,.3,.2,.1), seed 0",
+                   "nd_sequence": nd_seq, "micro_batches": len(nd_seq),
+                   "images_per_sec": round(B * len(nd_seq) / dd, 2), "ms_per_micro_batch": round(1e3 * dd / len(nd_seq), 2),
+                   "teacher_unet_passes": int(sum(nd_seq)), "student_unet_fwd_bwd_passes": int(student_passes)}
+        ld.set_arc2face_teacher(None)
+        del teacher
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
@@ -356,6 +408,8 @@ def main():
             res["roofline"] = roofline
         if cpu is not None:
             res["cpu_baseline"] = cpu
+        if distill is not None:
+            res["config2_distill_mix"] = distill
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -352,6 +352,50 @@ def test_arc2face_distill_step_vs_oracle():
     assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
 
 
+def test_guided_denoise_cfg_pixel_recon_vs_oracle():
+    """a10: the do_pixel_recon branch -- uncond pass on the first half batch, repeated, CFG combine, x0 prediction."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import ldm_oracle as O
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                         {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    ld.load_state_dict(usd, strict=False)
+    ld = ld.to(dev())
+    B = 4
+    x0 = synth.synthetic_input("cfg.x0", (B, 4, 64, 64))
+    x0[2:] = x0[:2]                                     # second half shares the initial conditions of the first
+    noise = synth.synthetic_input("cfg.noise", (B, 4, 64, 64))
+    noise[2:] = noise[:2]
+    t = torch.tensor([300, 700, 300, 700])
+    ctx = synth.synthetic_input("cfg.ctx", (16 * B, 77, ucfg["context_dim"]))
+    uctx = synth.synthetic_input("cfg.uctx", (16 * 2, 77, ucfg["context_dim"]))
+    scales = torch.tensor([1.5, 2.0, 3.0, 1.0])
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": False, "img_mask": None}
+    sch = O.make_schedule()
+    with torch.no_grad():
+        xn = O.q_sample(sch, x0, t, noise)
+        eps = O.unet_forward(usd, ucfg, xn, t, ctx, extra)
+        eps_u = O.unet_forward(usd, ucfg, xn[:2], t[:2], uctx, extra).repeat(2, 1, 1, 1)
+        s4 = scales.view(-1, 1, 1, 1)
+        x_rec_ref = O.predict_start_from_noise(sch, xn, t, eps * s4 - eps_u * (s4 - 1))
+    with torch.no_grad():
+        mo, x_rec = ld.guided_denoise(x0.to(dev()), noise.to(dev()), t.to(dev()), (ctx.to(dev()), None, dict(extra)),
+                                      unet_has_grad=False, do_pixel_recon=True,
+                                      cfg_info={"uncond_context": (uctx.to(dev()), None, dict(extra)),
+                                                "cfg_scales": scales.to(dev())})
+        _, x_rec_nocfg = ld.guided_denoise(x0.to(dev()), noise.to(dev()), t.to(dev()),
+                                           (ctx.to(dev()), None, dict(extra)), unet_has_grad=False,
+                                           do_pixel_recon=True,
+                                           cfg_info={"uncond_context": (uctx.to(dev()), None, dict(extra)),
+                                                     "cfg_scales": None})
+    assert rel_err(mo.cpu(), eps) < EPS_TOL
+    assert rel_err(x_rec.cpu(), x_rec_ref) < EPS_TOL, rel_err(x_rec.cpu(), x_rec_ref)
+    assert rel_err(x_rec_nocfg.cpu(), O.predict_start_from_noise(sch, xn, t, eps)) < EPS_TOL
+
+
 def test_cpu_tensor_fails_loudly():
     unet = build_unet(NARROW)
     with pytest.raises(RuntimeError):
