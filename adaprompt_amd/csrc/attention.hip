@@ -66,6 +66,8 @@ struct AttnParams {
     float* dv32; uint16_t* dv16; long lddv;
     int B, H, N, M, d;
     float scale;
+    int qsplit;                 // dK/dV kernel: the query range is cut into qsplit slices (blockIdx.z), f32 partials
+    float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
 };
 
 template <int KS>
@@ -141,7 +143,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<NCH>& r, const TileMap
 // forward
 // =============================================================================================
 template <int KS, int VT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int KSTRIDE = G::RSTRIDE;
     constexpr int VSTRIDE = VGeom<VT>::VSTRIDE;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
 // backward, part 1: dQ (query-stationary)
 // =============================================================================================
 template <int KS, int VT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int KSTRIDE = G::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // backward, part 2: dK, dV (key-stationary: a wave owns 32 keys, the workgroup 128 keys)
 // =============================================================================================
 template <int KS, int VT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int QSTRIDE = G::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -545,15 +547,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
             rd = ok ? -dlb[q0 + tid] : 0.f;
         }
     };
-    tile_load(rQ, mapQ, qb, min(64, p.N));
-    tile_load(rDO, mapDO, dob, min(64, p.N));
-    row_stats_load(0);
+    // this workgroup's slice of the query tiles (the whole range unless the grid was too small to fill the chip)
+    const int split = blockIdx.z;
+    const int qt0 = (int)((long)split * ntiles / p.qsplit), qt1 = (int)((long)(split + 1) * ntiles / p.qsplit);
+    tile_load(rQ, mapQ, qb + (size_t)qt0 * 64 * p.ldq, min(64, p.N - qt0 * 64));
+    tile_load(rDO, mapDO, dob + (size_t)qt0 * 64 * p.lddo, min(64, p.N - qt0 * 64));
+    row_stats_load(qt0 * 64);
     tile_store(rQ, mapQ, sQ);
     tile_store(rDO, mapDO, sDO);
     if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
     __syncthreads();
-    for (int qt = 0; qt < ntiles; ++qt) {
-        const bool more = qt + 1 < ntiles;
+    for (int qt = qt0; qt < qt1; ++qt) {
+        const bool more = qt + 1 < qt1;
         if (more) {
             const int q1 = (qt + 1) * 64;
             tile_load(rQ, mapQ, qb + (size_t)q1 * p.ldq, min(64, p.N - q1));
@@ -621,6 +626,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
                     size_t offv = ((size_t)b * p.M + key) * p.lddv + head * d + d0;
                     float k0 = dK[vt][4 * g] * p.scale, k1 = dK[vt][4 * g + 1] * p.scale;
                     float k2 = dK[vt][4 * g + 2] * p.scale, k3 = dK[vt][4 * g + 3] * p.scale;
+                    if (p.qsplit > 1) {
+                        const size_t C = (size_t)p.H * d, rows = (size_t)p.B * p.M;
+                        float* pk = p.part + (((size_t)split * 2) * rows + (size_t)b * p.M + key) * C + head * d + d0;
+                        *(float4*)pk = make_float4(k0, k1, k2, k3);
+                        *(float4*)(pk + rows * C) =
+                            make_float4(dV[vt][4 * g], dV[vt][4 * g + 1], dV[vt][4 * g + 2], dV[vt][4 * g + 3]);
+                        continue;
+                    }
                     if (p.dk32) *(float4*)(p.dk32 + offk) = make_float4(k0, k1, k2, k3);
                     if (p.dk16) {
                         uint2 w;
@@ -642,6 +655,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     }
 }
 
+// fixed-order sum of the query-split partials -> dK / dV in the requested dtypes (deterministic, no atomics)
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnParams p) {
+    const int C4 = p.H * p.d / 4;
+    const size_t rows = (size_t)p.B * p.M, C = (size_t)p.H * p.d;
+    const size_t total = rows * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sp = 0; sp < p.qsplit; ++sp) {
+                float4 v = *(const float4*)(p.part + (((size_t)sp * 2 + which) * rows + row) * C + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float* o32 = which ? p.dv32 : p.dk32;
+            uint16_t* o16 = which ? p.dv16 : p.dk16;
+            const long ld = which ? p.lddv : p.lddk;
+            if (o32) *(float4*)(o32 + row * ld + c) = acc;
+            if (o16) {
+                uint2 w;
+                w.x = pack_bf16x2(acc.x, acc.y);
+                w.y = pack_bf16x2(acc.z, acc.w);
+                *(uint2*)(o16 + row * ld + c) = w;
+            }
+        }
+    }
+}
+
+// query-split factor of the dK/dV kernel: key-stationary workgroups number ceil(M/128)*B*H, which is only 32 for the
+// cross-attention layers (M = 77) -- far too few for 256 CUs -- so the query loop is cut into slices
+static int dkv_qsplit(int B, int H, int N, int M, int d) {
+    const long blocks = (long)((M + 127) / 128) * B * H;
+    const int ntiles = (N + 63) / 64;
+    if (blocks >= 256 || ntiles < 2) return 1;
+    long want = (512 + blocks - 1) / blocks;
+    if (want > 16) want = 16;
+    if (want > ntiles) want = ntiles;
+    // the partials are written and read once more: keep them under 16 MB, otherwise (self-attention at 16x16 with
+    // 1280 channels: 10 MB per slice) the extra HBM pass costs more than the idle CUs did (measured 71 vs 48 us)
+    const long per_slice = 2L * B * M * H * d * 4;
+    while (want > 1 && want * per_slice > (16L << 20)) --want;
+    return (int)want;
+}
+
 // =============================================================================================
 // host dispatch
 // =============================================================================================
@@ -659,8 +717,14 @@ static int launch_bwd(const AttnParams& p, hipStream_t s) {
     dim3 g1((p.N + 127) / 128, p.B * p.H);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT>), g1, dim3(256), lds1, s, p);
     size_t lds2 = 2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4;
-    dim3 g2((p.M + 127) / 128, p.B * p.H);
+    dim3 g2((p.M + 127) / 128, p.B * p.H, p.qsplit);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT>), g2, dim3(256), lds2, s, p);
+    if (p.qsplit > 1) {
+        long tot = (long)p.B * p.M * (p.H * p.d / 4);
+        long nb = (tot + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, p);
+    }
     return adap_check_launch("attn_bwd");
 }
 
@@ -700,13 +764,20 @@ extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long l
     ATTN_DISPATCH(launch_fwd, p, (hipStream_t)stream);
 }
 
+extern "C" long adap_attention_bwd_workspace_floats(int B, int H, int N, int M, int d) {
+    long delta = ((long)B * H * N + 3) & ~3L;
+    int qs = dkv_qsplit(B, H, N, M, d);
+    return delta + (qs > 1 ? (long)qs * 2 * B * M * H * d : 0);
+}
+
 extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                   const uint8_t* key_mask, const void* out, long ldo, const void* dout, long lddo,
-                                  const float* lse, float* delta_ws,
+                                  const float* lse, float* workspace,
                                   float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
                                   float* dv32, void* dv16, long lddv,
                                   int B, int H, int N, int M, int d, float scale, void* stream) {
-    ADAP_REQUIRE(q && k && v && out && dout && lse && delta_ws, ADAP_ERR_SHAPE, "attention_bwd: null pointer");
+    ADAP_REQUIRE(q && k && v && out && dout && lse && workspace, ADAP_ERR_SHAPE, "attention_bwd: null pointer");
+    float* delta_ws = workspace;
     ADAP_REQUIRE((dq32 || dq16) && (dk32 || dk16) && (dv32 || dv16), ADAP_ERR_SHAPE, "attention_bwd: missing output");
     int rc = attn_common_checks("attention_bwd", B, H, N, M, d, ldq, ldk, ldv);
     if (rc) return rc;
@@ -724,6 +795,8 @@ extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long l
     p.dk32 = dk32; p.dk16 = (uint16_t*)dk16; p.lddk = lddk;
     p.dv32 = dv32; p.dv16 = (uint16_t*)dv16; p.lddv = lddv;
     p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    p.qsplit = dkv_qsplit(B, H, N, M, d);
+    p.part = workspace + (((size_t)B * H * N + 3) & ~(size_t)3);
     ATTN_DISPATCH(launch_bwd, p, s);
 }
 

@@ -26,8 +26,7 @@ from .. import _lib
 _ST_KEYS = ("d", "d_max", "d_numerator", "d_denom", "d_hat", "k")
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = _lib.current_stream
 
 
 class Prodigy(torch.optim.Optimizer):

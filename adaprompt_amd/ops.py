@@ -12,8 +12,7 @@ F32 = torch.float32
 BF16 = torch.bfloat16
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = _lib.current_stream
 
 
 class KernelTimer:
@@ -65,6 +64,9 @@ def _ptr(t):
 
 def _rows_ld(t):
     """(rows, ld) of a pixel-major tensor whose leading dims are packed with respect to stride(-2)."""
+    if t.is_contiguous() and t.is_cuda:              # the common case, checked in C
+        c = t.shape[-1]
+        return (t.numel() // c if c else 0), c
     assert t.is_cuda, "HIP kernels need device tensors (no CPU fallback)"
     assert t.stride(-1) == 1 or t.shape[-1] == 1, f"channel dim must be contiguous, got strides {t.stride()}"
     if t.dim() == 1:
@@ -156,7 +158,7 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
         y32 = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=F32)
     ws = None
     if ksplit == 0:
-        nws = _lib.call_long("adap_conv2d_workspace_floats", B, Ho, Wo, Cin, Cout, KH, KH)
+        nws = _lib.size_query("adap_conv2d_workspace_floats", B, Ho, Wo, Cin, Cout, KH, KH)
     else:
         nws = ksplit * B * Ho * Wo * Cout if ksplit > 1 else 0
     if nws:
@@ -225,7 +227,7 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     B, C = x.shape[0], x.shape[-1]
     rows, ldx = _rows_ld(x)
     HW = rows // B
-    ws = torch.empty(_lib.call_long("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
+    ws = torch.empty(_lib.size_query("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
     mean = torch.empty(B, 32, device=x.device, dtype=F32)
     rstd = torch.empty(B, 32, device=x.device, dtype=F32)
     y32 = torch.empty(x.shape, device=x.device, dtype=F32) if out_f32 else None
@@ -244,7 +246,7 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=Fa
     rows, ldx = _rows_ld(x)
     _, lddy = _rows_ld(dy)
     HW = rows // B
-    ws = torch.empty(_lib.call_long("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
+    ws = torch.empty(_lib.size_query("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
     acc = 0
     dx32 = None
     if accumulate_into is not None:
@@ -318,7 +320,7 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=Non
     d = C // heads
     assert dout.dtype == BF16 and out.dtype == BF16
     dev = q.device
-    delta = torch.empty(B, heads, N, device=dev, dtype=F32)
+    delta = torch.empty(_lib.size_query("adap_attention_bwd_workspace_floats", B, heads, N, M, d), device=dev, dtype=F32)
     dq = torch.empty(B, N, C, device=dev, dtype=out_dtype) if dq is None else dq
     dk = torch.empty(B, M, C, device=dev, dtype=out_dtype) if dk is None else dk
     dv = torch.empty(B, M, C, device=dev, dtype=out_dtype) if dv is None else dv

@@ -317,8 +317,10 @@ def main():
             return {"launches_per_step": v["launches"] // 2, "ms_per_step": round(v["ms"] / 2, 3),
                     "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 1),
                     "achieved": round(v["work"] / (v["ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9), 1), "unit": unit}
+        traffic, traffic_src = pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src,
                     "launches_per_step": c["launches"] // 2, "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 1),
                     "ms_per_step_in_kernel": round(c["ms"] / 2, 3),
                     "note": "algorithmic 2*MAC FLOPs of the launches dispatched to this kernel / their HIP-event time on the "
@@ -413,6 +415,24 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC summary (profiles/rNN_pmc_traffic.json, written by
+    tools/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same
+    command; counters cannot be collected from inside the timed run).  None when no summary holds the kernel."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        e = d.get("kernels", {}).get(kernel)
+        if e:
+            return e["traffic_bytes_per_launch"], os.path.relpath(path, here)
+    return None, None
 
 
 def reducer_bytes(world):

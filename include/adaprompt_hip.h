@@ -114,10 +114,13 @@ int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, con
 int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                        const uint8_t* key_mask, void* out, long ldo, float* lse,
                        int B, int H, int N, int M, int d, float scale, void* stream);
-/* dq/dk/dv as f32 and/or bf16; delta_ws: B*H*N floats of scratch. */
+/* dq/dk/dv as f32 and/or bf16; workspace: adap_attention_bwd_workspace_floats(...) floats of scratch (the row
+ * dots delta = sum(dO * O) and, when few key blocks exist -- cross attention, M = 77 -- the f32 partials of the
+ * query-split dK/dV pass, summed in a fixed order). */
+long adap_attention_bwd_workspace_floats(int B, int H, int N, int M, int d);
 int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                        const uint8_t* key_mask, const void* out, long ldo, const void* dout, long lddo,
-                       const float* lse, float* delta_ws,
+                       const float* lse, float* workspace,
                        float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
                        float* dv32, void* dv16, long lddv,
                        int B, int H, int N, int M, int d, float scale, void* stream);
