@@ -25,6 +25,7 @@
 // resolutions: every split writes its raw fp32 tile to a workspace slab and a second kernel sums the
 // slabs in a fixed order and applies the epilogue -- no float atomics, bit-reproducible.
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvParams {
     const void* x;          // activations (bf16 or f32), pixel-major
@@ -53,6 +54,8 @@ struct ConvParams {
     long batch_stride_w;
     long batch_stride_y32;
     long batch_stride_y16;
+    int dbg;                // what-if switches for tuning (env ADAP_CONV_DEBUG; 0 in production): 1 no DMA in the loop,
+                            // 2 no MFMA, 4 no epilogue stores -- results are garbage with any of them set
 };
 
 #define BM 128
@@ -661,6 +664,17 @@ __global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
     }
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 static void launch_reduce(const ConvParams& p, hipStream_t stream) {
     const int M = p.B * p.Hout * p.Wout;
     long total = (long)M * (p.Cout >> 2);
@@ -698,7 +712,7 @@ static int launch_ring(const ConvParams& p, hipStream_t stream) {
 #define HALO_W (HALO_TW + 2)
 #define HALO_SLOTS ((HALO_TH + 2) * HALO_W)      // 340
 #define HALO_PASSES 6                            // 6 x 64 slots >= 340
-template <int BN>
+template <int BN, bool PERSIST>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
     constexpr int WN = BN / 2;
     constexpr int MT = WN / 16;
@@ -719,15 +733,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
 
     const int tiles_x = p.Win / HALO_TW, tiles_y = p.Hin / HALO_TH;
     const int nwg = p.ntiles_m * p.ntiles_n;
-    const int bid = xcd_remap(blockIdx.x, nwg);
-    const int tn = bid % p.ntiles_n;
-    int tm = bid / p.ntiles_n;
-    const int tx = tm % tiles_x;
-    tm /= tiles_x;
-    const int ty = tm % tiles_y;
-    const int bimg = tm / tiles_y;
-    const int y0 = ty * HALO_TH, x0 = tx * HALO_TW;
-    const int n0 = tn * BN;
 
     const int nchunks_total = p.ktiles_per_tap;        // 64-channel slices of Cin
     int ch_begin = 0, ch_end = nchunks_total;
@@ -737,27 +742,50 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
         ch_end = min(nchunks_total, ch_begin + per);
     }
     const int nch = ch_end - ch_begin;
+    if (nch <= 0) return;
 
     const int srow = tid >> 3;                          // 0..63
-    const int lchunk = (lane & 7) ^ ((lane >> 3) & 7);
-    // halo slots staged by this thread: s = 64*i + srow -> window pixel (s / 34, s % 34)
-    unsigned a_base[HALO_PASSES], a_kill[HALO_PASSES];
+    // LDS image of the window: slot (hr, hc) -> 128-B row hr*34 + hc, its eight 16-B chunks XOR-swizzled by the window
+    // COLUMN (hc & 7).  Keying on the column (not the slot index) makes a tap's row shift a plain +34*128*ky bytes
+    // (an instruction immediate), so only the three kx variants of a fragment address live in registers.  16 lanes of
+    // a fragment read 16 consecutive columns of one row: every key appears twice, on opposite bank halves.
+    const int wchunk = (lane & 7) ^ ((lane >> 3) & 7);  // weights: rows of 8*wv + lane/8, key = row & 7
+
+    // PERSISTENT: this workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... as ONE stream of K steps --
+    // the DMA ring never drains at a tile boundary: the next tile's halo window and first weight slices are already in
+    // flight while the current tile's last taps compute and its epilogue stores issue (measured before: prologue +
+    // epilogue + drain were 28 % of the 512->512 @128^2 launch with one workgroup per CU).
+    struct Tile {
+        unsigned a_base[HALO_PASSES];   // halo slots staged by this thread: s = 64*i + srow; bit 31 set = zero fill
+        unsigned b_base[BPASS];         // (offsets stay below 2^31, so adding the chunk offset keeps the bit)
+        int bimg, y0, x0, n0;
+    };
+    auto decode = [&](int tile_id, Tile& c) {
+        const int bid = xcd_remap(tile_id, nwg);
+        const int tn = bid % p.ntiles_n;
+        int tm = bid / p.ntiles_n;
+        const int tx = tm % tiles_x;
+        tm /= tiles_x;
+        const int ty = tm % tiles_y;
+        c.bimg = tm / tiles_y;
+        c.y0 = ty * HALO_TH;
+        c.x0 = tx * HALO_TW;
+        c.n0 = tn * BN;
 #pragma unroll
-    for (int i = 0; i < HALO_PASSES; ++i) {
-        int sidx = 64 * i + srow;
-        int hr = sidx / HALO_W, hc = sidx - hr * HALO_W;
-        int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-        bool ok = sidx < HALO_SLOTS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-        a_base[i] = (unsigned)((((bimg * p.Hin + iy) * p.Win + ix) * (int)p.ldx + lchunk * 8) * 2);
-        a_kill[i] = ok ? 0u : OOB;
-    }
-    unsigned b_base[BPASS], b_kill[BPASS];
+        for (int i = 0; i < HALO_PASSES; ++i) {
+            int sidx = 64 * i + srow;
+            int hr = sidx / HALO_W, hc = sidx - hr * HALO_W;
+            int iy = c.y0 - 1 + hr, ix = c.x0 - 1 + hc;
+            bool ok = sidx < HALO_SLOTS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            int lchunk = (lane & 7) ^ (hc & 7);
+            c.a_base[i] = ok ? (unsigned)((((c.bimg * p.Hin + iy) * p.Win + ix) * (int)p.ldx + lchunk * 8) * 2) : OOB;
+        }
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-        int n = n0 + srow + 64 * i;
-        b_kill[i] = n < p.Cout ? 0u : OOB;
-        b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
-    }
+        for (int i = 0; i < BPASS; ++i) {
+            int n = c.n0 + srow + 64 * i;
+            c.b_base[i] = n < p.Cout ? (unsigned)((n * p.Cin + wchunk * 8) * 2) : OOB;
+        }
+    };
     int nB = 0;
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) nB += (64 * i + 8 * wv < BN) ? 1 : 0;
@@ -765,27 +793,23 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
-    auto stage_a = [&](int buf, int chunk) {             // HALO_PASSES DMA instructions per wave
-        const int c0 = chunk * BK;
-        unsigned kill = (c0 + lchunk * 8 < p.Cin) ? 0u : OOB;
-        asm volatile("" : "+v"(kill));
+    auto stage_a = [&](const Tile& c, int buf, int chunk) {     // HALO_PASSES DMA instructions per wave
+        const int c0 = chunk * BK;                               // Cin % 64 == 0 (choose_halo): no ragged K slice
         char* base = sA + buf * A_STAGE + wv * 1024;
 #pragma unroll
         for (int i = 0; i < HALO_PASSES; ++i) {
-            unsigned voff = (a_base[i] + (unsigned)(c0 * 2)) | a_kill[i] | kill;
+            unsigned voff = c.a_base[i] + (unsigned)(c0 * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(base + i * 8192), 16, voff, 0, 0, 0);
         }
     };
-    auto stage_b = [&](int buf, int chunk, int tap) {    // nB DMA instructions per wave
+    auto stage_b = [&](const Tile& c, int buf, int chunk, int tap) {    // nB DMA instructions per wave
         const int c0 = chunk * BK;
-        unsigned kill = (c0 + lchunk * 8 < p.Cin) ? 0u : OOB;
-        asm volatile("" : "+v"(kill));
         const unsigned tapw = (unsigned)((tap * p.Cout * p.Cin + c0) * 2);
         char* base = sB + buf * B_STAGE + wv * 1024;
 #pragma unroll
         for (int i = 0; i < BPASS; ++i) {
             if (64 * i + 8 * wv < BN) {
-                unsigned voff = (b_base[i] + tapw) | b_kill[i] | kill;
+                unsigned voff = c.b_base[i] + tapw;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(base + i * 8192), 16, voff, 0, 0, 0);
             }
         }
@@ -798,109 +822,150 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
         for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
-    // window slot of this lane's pixel in fragment j at tap (0,0): patch row 2*wm + (j>>1), column (j&1)*16 + frow
-    int sbase[PT];
+    // LDS byte offsets of every fragment this lane will ever read, computed ONCE: the nine taps are unrolled below, so
+    // the ring slot (tap % 3), the tap's window shift and the K half (s) fold into immediates / these registers and
+    // the per-step instruction stream is DMA issue + 16 ds_read_b128 + 32 MFMA, no address arithmetic.
+    //   window: slot of this lane's pixel in fragment j at tap (ky,kx) = (2*wm + (j>>1) + ky) * 34 + (j&1)*16 + frow + kx
+    //   the s = 1 half is the same 16-B chunk position XOR 4  ->  byte offset XOR 64
+    int aoff[3][PT];
 #pragma unroll
-    for (int j = 0; j < PT; ++j) sbase[j] = (2 * wm + (j >> 1)) * HALO_W + (j & 1) * 16 + frow;
-
-    auto compute = [&](int abuf, int bbuf, int tap) {
-        const char* a = sA + abuf * A_STAGE;
-        const char* b = sB + bbuf * B_STAGE;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int shift = ky * HALO_W + kx;
+    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 fw[MT], fx[PT];
-            const int cc = 4 * s + fchunk;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                int r = wn * WN + i * 16 + frow;
-                fw[i] = *(const bf16x8*)(b + r * 128 + ((cc ^ (r & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < PT; ++j) {
-                int sl = sbase[j] + shift;
-                fx[j] = *(const bf16x8*)(a + sl * 128 + ((cc ^ (sl & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < PT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < PT; ++j) {
+            int hc = (j & 1) * 16 + frow + kx;
+            int sl = (2 * wm + (j >> 1)) * HALO_W + hc;
+            aoff[kx][j] = sl * 128 + ((fchunk ^ (hc & 7)) << 4);
         }
-    };
-
-    // ---- pipeline: step t = (chunk t/9, tap t%9).  B(t+2) is issued at step t; A(chunk+1) at tap 0, after B(t+2).
-    const int T = nch * 9;
-    if (nch > 0) {
-        stage_a(0, ch_begin);
-        stage_b(0, ch_begin, 0);
-        stage_b(1, ch_begin, 1);
-    }
-    int bbuf = 0;
-    for (int t = 0; t < T; ++t) {
-        const int ci = t / 9, tap = t - 9 * ci;
-        // DMA instructions that may still be in flight while tile t is complete: B(t+1), and A(ci+1) during taps 1-2
-        int allow = (t + 1 < T) ? nB : 0;
-        if ((tap == 1 || tap == 2) && ci + 1 < nch) allow += HALO_PASSES;
-        switch (allow) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < T) {
-            int t2 = t + 2, c2 = t2 / 9;
-            int nb = bbuf + 2;
-            if (nb >= 3) nb -= 3;
-            stage_b(nb, ch_begin + c2, t2 - 9 * c2);
-        }
-        if (tap == 0 && ci + 1 < nch) stage_a((ci + 1) & 1, ch_begin + ci + 1);
-        compute(ci & 1, bbuf, tap);
-        if (++bbuf == 3) bbuf = 0;
+    int woff[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int r = wn * WN + i * 16 + frow;
+        woff[i] = r * 128 + ((fchunk ^ (r & 7)) << 4);
     }
 
     const int M = p.B * p.Hin * p.Win;
     float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
+    auto epilogue = [&](const Tile& c) {
 #pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int yy = y0 + 2 * wm + (j >> 1), xx = x0 + (j & 1) * 16 + frow;
-        const int m = (bimg * p.Hin + yy) * p.Win + xx;
+        for (int j = 0; j < PT; ++j) {
+            const int yy = c.y0 + 2 * wm + (j >> 1), xx = c.x0 + (j & 1) * 16 + frow;
+            const int m = (c.bimg * p.Hin + yy) * p.Win + xx;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
-            if (c0 >= p.Cout) continue;
-            if (slab) {
-                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                continue;
-            }
-            float v[4];
+            for (int i = 0; i < MT; ++i) {
+                const int c0 = c.n0 + wn * WN + i * 16 + fchunk * 4;
+                if (c0 < p.Cout) {
+                    if (slab) {
+                        *(float4*)(slab + (size_t)m * p.Cout + c0) =
+                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    } else {
+                        float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            if (p.bias) {
-                float4 t = *(const float4*)(p.bias + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.chan_add) {
-                float4 t = *(const float4*)(p.chan_add + (size_t)bimg * p.ld_ca + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.residual) {
-                float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.y16) {
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
+                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+                        if (p.bias) {
+                            float4 t = *(const float4*)(p.bias + c0);
+                            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                        }
+                        if (p.chan_add) {
+                            float4 t = *(const float4*)(p.chan_add + (size_t)c.bimg * p.ld_ca + c0);
+                            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                        }
+                        if (p.residual) {
+                            float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+                            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                        }
+                        if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (p.y16) {
+                            uint2 o;
+                            o.x = pack_bf16x2(v[0], v[1]);
+                            o.y = pack_bf16x2(v[2], v[3]);
+                            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
+                        }
+                    }
+                }
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
+    };
+
+    // ---- the step stream.  A step = (chunk, tap); the nine taps of a chunk are unrolled (ring slot = tap % 3 because
+    // 9 % 3 == 0).  B(step+2) is issued at each step, the next chunk's window at tap 0 after it; "step+2" and "next
+    // chunk" run on into the next tile of this workgroup.
+    const int G = gridDim.x;
+    int tile_id = blockIdx.x;
+    if (tile_id >= nwg) return;
+    Tile cur, nxt;
+    decode(tile_id, cur);
+    bool has_next = PERSIST && tile_id + G < nwg;      // !PERSIST: one tile per workgroup, no second tile context
+    if (has_next) decode(tile_id + G, nxt);
+    stage_a(cur, 0, ch_begin);
+    stage_b(cur, 0, ch_begin, 0);
+    stage_b(cur, 1, ch_begin, 1);
+    int gc = 0;            // chunks consumed so far by this workgroup: window of chunk gc lives in sA[gc & 1]
+    bool after_epilogue = false;
+    for (;;) {
+        for (int ci = 0; ci < nch; ++ci) {
+            const bool last_chunk = ci + 1 == nch;
+            const bool more_chunks = !last_chunk || has_next;
+            const char* a = sA + (gc & 1) * A_STAGE;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // DMA instructions that may still be in flight while this step's operands are complete: B(step+1), and
+                // the next chunk's window during taps 1-2.  Right after an epilogue the counter also holds that tile's
+                // stores, whose order against loads is not guaranteed: drain everything once.
+                const bool more_steps = tap < 8 || more_chunks;
+                if (tap == 0 && after_epilogue) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if ((tap == 1 || tap == 2) && more_chunks) {
+                    if (nB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                } else if (more_steps) {
+                    if (nB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!(p.dbg & 1)) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int nb = (tap + 2) % 3;
+                    if (tap + 2 < 9) stage_b(cur, nb, ch_begin + ci, tap + 2);
+                    else if (!last_chunk) stage_b(cur, nb, ch_begin + ci + 1, tap + 2 - 9);
+                    else if (has_next) stage_b(nxt, nb, ch_begin, tap + 2 - 9);
+                    if (tap == 0) {
+                        if (!last_chunk) stage_a(cur, (gc + 1) & 1, ch_begin + ci + 1);
+                        else if (has_next) stage_a(nxt, (gc + 1) & 1, ch_begin);
+                    }
+                }
+                if (!(p.dbg & 2)) {
+                    const char* b = sB + (tap % 3) * B_STAGE;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 fw[MT], fx[PT];
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) fw[i] = *(const bf16x8*)(b + (woff[i] ^ (s2 * 64)));
+#pragma unroll
+                        for (int j = 0; j < PT; ++j)
+                            fx[j] = *(const bf16x8*)(a + (tap / 3) * (HALO_W * 128) + (aoff[tap % 3][j] ^ (s2 * 64)));
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < PT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            after_epilogue = false;
+            ++gc;
+        }
+        if (!(p.dbg & 4)) epilogue(cur);
+        if (!has_next) break;
+        tile_id += G;
+        cur = nxt;
+        has_next = PERSIST && tile_id + G < nwg;
+        if (has_next) decode(tile_id + G, nxt);
+        after_epilogue = true;
     }
 }
 
@@ -909,11 +974,18 @@ static int launch_halo(const ConvParams& p, hipStream_t stream) {
     size_t lds = 2 * HALO_PASSES * 64 * 128 + 3 * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(p.ntiles_m * p.ntiles_n, 1, p.ksplit);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN>), grid, dim3(512), lds, stream, p);
+    // one workgroup per CU (144 KB of LDS each).  More tiles than CUs and no split-K: persistent workgroups walk the
+    // tiles; otherwise one tile per workgroup (the variant without the second tile context, fewer registers).
+    const int nwg = p.ntiles_m * p.ntiles_n;
+    if (p.ksplit == 1 && nwg > num_cus()) {
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, true>), dim3(num_cus(), 1, 1), dim3(512), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, false>), dim3(nwg, 1, p.ksplit), dim3(512), lds, stream, p);
+    }
     if (p.ksplit > 1) launch_reduce(p, stream);
     return adap_check_launch("conv3x3_halo");
 }
@@ -949,7 +1021,7 @@ static bool choose_big(long M, int Cout, int ktiles_total, int x_dtype, int nbat
 static bool choose_halo(int Hin, int Win, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int stride, int pad, int up,
                         int x_dtype, int nbatch) {
     return KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 0 && x_dtype == 1 && nbatch == 1 && Hout == Hin &&
-           Wout == Win && Hin % HALO_TH == 0 && Win % HALO_TW == 0 && Cout > 64 && Cin >= 64;
+           Wout == Win && Hin % HALO_TH == 0 && Win % HALO_TW == 0 && Cout > 64 && Cin >= 64 && Cin % 64 == 0;
 }
 
 static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
@@ -1073,6 +1145,14 @@ extern "C" int adap_conv2d_nhwc(
     p.ntiles_m = (int)((M + (big ? BMB : BM) - 1) / (big ? BMB : BM));
     p.alpha = alpha;
     p.batch_stride_x = bs_x; p.batch_stride_w = bs_w; p.batch_stride_y32 = bs_y32; p.batch_stride_y16 = bs_y16;
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("ADAP_CONV_DEBUG");
+            dbg = e ? atoi(e) : 0;
+        }
+        p.dbg = dbg;
+    }
     hipStream_t s = (hipStream_t)stream;
 
     const int bn = choose_bn(Cout);

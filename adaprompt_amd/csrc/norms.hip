@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
 
 static void gn_chunks(int HW, int C, int* nchunks, int* rows_per_chunk) {
     long elems = (long)HW * C;
-    int n = (int)(elems / 32768);
+    int n = (int)(elems / 8192);
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     if (n > HW) n = HW;
