@@ -26,6 +26,7 @@
 // slabs in a fixed order and applies the epilogue -- no float atomics, bit-reproducible.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct ConvParams {
     const void* x;          // activations (bf16 or f32), pixel-major
@@ -712,8 +713,8 @@ static int launch_ring(const ConvParams& p, hipStream_t stream) {
 #define HALO_W (HALO_TW + 2)
 #define HALO_SLOTS ((HALO_TH + 2) * HALO_W)      // 340
 #define HALO_PASSES 6                            // 6 x 64 slots >= 340
-template <int BN, bool PERSIST>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
+template <int BN, int ROLE>
+__device__ __forceinline__ void halo_body(const ConvParams& p) {
     constexpr int WN = BN / 2;
     constexpr int MT = WN / 16;
     constexpr int PT = 4;
@@ -751,10 +752,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
     // a fragment read 16 consecutive columns of one row: every key appears twice, on opposite bank halves.
     const int wchunk = (lane & 7) ^ ((lane >> 3) & 7);  // weights: rows of 8*wv + lane/8, key = row & 7
 
-    // PERSISTENT: this workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... as ONE stream of K steps --
-    // the DMA ring never drains at a tile boundary: the next tile's halo window and first weight slices are already in
-    // flight while the current tile's last taps compute and its epilogue stores issue (measured before: prologue +
-    // epilogue + drain were 28 % of the 512->512 @128^2 launch with one workgroup per CU).
+    // (A persistent variant -- one workgroup per CU walking the tiles as one unbroken stream of K steps, the next
+    // tile's window and weights prefetched across the tile boundary -- was built and measured: 5-15 % SLOWER than one
+    // tile per workgroup, because the epilogue's stores share the vmcnt counter with the DMA loads and force a full
+    // drain anyway, and the hardware dispatcher balances tiles better.  Removed.)
     struct Tile {
         unsigned a_base[HALO_PASSES];   // halo slots staged by this thread: s = 64*i + srow; bit 31 set = zero fill
         unsigned b_base[BPASS];         // (offsets stay below 2^31, so adding the chunk offset keeps the bit)
@@ -845,14 +846,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
 
     const int M = p.B * p.Hin * p.Win;
     float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
-    auto epilogue = [&](const Tile& c) {
+    auto epilogue = [&](int c_bimg, int c_y0, int c_x0, int c_n0) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const int yy = c.y0 + 2 * wm + (j >> 1), xx = c.x0 + (j & 1) * 16 + frow;
-            const int m = (c.bimg * p.Hin + yy) * p.Win + xx;
+            const int yy = c_y0 + 2 * wm + (j >> 1), xx = c_x0 + (j & 1) * 16 + frow;
+            const int m = (c_bimg * p.Hin + yy) * p.Win + xx;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int c0 = c.n0 + wn * WN + i * 16 + fchunk * 4;
+                const int c0 = c_n0 + wn * WN + i * 16 + fchunk * 4;
                 if (c0 < p.Cout) {
                     if (slab) {
                         *(float4*)(slab + (size_t)m * p.Cout + c0) =
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
                             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
                         }
                         if (p.chan_add) {
-                            float4 t = *(const float4*)(p.chan_add + (size_t)c.bimg * p.ld_ca + c0);
+                            float4 t = *(const float4*)(p.chan_add + (size_t)c_bimg * p.ld_ca + c0);
                             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
                         }
                         if (p.residual) {
@@ -890,102 +891,122 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
     // ---- the step stream.  A step = (chunk, tap); the nine taps of a chunk are unrolled (ring slot = tap % 3 because
     // 9 % 3 == 0).  B(step+2) is issued at each step, the next chunk's window at tap 0 after it; "step+2" and "next
     // chunk" run on into the next tile of this workgroup.
-    const int G = gridDim.x;
-    int tile_id = blockIdx.x;
-    if (tile_id >= nwg) return;
-    Tile cur, nxt;
-    decode(tile_id, cur);
-    bool has_next = PERSIST && tile_id + G < nwg;      // !PERSIST: one tile per workgroup, no second tile context
-    if (has_next) decode(tile_id + G, nxt);
+    //
+    // PP (ping-pong): waves 0-3 (channel half 0) and waves 4-7 (channel half 1) share the four SIMDs pairwise.  With a
+    // single barrier per step both waves of a SIMD are always in the same phase -- DMA issue, LDS reads, then MFMA --
+    // and the matrix pipe idles through the first two.  Here a step has two barriers (X, Y) and the halves run half a
+    // step apart: between X and Y half 0 issues its DMAs and reads its fragments while half 1 runs the MFMAs of the
+    // PREVIOUS step out of registers; between Y and the next X they swap.  Every SIMD always has one wave in its MFMA
+    // phase.  Ring slots and window buffers are only overwritten by DMAs issued after the X that follows their last
+    // reader, exactly as without PP, because half 1 finishes reading step t before X(t+1).
+    if ((int)blockIdx.x >= nwg) return;
+    bf16x8 fw[2][MT], fx[2][PT];
+    auto load_frags = [&](const char* a, int tap) {
+        const char* b = sB + (tap % 3) * B_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fw[s2][i] = *(const bf16x8*)(b + (woff[i] ^ (s2 * 64)));
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                fx[s2][j] = *(const bf16x8*)(a + (tap / 3) * (HALO_W * 128) + (aoff[tap % 3][j] ^ (s2 * 64)));
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s2][i], fx[s2][j], acc[i][j], 0, 0, 0);
+    };
+
+    // one role per instantiation of this body (ROLE 0: single-barrier schedule; 1: early half; 2: late half), so that
+    // each gets its own straight-line schedule and register allocation; all roles execute the same barriers
+    Tile cur;
+    decode(blockIdx.x, cur);
     stage_a(cur, 0, ch_begin);
     stage_b(cur, 0, ch_begin, 0);
     stage_b(cur, 1, ch_begin, 1);
-    int gc = 0;            // chunks consumed so far by this workgroup: window of chunk gc lives in sA[gc & 1]
-    bool after_epilogue = false;
-    for (;;) {
-        for (int ci = 0; ci < nch; ++ci) {
-            const bool last_chunk = ci + 1 == nch;
-            const bool more_chunks = !last_chunk || has_next;
-            const char* a = sA + (gc & 1) * A_STAGE;
+    bool pending = false;  // late half: fragments of the previous step are in registers, MFMAs not yet issued
+    for (int ci = 0; ci < nch; ++ci) {
+        const bool last_chunk = ci + 1 == nch;
+        const char* a = sA + (ci & 1) * A_STAGE;          // window of chunk ci lives in sA[ci & 1]
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                // DMA instructions that may still be in flight while this step's operands are complete: B(step+1), and
-                // the next chunk's window during taps 1-2.  Right after an epilogue the counter also holds that tile's
-                // stores, whose order against loads is not guaranteed: drain everything once.
-                const bool more_steps = tap < 8 || more_chunks;
-                if (tap == 0 && after_epilogue) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if ((tap == 1 || tap == 2) && more_chunks) {
-                    if (nB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                } else if (more_steps) {
-                    if (nB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (!(p.dbg & 1)) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int nb = (tap + 2) % 3;
-                    if (tap + 2 < 9) stage_b(cur, nb, ch_begin + ci, tap + 2);
-                    else if (!last_chunk) stage_b(cur, nb, ch_begin + ci + 1, tap + 2 - 9);
-                    else if (has_next) stage_b(nxt, nb, ch_begin, tap + 2 - 9);
-                    if (tap == 0) {
-                        if (!last_chunk) stage_a(cur, (gc + 1) & 1, ch_begin + ci + 1);
-                        else if (has_next) stage_a(nxt, (gc + 1) & 1, ch_begin);
-                    }
-                }
-                if (!(p.dbg & 2)) {
-                    const char* b = sB + (tap % 3) * B_STAGE;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        bf16x8 fw[MT], fx[PT];
-#pragma unroll
-                        for (int i = 0; i < MT; ++i) fw[i] = *(const bf16x8*)(b + (woff[i] ^ (s2 * 64)));
-#pragma unroll
-                        for (int j = 0; j < PT; ++j)
-                            fx[j] = *(const bf16x8*)(a + (tap / 3) * (HALO_W * 128) + (aoff[tap % 3][j] ^ (s2 * 64)));
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < PT; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-                    }
-                }
+        for (int tap = 0; tap < 9; ++tap) {
+            // DMA instructions that may still be in flight while this step's operands are complete: B(step+1), and the
+            // next chunk's window during taps 1-2
+            const bool more_steps = tap < 8 || !last_chunk;
+            if ((tap == 1 || tap == 2) && !last_chunk) {
+                if (nB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            } else if (more_steps) {
+                if (nB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            after_epilogue = false;
-            ++gc;
+            __builtin_amdgcn_s_barrier();                       // X: operands of this step are in LDS
+            asm volatile("" ::: "memory");
+            auto issue = [&]() {
+                if (ROLE == 0 && (p.dbg & 1)) return;
+                const int nb = (tap + 2) % 3;
+                if (tap + 2 < 9) stage_b(cur, nb, ch_begin + ci, tap + 2);
+                else if (!last_chunk) stage_b(cur, nb, ch_begin + ci + 1, tap + 2 - 9);
+                if (tap == 0 && !last_chunk) stage_a(cur, (ci + 1) & 1, ch_begin + ci + 1);
+            };
+            if (ROLE == 0) {
+                issue();
+                if (!(p.dbg & 2)) {
+                    load_frags(a, tap);
+                    mfmas();
+                }
+            } else if (ROLE == 1) {
+                issue();
+                load_frags(a, tap);
+                __builtin_amdgcn_s_barrier();                   // Y
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                if (pending) {
+                    __builtin_amdgcn_s_setprio(1);
+                    mfmas();
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                __builtin_amdgcn_s_barrier();                   // Y
+                asm volatile("" ::: "memory");
+                issue();
+                load_frags(a, tap);
+                pending = true;
+            }
         }
-        if (!(p.dbg & 4)) epilogue(cur);
-        if (!has_next) break;
-        tile_id += G;
-        cur = nxt;
-        has_next = PERSIST && tile_id + G < nwg;
-        if (has_next) decode(tile_id + G, nxt);
-        after_epilogue = true;
     }
+    if (ROLE == 2) mfmas();             // the late half's last step: no barrier any more (the early half is done)
+    if (ROLE != 0 || !(p.dbg & 4)) epilogue(cur.bimg, cur.y0, cur.x0, cur.n0);
+}
+
+template <int BN, bool PP>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
+    if (!PP) halo_body<BN, 0>(p);
+    else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) halo_body<BN, 1>(p);   // waves 0-3
+    else halo_body<BN, 2>(p);                                                              // waves 4-7
 }
 
 template <int BN>
 static int launch_halo(const ConvParams& p, hipStream_t stream) {
+    constexpr bool PP = BN == 128;      // ping-pong halves (see halo_body); the 160-wide tile spills with them
     size_t lds = 2 * HALO_PASSES * 64 * 128 + 3 * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // one workgroup per CU (144 KB of LDS each).  More tiles than CUs and no split-K: persistent workgroups walk the
-    // tiles; otherwise one tile per workgroup (the variant without the second tile context, fewer registers).
+    // one workgroup per CU at a time (144 KB of LDS each), one tile per workgroup
     const int nwg = p.ntiles_m * p.ntiles_n;
-    if (p.ksplit == 1 && nwg > num_cus()) {
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, true>), dim3(num_cus(), 1, 1), dim3(512), lds, stream, p);
-    } else {
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BN, false>), dim3(nwg, 1, p.ksplit), dim3(512), lds, stream, p);
-    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PP>), dim3(nwg, 1, p.ksplit), dim3(512), lds, stream, p);
     if (p.ksplit > 1) launch_reduce(p, stream);
     return adap_check_launch("conv3x3_halo");
 }
@@ -1024,8 +1045,20 @@ static bool choose_halo(int Hin, int Win, int Hout, int Wout, int Cin, int Cout,
            Wout == Win && Hin % HALO_TH == 0 && Win % HALO_TW == 0 && Cout > 64 && Cin >= 64 && Cin % 64 == 0;
 }
 
-static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
+// channel tile of the stencil-window kernel: the ping-pong schedule exists for the 128-wide tile only (the 160-wide one
+// has no registers left for a second fragment set), and it is worth more than a partly empty last tile costs:
+// 128 whenever it wastes < 10 % of the channel tiles (640, 960, 1280, 1920, 2560 ...), else 160 (320)
+static int choose_bn_halo(int Cout) {
     int bn = choose_bn(Cout);
+    if (bn == 160) {
+        int t128 = (Cout + 127) / 128;
+        if (t128 * 128 * 10 <= Cout * 11) bn = 128;
+    }
+    return bn;
+}
+
+static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
+    int bn = choose_bn_halo(Cout);
     long blocks = (long)B * (H / HALO_TH) * (W / HALO_TW) * ((Cout + bn - 1) / bn);
     int nchunks = (Cin + BK - 1) / BK;
     if (blocks >= 200 || nchunks < 2) return 1;
@@ -1155,7 +1188,7 @@ extern "C" int adap_conv2d_nhwc(
     }
     hipStream_t s = (hipStream_t)stream;
 
-    const int bn = choose_bn(Cout);
+    const int bn = halo ? choose_bn_halo(Cout) : choose_bn(Cout);
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (halo) {
         g_last_variant = 4000 + bn;
