@@ -1101,6 +1101,15 @@ extern "C" long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin,
     return ks > 1 ? (long)ks * M * Cout : 0;
 }
 
+static bool narrow_tiles_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAP_NARROW_TILES");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
 // which kernel the last adap_conv2d_nhwc call of this thread dispatched to (bench.py's per-kernel roofline):
 // 1000*variant + BN, variant 0 = conv_gemm_kernel f32 activations, 1 = conv_gemm_kernel bf16, 2 = conv_gemm_ring_kernel<256,.,3>,
 // 3 = conv_gemm_ring_kernel<128,.,4>, 4 = conv3x3_halo_kernel
@@ -1188,7 +1197,18 @@ extern "C" int adap_conv2d_nhwc(
     }
     hipStream_t s = (hipStream_t)stream;
 
-    const int bn = halo ? choose_bn_halo(Cout) : choose_bn(Cout);
+    int bn = halo ? choose_bn_halo(Cout) : choose_bn(Cout);
+    bool use_big = big;
+    if (!halo && nbatch == 1 && up == 0 && p.ksplit == 1 && p.ktiles_total >= 4 && narrow_tiles_enabled()) {
+        // too few workgroups for 256 CUs and K too short for split-K to pay: trade tile size for workgroups.
+        // 256x160 -> 128x160 -> 128x64 until there are >= 200 of them (these layers are latency-, not MFMA-bound)
+        long t160 = (Cout + bn - 1) / bn, t64 = (Cout + 63) / 64;
+        if (use_big && ((M + BMB - 1) / BMB) * t160 < 200) {
+            use_big = false;
+            p.ntiles_m = (int)((M + BM - 1) / BM);
+        }
+        if (!use_big && ((M + BM - 1) / BM) * t160 < 200 && ((M + BM - 1) / BM) * t64 > ((M + BM - 1) / BM) * t160) bn = 64;
+    }
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (halo) {
         g_last_variant = 4000 + bn;
@@ -1196,7 +1216,7 @@ extern "C" int adap_conv2d_nhwc(
         if (bn == 160) return launch_halo<160>(p, s);
         return launch_halo<128>(p, s);
     }
-    if (big) {
+    if (use_big) {
         g_last_variant = 2000 + bn;
         if (bn == 160) return launch_ring<256, 160, 3>(p, s);
         return launch_ring<256, 128, 3>(p, s);
