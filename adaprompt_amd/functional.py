@@ -41,6 +41,39 @@ class WeightCache:
         self._packs.clear()
 
 
+# ---------------------------------------------------------------------------------------------
+# bf16 side copies of residual-stream gradients.  Autograd hands ONE tensor (f32, the reference's precision for the
+# residual stream) from a block's backward to the previous block's; the first thing that block does with it is a
+# data-gradient contraction, whose matrix-core operand is bf16 anyway.  The kernel that produces the f32 gradient
+# (GroupNorm backward with accumulation, conv epilogue) writes the bf16 operand copy in the same pass, and the copy
+# travels beside autograd in this table, keyed by the f32 tensor's address.  The entry keeps the f32 tensor alive (so
+# its address cannot be reused, and autograd's input buffer cannot add into it in place: use_count > 1) and records
+# its version; a gradient that was summed with another one by autograd is a new tensor and simply misses here.
+# ---------------------------------------------------------------------------------------------
+_GRAD16 = {}
+STATS = [0, 0]          # hits, misses of the table (diagnostics)
+
+
+def _stash16(g32, g16):
+    if g16 is not None:
+        _GRAD16[g32.data_ptr()] = (g32, g32._version, g16)
+    return g32
+
+
+def _operand(g):
+    """the bf16 copy of gradient ``g`` if its producer left one (same storage, unmodified), else ``g`` itself."""
+    e = _GRAD16.pop(g.data_ptr(), None)
+    if e is not None and e[0].numel() == g.numel() and e[0]._version == e[1] == g._version:
+        STATS[0] += 1
+        return e[2].view(g.shape)
+    STATS[1] += 1
+    return g
+
+
+def clear_grad_copies():
+    _GRAD16.clear()
+
+
 def _conv_bwd_data(g, pk, K, pad, bf16=False):
     """dX of a stride-1 conv: the same implicit GEMM with the flipped/transposed pack.  ``bf16``: the result only
     feeds a GroupNorm backward, so it is written as bf16 (half the traffic of both kernels)."""
@@ -84,15 +117,16 @@ class ResBlockFn(torch.autograd.Function):
         g1w, g1b = P["gn1"]
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
-        ga2 = _conv_bwd_data(g, c2, 3, 1, bf16=True)
+        gop = _operand(g)
+        ga2 = _conv_bwd_data(gop, c2, 3, 1, bf16=True)
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
         ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
         if sk is None:
             gx = g.clone(memory_format=torch.contiguous_format)
         else:
-            gx, _ = ops.conv2d(g, sk.bwd, sk.bwd.shape[1], 1)
-        ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, accumulate_into=gx)
-        return gx, None, None
+            gx, _ = ops.conv2d(gop, sk.bwd, sk.bwd.shape[1], 1)
+        _, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, accumulate_into=gx)
+        return _stash16(gx, gx16), None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -160,10 +194,12 @@ class SpatialTransformerFn(torch.autograd.Function):
         P, heads = ctx.P, ctx.heads
         B, H, W, C = x.shape
         N = H * W
+        gop = _operand(g)
         g = g.reshape(B, N, C) if g.is_contiguous() else g.contiguous().view(B, N, C)
+        gop = gop.reshape(B, N, C) if (gop.dtype == BF16 and gop.is_contiguous()) else g
         # every f32 residual-stream gradient also gets a bf16 copy from the kernel that produces it, so the next
         # data-gradient contraction reads bf16 (LDS-DMA path) instead of converting f32 on the fly
-        gt3, gt3h = _lin_bwd(g, P["proj_out"], out_f32=True, out_bf16=True)       # [B,N,C]
+        gt3, gt3h = _lin_bwd(gop, P["proj_out"], out_f32=True, out_bf16=True)     # [B,N,C]
         # feed-forward
         _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)           # bf16 [B,N,4C]
         ghh = ops.geglu_bwd(ggg, hh)                                               # bf16 [B,N,8C]
@@ -198,8 +234,8 @@ class SpatialTransformerFn(torch.autograd.Function):
         _, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=False, out_bf16=True)
         gx = g.clone(memory_format=torch.contiguous_format).view(B, H, W, C)
         gnw, gnb = P["norm"]
-        ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, accumulate_into=gx)
-        return gx, g_ck, g_cv, None, None, None, None
+        _, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True, accumulate_into=gx)
+        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -223,12 +259,15 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         pk, mode = ctx.pk, ctx.mode
+        if mode == "same":
+            g = _operand(g)
         if mode == "down":
             gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], 3, 1, 1, up=2, out_hw=ctx.in_hw)
         elif mode == "up":
             gx = ops.sumpool2x2(_conv_bwd_data(g, pk, 3, 1))
         else:
-            gx = _conv_bwd_data(g, pk, 3, 1)
+            gx, gx16 = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], 3, 1, 1, out_f32=True, out_bf16=True)
+            _stash16(gx, gx16)
         return gx, None, None
 
 

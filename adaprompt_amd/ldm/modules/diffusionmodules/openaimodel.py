@@ -291,6 +291,7 @@ class UNetModel(nn.Module):
 
     def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
         assert y is None, "the SD-1.5 UNet is not class-conditional"
+        HF.clear_grad_copies()          # bf16 gradient side copies of a finished backward (functional._GRAD16)
         ei = extra_info if extra_info is not None else {}
         use_layerwise_context = ei.get("use_layerwise_context", False)
         iter_type = ei.get("iter_type", "normal_recon")
