@@ -457,8 +457,11 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform; t
 // BMT = 256 (8 waves, NST = 3: the large-problem variant above) or 128 (4 waves, NST = 4: problems with fewer
 // workgroups than CUs, where occupancy is moot and the latency of one workgroup's K loop is everything -- three K
 // steps of DMA in flight instead of one).
-template <int BMT, int BN, int NST>
-__global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
+// ROLE: 0 = one barrier per K step; 1 / 2 = the early / late half of the ping-pong schedule (BMT = 256 only; see
+// halo_body: waves w and w+4 share a SIMD and run half a step apart, so one of them is always in its MFMA phase).
+// ONE_TAP: 1x1 / Linear (no tap decode, no validity masks in the staging path).
+template <int BMT, int BN, int NST, int ROLE, bool ONE_TAP>
+__device__ __forceinline__ void ring_body(const ConvParams& p) {
     constexpr int WN = BN / 2;
     constexpr int MT = WN / 16;
     constexpr int PT = 4;
@@ -541,12 +544,31 @@ __global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
         b_base[i] = (unsigned)((n * p.Cin + lchunk * 8) * 2);
     }
     auto stage = [&](int buf, int kt) {
+        char* abase = sA + buf * A_STAGE + wv * 1024;
+        char* bbase = sB + buf * B_STAGE + wv * 1024;
+        if (ONE_TAP) {
+            const int c0 = kt * BK;
+            unsigned kill = (c0 + lchunk * 8 < p.Cin) ? 0u : OOB;
+            asm volatile("" : "+v"(kill));
+            const unsigned off = (unsigned)(c0 * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned voff = (a_base[i] + off) | ((a_mask[i] & 1u) ? 0u : OOB) | kill;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(abase + i * (RP * 128)), 16, voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                if (RP * i + 8 * wv < BN) {               // wave-uniform
+                    unsigned voff = (b_base[i] + off) | b_kill[i] | kill;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(bbase + i * (RP * 128)), 16, voff, 0, 0, 0);
+                }
+            }
+            return;
+        }
         int tap = kt / p.ktiles_per_tap;
         int c0 = (kt - tap * p.ktiles_per_tap) * BK;
         int ky = tap / p.KW, kx = tap - ky * p.KW;
         bool cok = c0 + lchunk * 8 < p.Cin;
-        char* abase = sA + buf * A_STAGE + wv * 1024;
-        char* bbase = sB + buf * B_STAGE + wv * 1024;
         {
             // branch-free (see conv_gemm_kernel): the counted vmcnt below relies on every wave issuing exactly
             // 4 + nB DMA instructions per stage
@@ -578,29 +600,38 @@ __global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
 
-    auto compute = [&](int buf) {
+    // fragment byte offsets, computed once (the K half s = 1 is the same chunk position XOR 4 -> offset XOR 64)
+    int woff[MT], xoff[PT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int r = wn * WN + i * 16 + frow;
+        woff[i] = r * 128 + ((fchunk ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        int r = wm * 64 + j * 16 + frow;
+        xoff[j] = r * 128 + ((fchunk ^ (r & 7)) << 4);
+    }
+    bf16x8 fw[2][MT], fx[2][PT];
+    auto load_frags = [&](int buf) {
         const char* a = sA + buf * A_STAGE;
         const char* b = sB + buf * B_STAGE;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 fw[MT], fx[PT];
-            const int cc = 4 * s + fchunk;
+        for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                int r = wn * WN + i * 16 + frow;
-                fw[i] = *(const bf16x8*)(b + r * 128 + ((cc ^ (r & 7)) << 4));
-            }
+            for (int i = 0; i < MT; ++i) fw[s2][i] = *(const bf16x8*)(b + (woff[i] ^ (s2 * 64)));
 #pragma unroll
-            for (int j = 0; j < PT; ++j) {
-                int r = wm * 64 + j * 16 + frow;
-                fx[j] = *(const bf16x8*)(a + r * 128 + ((cc ^ (r & 7)) << 4));
-            }
+            for (int j = 0; j < PT; ++j) fx[s2][j] = *(const bf16x8*)(a + (xoff[j] ^ (s2 * 64)));
+        }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < PT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[s2][i], fx[s2][j], acc[i][j], 0, 0, 0);
     };
 
     const int ntl = kt_end - kt_begin;
@@ -609,21 +640,48 @@ __global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
     for (int i = 0; i < NST - 1; ++i)
         if (i < ntl) stage(i, kt_begin + i);
     int buf = 0;
+    bool pending = false;
     for (int t = 0; t < ntl; ++t) {
         // tile t has landed once only the stages issued after it (tiles t+1 .. t+NST-2) can still be in flight
         int ahead = ntl - 1 - t;
         if (ahead > NST - 2) ahead = NST - 2;
         wait_vmcnt(ahead * L);
-        __builtin_amdgcn_s_barrier();          // tile t visible to every wave; every wave is done with tile t-1
+        __builtin_amdgcn_s_barrier();          // X: tile t visible to every wave; every wave has read tile t-1
         asm volatile("" ::: "memory");
-        if (t + NST - 1 < ntl) {
-            int nb = buf + NST - 1;
-            if (nb >= NST) nb -= NST;
-            stage(nb, kt_begin + t + NST - 1); // refills the buffer tile t-1 was multiplied from
+        auto issue = [&]() {
+            if (t + NST - 1 < ntl) {
+                int nb = buf + NST - 1;
+                if (nb >= NST) nb -= NST;
+                stage(nb, kt_begin + t + NST - 1); // refills the buffer tile t-1 was multiplied from
+            }
+        };
+        if (ROLE == 0) {
+            issue();
+            load_frags(buf);
+            mfmas();
+        } else if (ROLE == 1) {
+            issue();
+            load_frags(buf);
+            __builtin_amdgcn_s_barrier();      // Y
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_setprio(1);
+            mfmas();
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            if (pending) {
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_s_barrier();      // Y
+            asm volatile("" ::: "memory");
+            issue();
+            load_frags(buf);
+            pending = true;
         }
-        compute(buf);
         if (++buf == NST) buf = 0;
     }
+    if (ROLE == 2 && pending) mfmas();         // the late half's last step (no barrier: the early half is done)
 
     float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
 #pragma unroll
@@ -665,6 +723,16 @@ __global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
     }
 }
 
+template <int BMT, int BN, int NST, bool ONE_TAP>
+__global__ __launch_bounds__(BMT * 2) void conv_gemm_ring_kernel(ConvParams p) {
+    // ping-pong halves measured on the 256-row variant: no gain (these GEMMs are bound by the L2 -> LDS operand feed,
+    // ~7.8 TB/s aggregate at 52 KB per K step per CU, not by the per-step schedule), so the plain schedule is used
+    constexpr bool PP = false;
+    if (!PP) ring_body<BMT, BN, NST, 0, ONE_TAP>(p);
+    else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) ring_body<BMT, BN, NST, 1, ONE_TAP>(p);   // waves 0-3
+    else ring_body<BMT, BN, NST, 2, ONE_TAP>(p);                                                              // waves 4-7
+}
+
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -684,19 +752,25 @@ static void launch_reduce(const ConvParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, M, p.Hout * p.Wout);
 }
 
-template <int BMT, int BN, int NST>
-static int launch_ring(const ConvParams& p, hipStream_t stream) {
+template <int BMT, int BN, int NST, bool ONE_TAP>
+static int launch_ring_t(const ConvParams& p, hipStream_t stream) {
     size_t lds = (size_t)NST * (BMT + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<BMT, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+        hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<BMT, BN, NST, ONE_TAP>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(p.ntiles_m * p.ntiles_n, 1, p.ksplit);
-    hipLaunchKernelGGL((conv_gemm_ring_kernel<BMT, BN, NST>), grid, dim3(BMT * 2), lds, stream, p);
+    hipLaunchKernelGGL((conv_gemm_ring_kernel<BMT, BN, NST, ONE_TAP>), grid, dim3(BMT * 2), lds, stream, p);
     if (p.ksplit > 1) launch_reduce(p, stream);
     return adap_check_launch("conv_gemm_ring");
+}
+
+template <int BMT, int BN, int NST>
+static int launch_ring(const ConvParams& p, hipStream_t stream) {
+    if (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.up == 0) return launch_ring_t<BMT, BN, NST, true>(p, stream);
+    return launch_ring_t<BMT, BN, NST, false>(p, stream);
 }
 
 // =============================================================================================
