@@ -153,6 +153,12 @@ class LatentDiffusion(DDPM):
             return self.scale_factor * encoder_posterior
         raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
 
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        """z NCHW latent -> image NCHW in [-1, 1] (ddpm.py:1260-1267 and the un-tiled tail)."""
+        assert not predict_cids
+        return self.first_stage_model.decode(z * (1.0 / self.scale_factor))
+
     def sample_latent_nhwc(self, moments, noise=None):
         """pixel-major fast path of the same: moments [B,h,w,2z] -> scale_factor * sample, [B,h,w,z]."""
         if noise is None:

@@ -1,6 +1,6 @@
-"""VAE ``Encoder`` of the first stage on the MI355X kernels (reference
-ldm/modules/diffusionmodules/model.py:408-499 with ResnetBlock :83-142, Downsample :61-80,
-AttnBlock :151-242, Normalize :39-40).  Parameter names follow the reference
+"""VAE ``Encoder`` (reference ldm/modules/diffusionmodules/model.py:408-499) and ``Decoder`` (:502-608) of the
+first stage on the MI355X kernels, with ResnetBlock :83-142, Downsample :61-80, Upsample :42-58,
+AttnBlock :151-242, Normalize :39-40.  Parameter names follow the reference
 (``first_stage_model.encoder.*`` checkpoints load by key).  Forward only: the first stage is
 frozen and runs under no_grad on the training path (ddpm.py:1381-1419).
 
@@ -182,3 +182,95 @@ class Encoder(nn.Module):
         """reference signature: x NCHW -> NCHW (a view of the pixel-major result)."""
         with torch.no_grad():
             return self.forward_nhwc(x.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)
+
+
+class Upsample(nn.Module):
+    """nearest x2 then conv3x3 (model.py:42-58): the upsample is folded into the conv's gather (``up=1``)."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        assert with_conv
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self._wc = HF.WeightCache()
+
+    def forward(self, x):
+        pk = self._wc.get("conv", self.conv.weight, self.conv.bias)
+        y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias)
+        return y
+
+
+class Decoder(nn.Module):
+    """model.py:502-608.  SD-1.5: z [B,4,64,64] -> conv_in 4->512, mid (res, attn, res), four levels of three
+    ResnetBlocks (512,512,256,128) with nearest-x2 + conv between them, GroupNorm + swish + conv_out 128->3.
+    Inference only (``decode_first_stage`` runs under no_grad in the sampler scripts)."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
+                 use_linear_attn=False, attn_type="vanilla", **ignorekwargs):
+        super().__init__()
+        assert not use_linear_attn and len(list(attn_resolutions)) == 0, "SD-1.5 VAE: attention only in mid"
+        self.ch = ch
+        self.temb_ch = 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution = resolution
+        self.in_channels = in_channels
+        self.give_pre_end = give_pre_end
+        self.tanh_out = tanh_out
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = nn.Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+            up = nn.Module()
+            up.block = block
+            up.attn = nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res = curr_res * 2
+            self.up.insert(0, up)          # prepend to get consistent order
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self._wc = HF.WeightCache()
+
+    def forward_nhwc(self, z_hwc):
+        """z pixel-major [B,h,w,z_channels] f32 -> image pixel-major [B,8h,8w,out_ch] f32."""
+        if not z_hwc.is_cuda:
+            raise RuntimeError("adaprompt_amd Decoder runs on the MI355X HIP kernels only; got a CPU tensor")
+        wc = self._wc
+        cin = wc.get("conv_in", self.conv_in.weight, self.conv_in.bias)
+        z16 = ops.pad_cast_bf16(z_hwc.contiguous().float(), cin.I8)
+        h, _ = ops.conv2d(z16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias)
+        h = self.mid.block_1(h)
+        h = self.mid.attn_1(h)
+        h = self.mid.block_2(h)
+        for i_level in reversed(range(self.num_resolutions)):
+            for blk in self.up[i_level].block:
+                h = blk(h)
+            if i_level != 0:
+                h = self.up[i_level].upsample(h)
+        if self.give_pre_end:
+            return h
+        _, a, _, _ = ops.groupnorm_fwd(h, self.norm_out.weight, self.norm_out.bias, 1e-6, 1)
+        co = wc.get("conv_out", self.conv_out.weight, self.conv_out.bias)
+        y, _ = ops.conv2d(a, co.fwd, co.O4, 3, 1, 1, bias=co.bias)
+        y = y[..., :self.conv_out.out_channels]
+        if self.tanh_out:
+            y = torch.tanh(y)
+        return y
+
+    def forward(self, z):
+        """reference signature: z NCHW -> image NCHW (a view of the pixel-major result)."""
+        with torch.no_grad():
+            return self.forward_nhwc(z.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

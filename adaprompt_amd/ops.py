@@ -376,13 +376,16 @@ def geglu_bwd(dout, h):
 
 
 def linear_small(x, w, bias=None, pre_silu=False, post_silu=False):
-    """exact f32, x [R<=8, K] -> [R, N]"""
+    """exact f32, x [R, K] -> [R, N]; the kernel keeps up to 8 rows in registers per pass over the weights, larger
+    batches (the sampler's 16) go through in slices of 8"""
     R, K = x.shape
     N = w.shape[0]
     assert x.dtype == F32 and w.dtype == F32 and w.is_contiguous() and x.stride(1) == 1
     y = torch.empty(R, N, device=x.device, dtype=F32)
-    _lib.call("adap_linear_small", x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), N, R, K, N,
-              int(pre_silu), int(post_silu), _stream())
+    for r0 in range(0, R, 8):
+        r = min(8, R - r0)
+        _lib.call("adap_linear_small", x[r0:].data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y[r0:].data_ptr(), N, r, K,
+                  N, int(pre_silu), int(post_silu), _stream())
     return y
 
 

@@ -188,6 +188,48 @@ def vae_encoder_param_shapes(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_
     return out
 
 
+def vae_decoder_param_shapes(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, embed_dim=4,
+                             **_unused):
+    """(name, shape) for ``AutoencoderKL.decoder`` + ``post_quant_conv`` (model.py:502-573; autoencoder.py:304)."""
+    out = []
+
+    def conv(p, i, o, k):
+        out.append((p + ".weight", (o, i, k, k)))
+        out.append((p + ".bias", (o,)))
+
+    def norm(p, c):
+        out.append((p + ".weight", (c,)))
+        out.append((p + ".bias", (c,)))
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci)
+        conv(p + ".conv1", ci, co, 3)
+        norm(p + ".norm2", co)
+        conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".nin_shortcut", ci, co, 1)
+
+    nres = len(ch_mult)
+    bi = ch * ch_mult[nres - 1]
+    conv("decoder.conv_in", z_channels, bi, 3)
+    res("decoder.mid.block_1", bi, bi)
+    norm("decoder.mid.attn_1.norm", bi)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(f"decoder.mid.attn_1.{n}", bi, bi, 1)
+    res("decoder.mid.block_2", bi, bi)
+    for lvl in reversed(range(nres)):
+        bo = ch * ch_mult[lvl]
+        for b in range(num_res_blocks + 1):
+            res(f"decoder.up.{lvl}.block.{b}", bi, bo)
+            bi = bo
+        if lvl != 0:
+            conv(f"decoder.up.{lvl}.upsample.conv", bi, bi, 3)
+    norm("decoder.norm_out", bi)
+    conv("decoder.conv_out", bi, out_ch, 3)
+    conv("post_quant_conv", embed_dim, z_channels, 1)
+    return out
+
+
 SD15_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320,
                  attention_resolutions=(4, 2, 1), num_res_blocks=2, channel_mult=(1, 2, 4, 4),
                  num_heads=8, use_spatial_transformer=True, transformer_depth=1,
@@ -202,6 +244,9 @@ def synthetic_unet_state_dict(cfg=None, seed=0, prefix="model.diffusion_model.")
     return synthetic_like(unet_param_shapes(**cfg), seed, prefix)
 
 
-def synthetic_vae_state_dict(ddconfig=None, embed_dim=4, seed=0, prefix="first_stage_model."):
+def synthetic_vae_state_dict(ddconfig=None, embed_dim=4, seed=0, prefix="first_stage_model.", decoder=False):
     dd = dict(SD15_VAE_DD if ddconfig is None else ddconfig)
-    return synthetic_like(vae_encoder_param_shapes(embed_dim=embed_dim, **dd), seed, prefix)
+    shapes = vae_encoder_param_shapes(embed_dim=embed_dim, **dd)
+    if decoder:
+        shapes = shapes + vae_decoder_param_shapes(embed_dim=embed_dim, **dd)
+    return synthetic_like(shapes, seed, prefix)

@@ -137,6 +137,8 @@ def main():
                     help="replay the micro-batch as two hipGraphs (fwd, bwd) instead of launching eagerly; measured "
                          "45.1 vs 44.3 ms/step on MI355X -- the step is GPU-bound, not launch-bound, so eager is the default")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-ddim", action="store_true",
+                    help="skip the extra leg that times config 5 (50-step DDIM at bs=8 with guidance + VAE decode)")
     ap.add_argument("--no-distill-mix", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
     args = ap.parse_args()
@@ -381,6 +383,42 @@ def main():
         ld.set_arc2face_teacher(None)
         del teacher
 
+    # ---- extra leg: config 5 -- 50 DDIM steps at bs=8 (UNet batch 16 under classifier-free guidance,
+    # context [256,77,768]) and the VAE decode of the 8 latents
+    ddim = None
+    if world == 1 and not args.no_ddim:
+        from adaprompt_amd import synth
+        from adaprompt_amd.ldm.models.diffusion.ddim import DDIMSampler
+        dec = ld.first_stage_model.build_decoder()
+        dsd = device_state_dict(synth.vae_decoder_param_shapes(**synth.SD15_VAE_DD), "", device, 9)
+        ld.first_stage_model.load_state_dict(dsd, strict=False)
+        del dsd
+        nb, S = 8, 50
+        ex = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+              "is_training": False, "capture_distill_attn": False, "img_mask": None}
+        c = (torch.randn(16 * nb, 77, 768, device=device, generator=gen) * 0.05, ["a photo of z"] * nb, dict(ex))
+        uc = (torch.randn(16 * nb, 77, 768, device=device, generator=gen) * 0.05, [""] * nb, dict(ex))
+        sampler = DDIMSampler(ld)
+
+        def gen_images(steps):
+            xT = torch.randn(nb, 4, 64, 64, device=device, generator=gen)
+            with torch.no_grad():
+                z, _ = sampler.sample(S=steps, batch_size=nb, shape=[4, 64, 64], conditioning=c, verbose=False,
+                                      guidance_scale=[10, 4], unconditional_conditioning=uc, eta=0.0, x_T=xT)
+                return ld.decode_first_stage(z)
+
+        gen_images(2)                     # warm-up: weight packs of the decoder, batch-16 workspaces
+        sync()
+        t1 = time.perf_counter()
+        img = gen_images(S)
+        sync()
+        dd_ = time.perf_counter() - t1
+        ddim = {"workload": "config 5: 50-step DDIM (eta 0, guidance annealed 10 -> 4, UNet batch 16 = 8 cond + 8 uncond, "
+                            "context [256,77,768]) + VAE decode of 8 latents to 512x512",
+                "images": nb, "steps": S, "seconds": round(dd_, 3), "sec_per_image": round(dd_ / nb, 4),
+                "images_per_sec": round(nb / dd_, 3), "finite": bool(torch.isfinite(img).all())}
+        del dec, sampler, c, uc, img
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
@@ -412,6 +450,8 @@ def main():
             res["cpu_baseline"] = cpu
         if distill is not None:
             res["config2_distill_mix"] = distill
+        if ddim is not None:
+            res["config5_ddim"] = ddim
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -328,6 +328,39 @@ def autoencoder_encode_moments(sd, dd, x, mask=None, prefix="first_stage_model."
     return _conv(sd, prefix + "quant_conv", h)
 
 
+def vae_upsample(sd, p, x):
+    """Upsample.forward, model.py:52-58: nearest x2 then conv3x3 pad 1."""
+    x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    return _conv(sd, p + ".conv", x, padding=1)
+
+
+def vae_decoder_forward(sd, dd, z, prefix="first_stage_model.decoder."):
+    """Decoder.forward, model.py:575-608 (attn_resolutions=[] -> attention only in mid, give_pre_end/tanh off)."""
+    P = prefix
+    mult = tuple(dd["ch_mult"])
+    h = _conv(sd, P + "conv_in", z, padding=1)
+    h = vae_resnet_block(sd, P + "mid.block_1", h)
+    h = vae_attn_block(sd, P + "mid.attn_1", h)
+    h = vae_resnet_block(sd, P + "mid.block_2", h)
+    for lvl in reversed(range(len(mult))):
+        for b in range(dd["num_res_blocks"] + 1):
+            h = vae_resnet_block(sd, f"{P}up.{lvl}.block.{b}", h)
+        if lvl != 0:
+            h = vae_upsample(sd, f"{P}up.{lvl}.upsample", h)
+    h = silu(group_norm32(h, sd[P + "norm_out.weight"], sd[P + "norm_out.bias"], 1e-6))
+    return _conv(sd, P + "conv_out", h, padding=1)
+
+
+def autoencoder_decode(sd, dd, z, prefix="first_stage_model."):
+    """AutoencoderKL.decode, autoencoder.py:330-333: post_quant_conv then the decoder."""
+    return vae_decoder_forward(sd, dd, _conv(sd, prefix + "post_quant_conv", z), prefix + "decoder.")
+
+
+def decode_first_stage(sd, dd, z, scale_factor=0.18215, prefix="first_stage_model."):
+    """LatentDiffusion.decode_first_stage, ddpm.py:1260-1267 (+ the un-tiled tail): z / scale_factor, decode."""
+    return autoencoder_decode(sd, dd, z / scale_factor, prefix)
+
+
 def gaussian_sample(moments, noise):
     """DiagonalGaussianDistribution, distributions.py:24-37, with the noise supplied:
     chunk(2,1); clamp(logvar,-30,20); mean + exp(0.5*logvar)*noise."""

@@ -191,6 +191,35 @@ def run_anneal():
          anneal_values=np.array(av, dtype=np.float64), anneal_array=np.array(aa, dtype=np.float64))
 
 
+def run_decoder_and_ddim(model, util, full):
+    """VAE Decoder + post_quant_conv (model.py:502-608, autoencoder.py:330-333) and the DDIM schedule helpers
+    (util.py:46-77)."""
+    def run_dec(dd, B, res, tag, sub):
+        dec = model.Decoder(**dd)
+        fill(dec, "first_stage_model.decoder.", 0)
+        pqc = torch.nn.Conv2d(4, dd["z_channels"], 1)
+        fill(pqc, "first_stage_model.post_quant_conv.", 0)
+        z = synth.synthetic_input(f"dec.{tag}.z", (B, 4, res // 8, res // 8), 0, 1.0)
+        img = dec(pqc(z))
+        save(f"vae_decode_{tag}", B=B, res=res, sub=sub, image=img[:, :, ::sub, ::sub])
+
+    run_dec(dict(synth.SD15_VAE_DD, ch=32, resolution=64), 2, 64, "narrow", 1)
+    if full:
+        run_dec(dict(synth.SD15_VAE_DD), 1, 512, "sd15", 4)
+    betas = util.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = torch.tensor(np.cumprod(1.0 - betas, axis=0))
+    out = {}
+    for S, eta, method in ((50, 0.0, "uniform"), (20, 0.5, "uniform"), (10, 0.0, "quad")):
+        ts = util.make_ddim_timesteps(method, S, 1000, verbose=False)
+        sig, al, alp = util.make_ddim_sampling_parameters(ac, ts, eta, verbose=False)
+        tag = f"S{S}_{method}"
+        out[tag + "_ts"] = np.asarray(ts)
+        out[tag + "_sigmas"] = np.asarray(sig, dtype=np.float64)
+        out[tag + "_alphas"] = np.asarray(al, dtype=np.float64)
+        out[tag + "_alphas_prev"] = np.asarray(alp, dtype=np.float64)
+    save("ddim_params", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -368,6 +397,7 @@ def main():
     # ---------------- optimiser: Prodigy.step + grad-norm clip + LR schedule (ldm/prodigy.py, ldm/util.py:26-41) ------
     run_prodigy()
     run_anneal()
+    run_decoder_and_ddim(model, util, args.full)
 
     if args.full:
         run_unet(dict(synth.SD15_UNET), 1, 77, "sd15_recon", with_grad=True, subsample=True)
