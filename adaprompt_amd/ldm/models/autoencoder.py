@@ -64,6 +64,8 @@ class AutoencoderKL(nn.Module):
         """z pixel-major [B,h,w,embed_dim] -> image pixel-major [B,8h,8w,3]."""
         if self.decoder is None:
             raise RuntimeError("AutoencoderKL was built without its decoder: pass with_decoder=True or call build_decoder()")
+        if not z_hwc.is_cuda:
+            raise RuntimeError("adaprompt_amd AutoencoderKL.decode runs on the MI355X HIP kernels only; got a CPU tensor")
         B, H, W, C = z_hwc.shape
         # the kernels address one operand through a 32-bit buffer descriptor (< 2 GiB): the widest decoder
         # activation is [b, 8H, 8W, 2*ch] f32, so large batches are decoded in slices

@@ -120,7 +120,7 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="without its decoder"):      # training replica: no decoder weights carried
         v.decode(torch.zeros(1, 4, 8, 8))
     v2 = AutoencoderKL(dict(synth.SD15_VAE_DD, ch=32, resolution=64), None, 4, with_decoder=True)
-    with pytest.raises(RuntimeError):                                    # CPU tensor: no fallback on the decode path
+    with pytest.raises(RuntimeError, match="HIP kernels only"):          # CPU tensor: no fallback on the decode path
         v2.decode(torch.zeros(1, 4, 8, 8))
 
 
