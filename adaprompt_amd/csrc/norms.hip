@@ -388,7 +388,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
                                                            const float* __restrict__ rstd, int act,
                                                            const float* __restrict__ partial, int stats_chunks,
                                                            int rows_per_chunk, float* __restrict__ dx32, long lddx32,
-                                                           int accumulate, uint16_t* __restrict__ dx16, long lddx16) {
+                                                           int accumulate, uint16_t* __restrict__ dx16, long lddx16,
+                                                           const float* __restrict__ add_src, long ldadd) {
     __shared__ float lA[GN_G], lB[GN_G];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
                 if (rr < row_end && k < g.nslots && q < g.Q) {
                     gn_load8<XB>(x, (boff + rr) * ldx + 8 * q, xv[u][k]);
                     gn_load8<DYB>(dy, (boff + rr) * lddy + 8 * q, d[u][k]);
-                    if (dx32 && accumulate) gn_load8<false>(dx32, (boff + rr) * lddx32 + 8 * q, ac[u][k]);
+                    if (dx32 && accumulate) gn_load8<false>(add_src, (boff + rr) * ldadd + 8 * q, ac[u][k]);
                 }
             }
         }
@@ -470,16 +471,18 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const void* __restric
 template <bool XB, bool DYB>
 static void gn_bwd_launch(const void* dy, long lddy, const void* x, long ldx, const float* gamma, const float* beta,
                           const float* mean, const float* rstd, float* dx32, long lddx32, int accumulate, void* dx16,
-                          long lddx16, float* workspace, int B, int HW, int C, int act, int n, int rpc, hipStream_t s) {
+                          long lddx16, const float* add_src, long ldadd, float* workspace, int B, int HW, int C, int act, int n,
+                          int rpc, hipStream_t s) {
     hipLaunchKernelGGL((gn_bwd_stats_kernel<XB, DYB>), dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
                        rstd, act, rpc, workspace);
     hipLaunchKernelGGL((gn_bwd_apply_kernel<XB, DYB>), dim3(n, B), dim3(256), 0, s, dy, lddy, x, ldx, HW, C, gamma, beta, mean,
-                       rstd, act, workspace, n, rpc, dx32, lddx32, accumulate, (uint16_t*)dx16, lddx16);
+                       rstd, act, workspace, n, rpc, dx32, lddx32, accumulate, (uint16_t*)dx16, lddx16, add_src, ldadd);
 }
 
 extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
+                                  const float* add_src, long ldadd,
                                   float* workspace, int B, int HW, int C, int act, void* stream) {
     ADAP_REQUIRE(dy && x && gamma && beta && mean && rstd && workspace && (dx32 || dx16), ADAP_ERR_SHAPE, "groupnorm_bwd: null pointer");
     ADAP_REQUIRE(C % GN_G == 0 && C % 8 == 0 && C <= 256 * 8 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_bwd: C=%d", C);
@@ -488,10 +491,17 @@ extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const
                  "groupnorm_bwd: x / dy alignment");
     ADAP_REQUIRE(!dx32 || (lddx32 % 4 == 0 && ((uintptr_t)dx32 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_bwd: dx32 alignment");
     ADAP_REQUIRE(!dx16 || (lddx16 % 8 == 0 && ((uintptr_t)dx16 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_bwd: dx16 alignment");
+    if (accumulate && !add_src) {           // in-place accumulation: the addend is dx32 itself
+        add_src = dx32;
+        ldadd = lddx32;
+    }
+    ADAP_REQUIRE(!accumulate || (dx32 && add_src && ldadd % 4 == 0 && ((uintptr_t)add_src % 16) == 0), ADAP_ERR_ALIGN,
+                 "groupnorm_bwd: accumulate needs dx32 and a 16-byte aligned addend");
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
     hipStream_t s = (hipStream_t)stream;
 #define GN_BWD(XB, DYB) gn_bwd_launch<XB, DYB>(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx32, lddx32, accumulate, dx16, lddx16, \
+                                               add_src, ldadd, \
                                               workspace, B, HW, C, act, n, rpc, s)
     if (x_dtype == 1 && dy_dtype == 1) GN_BWD(true, true);
     else if (x_dtype == 1) GN_BWD(true, false);

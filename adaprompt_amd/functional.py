@@ -121,11 +121,12 @@ class ResBlockFn(torch.autograd.Function):
         ga2 = _conv_bwd_data(gop, c2, 3, 1, bf16=True)
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
         ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
-        if sk is None:
-            gx = g.clone(memory_format=torch.contiguous_format)
+        if sk is None:          # identity skip: dx + g straight into a new tensor (no clone of g)
+            gx, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True,
+                                         add_from=g if g.is_contiguous() else g.contiguous())
         else:
             gx, _ = ops.conv2d(gop, sk.bwd, sk.bwd.shape[1], 1)
-        _, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, accumulate_into=gx)
+            _, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, accumulate_into=gx)
         return _stash16(gx, gx16), None, None
 
 
@@ -232,9 +233,9 @@ class SpatialTransformerFn(torch.autograd.Function):
         gt0, gt0h = ops.layernorm_bwd(gn1, t0, P["norm1"][0], l1m, l1r, accumulate_into=gt1, want_bf16=True)
         # proj_in, GroupNorm
         _, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=False, out_bf16=True)
-        gx = g.clone(memory_format=torch.contiguous_format).view(B, H, W, C)
         gnw, gnb = P["norm"]
-        _, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True, accumulate_into=gx)
+        gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
+                                     add_from=g.view(B, H, W, C))          # x_in + proj_out(...): dx + g, no clone of g
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None
 
 

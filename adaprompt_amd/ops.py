@@ -245,7 +245,9 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     return y32, y16, mean, rstd
 
 
-def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=False, accumulate_into=None):
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=False, accumulate_into=None, add_from=None):
+    """``accumulate_into``: dx is added into that f32 tensor in place.  ``add_from``: dx + add_from goes to a NEW f32
+    tensor (the addend, e.g. a block's incoming gradient, is left untouched -- no clone needed)."""
     B, C = x.shape[0], x.shape[-1]
     rows, ldx = _rows_ld(x)
     _, lddy = _rows_ld(dy)
@@ -253,15 +255,20 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=Fa
     ws = torch.empty(_lib.size_query("adap_groupnorm_workspace_floats", B, HW, C), device=x.device, dtype=F32)
     acc = 0
     dx32 = None
+    add_ptr, ldadd = 0, 0
     if accumulate_into is not None:
         dx32, acc = accumulate_into, 1
+    elif add_from is not None:
+        assert add_from.dtype == F32 and add_from.numel() == x.numel()
+        dx32, acc = torch.empty(x.shape, device=x.device, dtype=F32), 1
+        add_ptr, ldadd = add_from.data_ptr(), _rows_ld(add_from)[1]
     elif out_f32:
         dx32 = torch.empty(x.shape, device=x.device, dtype=F32)
     lddx32 = _rows_ld(dx32)[1] if dx32 is not None else 0
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     _lib.call("adap_groupnorm_bwd", dy.data_ptr(), _dt(dy), lddy, x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
-              mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, ws.data_ptr(), B, HW, C, int(act),
-              _stream())
+              mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, add_ptr, ldadd, ws.data_ptr(), B, HW, C,
+              int(act), _stream())
     return dx32, dx16
 
 

@@ -92,10 +92,13 @@ int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma,
                        float* y32, long ldy32, void* y16, long ldy16,
                        float* mean, float* rstd, float* workspace,
                        int B, int HW, int C, float eps, int act, void* stream);
-/* dx (f32, optionally accumulated into, and/or bf16) from dy (f32 or bf16). */
+/* dx (f32 and/or bf16) from dy (f32 or bf16).  accumulate: dx32 = dx + add_src (the residual-stream gradient
+ * coming down the skip path); add_src NULL = dx32 itself (in place), otherwise any f32 tensor of the same shape,
+ * so the block's incoming gradient need not be cloned first.  dx16 is the bf16 copy of what dx32 receives. */
 int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
                        const float* gamma, const float* beta, const float* mean, const float* rstd,
                        float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
+                       const float* add_src, long ldadd,
                        float* workspace, int B, int HW, int C, int act, void* stream);
 
 /* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3, attention.py:267-269,275-285.

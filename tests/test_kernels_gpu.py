@@ -186,6 +186,13 @@ def test_groupnorm_fwd_bwd(B, C, H, eps, act):
     acc = base.clone()
     ops.groupnorm_bwd(nhwc(gy).to(torch.bfloat16), nhwc(x.detach()), gamma, beta, mean, rstd, act, accumulate_into=acc)
     assert rel(nchw(acc - base), gx_ref) < 4e-3
+    # out-of-place form: dx + addend into a new tensor, the addend untouched; the bf16 copy holds the same sum
+    keep = base.clone()
+    out32, out16 = ops.groupnorm_bwd(nhwc(gy).to(torch.bfloat16), nhwc(x.detach()), gamma, beta, mean, rstd, act,
+                                     out_bf16=True, add_from=base)
+    assert torch.equal(base, keep) and out32.data_ptr() != base.data_ptr()
+    assert torch.equal(out32, acc)
+    assert rel(out16.float(), out32) < 3e-3
 
 
 @pytest.mark.parametrize("rows,D", [(512, 320), (100, 640), (64, 1280), (33, 32)])
