@@ -223,28 +223,58 @@ class LatentDiffusion(DDPM):
     MAX_ACCUMU_BATCH_SIZE = 7
 
     def arc2face_distill_step(self, x_start, noise, t, cond, arc2face_prompt_emb, img_mask, fg_mask,
-                              num_denoising_steps=1, relative_ts=None, noises=None):
+                              num_denoising_steps=1, relative_ts=None, noises=None, batched_student=True):
         """The ``use_arc2face_as_target`` branch.  The teacher (``self.arc2face``) rolls ``num_denoising_steps`` out
         without grad; the student re-denoises the teacher's predictions and is regressed on the teacher's eps with
         bg_pixel_weight 0; the per-step losses are summed and divided by sqrt(ND).  The reference's indexing is kept
         literally: student step s starts from ``pred_x0s[s-1]``, i.e. for s = 0 from the LAST teacher prediction
-        (ddpm.py:2978).  -> (loss, grads, model_outputs, aux): call ``torch.autograd.backward(model_outputs, grads)``."""
+        (ddpm.py:2978).
+
+        ``batched_student``: the reference runs the student's (up to 7) passes one after the other on 1-2 instances
+        (MAX_ACCUMU_BATCH_SIZE, "to avoid OOM").  Nothing couples the samples of a UNet batch (GroupNorm and attention
+        are per sample), so here the passes are ONE forward/backward on the steps x instances batch -- the same
+        numbers, on grids that fill the chip (288 GB of HBM hold the activations of seven passes easily).
+        -> (loss, grads, model_outputs, aux): call ``torch.autograd.backward(model_outputs, grads)``; with
+        ``batched_student`` both lists have one element and ``aux['model_outputs_per_step']`` holds the per-step views."""
         nd = int(num_denoising_steps)
         teacher = self.arc2face(self, x_start, noise, t, arc2face_prompt_emb, num_denoising_steps=nd,
                                 relative_ts=relative_ts, noises=noises)
         noise_preds, pred_x0s, noises_, ts = teacher
-        max_num_loss_steps = self.MAX_ACCUMU_BATCH_SIZE // x_start.shape[0]
+        HB = x_start.shape[0]
+        max_num_loss_steps = self.MAX_ACCUMU_BATCH_SIZE // HB
         loss_start_step = max(0, nd - max_num_loss_steps)
         targets = noise_preds[loss_start_step:]
+        steps = list(range(loss_start_step, nd))
         c_emb, c_in, extra_info = cond
         extra_info = dict(extra_info)
         extra_info["img_mask"] = img_mask
         extra_info["capture_distill_attn"] = False                       # ddpm.py:2908
+        inv = 1.0 / float(np.sqrt(nd))                                    # ddpm.py:3035
+        if batched_student and len(steps) > 1:
+            nS = len(steps)
+            x0_all = torch.cat([pred_x0s[s - 1] for s in steps])
+            nz_all = torch.cat([noises_[s] for s in steps])
+            t_all = torch.cat([ts[s] for s in steps])
+            L, M, D = c_emb.shape[0] // HB, c_emb.shape[1], c_emb.shape[2]
+            c_all = c_emb.view(1, HB * L, M, D).expand(nS, HB * L, M, D).reshape(nS * HB * L, M, D)
+            ex_all = dict(extra_info)
+            if img_mask is not None:
+                ex_all["img_mask"] = img_mask.repeat(nS, 1, 1, 1)
+            mo_all, _ = self.guided_denoise(x0_all, nz_all, t_all, (c_all, c_in, ex_all))
+            per_step = list(mo_all.chunk(nS))
+            loss, gs, step_losses = 0.0, [], []
+            for mo, tgt in zip(per_step, targets):
+                l, g = self.calc_recon_loss(mo.contiguous(), tgt, img_mask, fg_mask, 1.0, 0.0)
+                step_losses.append(l)
+                loss = loss + l * inv
+                gs.append(g * inv)
+            return loss, [torch.cat(gs)], [mo_all], {"teacher": teacher, "step_losses": step_losses,
+                                                    "loss_start_step": loss_start_step,
+                                                    "model_outputs_per_step": per_step}
         model_outputs = []
-        for s in range(loss_start_step, nd):
+        for s in steps:
             mo, _ = self.guided_denoise(pred_x0s[s - 1], noises_[s], ts[s], (c_emb, c_in, extra_info))
             model_outputs.append(mo)
-        inv = 1.0 / float(np.sqrt(nd))                                    # ddpm.py:3035
         loss, grads, step_losses = 0.0, [], []
         for mo, tgt in zip(model_outputs, targets):
             l, g = self.calc_recon_loss(mo, tgt, img_mask, fg_mask, 1.0, 0.0)
@@ -252,7 +282,8 @@ class LatentDiffusion(DDPM):
             loss = loss + l * inv
             grads.append(g * inv)
         return loss, grads, model_outputs, {"teacher": teacher, "step_losses": step_losses,
-                                            "loss_start_step": loss_start_step}
+                                            "loss_start_step": loss_start_step,
+                                            "model_outputs_per_step": model_outputs}
 
     @staticmethod
     def half_batch_size(batch_size, num_denoising_steps):
@@ -277,7 +308,7 @@ class LatentDiffusion(DDPM):
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
     def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
                     num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
-                    trim_to_half_batch=True):
+                    trim_to_half_batch=True, batched_student=True):
         """``x_start``: a latent already encoded for this batch (e.g. by ``LatentPrefetcher`` on a side stream while
         the previous micro-batch's UNet pass was running); otherwise the batch is encoded here.
 
@@ -310,7 +341,8 @@ class LatentDiffusion(DDPM):
         if use_arc2face_as_target:
             t = self.shift_t_for_multistep(t, nd)
             loss, grads, outs, aux = self.arc2face_distill_step(
-                x_start, noise, t, cond, batch["arc2face_prompt_emb"], img_mask, fg_mask, nd, relative_ts, noises)
+                x_start, noise, t, cond, batch["arc2face_prompt_emb"], img_mask, fg_mask, nd, relative_ts, noises,
+                batched_student=batched_student)
             aux.update(x_start=x_start, t=t)
             return loss, grads, outs, aux
         c_emb, c_in, extra_info = cond

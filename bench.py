@@ -365,7 +365,7 @@ def main():
                 opt.step(clip_norm=ld.grad_clip)
                 reducer.zero()
                 sched.step()
-            return len(outs)
+            return len(aux["model_outputs_per_step"])
 
         for i, nd in enumerate((1, 3, 5, 7)):
             dstep(i, nd)
@@ -376,7 +376,7 @@ def main():
         dd = time.perf_counter() - t1
         distill = {"workload": "config 2 iteration mix: VAE encode of 4 + Arc2Face teacher rollout (full SD-1.5 UNet on the "
                                "same kernels, no grad) of ND steps on HALF_BS instances + student fwd/bwd on the teacher's "
-                               "predictions; ND drawn from {1,3,5,7} p=(.4,.3,.2,.1), seed 0",
+                               "predictions (the student's ND passes batched into one); ND drawn from {1,3,5,7} p=(.4,.3,.2,.1), seed 0",
                    "nd_sequence": nd_seq, "micro_batches": len(nd_seq),
                    "images_per_sec": round(B * len(nd_seq) / dd, 2), "ms_per_micro_batch": round(1e3 * dd / len(nd_seq), 2),
                    "teacher_unet_passes": int(sum(nd_seq)), "student_unet_fwd_bwd_passes": int(student_passes)}
