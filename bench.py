@@ -349,13 +349,21 @@ def main():
         nd_seq = [LatentDiffusion.draw_num_denoising_steps(7, rs) for _ in range(12)]
         tctx = torch.randn(B, 21, 768, device=device, generator=gen) * 0.05
 
+        dpf = None if args.no_prefetch else ld.make_prefetcher()     # next micro-batch's VAE encode on a side stream:
+        if dpf is not None:                                          # it fills the CUs the teacher's bs 1-2 passes idle
+            dpf.submit(batches[0], torch.randn(B, 4, 64, 64, device=device, generator=gen))
+
         def dstep(i, nd):
             batch = dict(batches[i % 2])
             batch["arc2face_prompt_emb"] = tctx
             t = torch.randint(0, 1000, (B,), device=device, generator=gen)
             noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+            x_start = None
+            if dpf is not None:
+                x_start = dpf.get()
+                dpf.submit(batches[(i + 1) % 2], torch.randn(B, 4, 64, 64, device=device, generator=gen))
             loss, grads, outs, aux = ld.shared_step(batch, t=t, noise=noise, num_denoising_steps=nd,
-                                                    use_arc2face_as_target=True)
+                                                    use_arc2face_as_target=True, x_start=x_start)
             reducer.wait()
             torch.autograd.backward(outs, grads)
             reducer.reduce()
