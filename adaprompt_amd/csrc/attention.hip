@@ -109,7 +109,8 @@ struct TileMap {
     int row[CPT];       // tile row of chunk i, or 64 (never valid)
     int goff[CPT];      // element offset in the global tile
     int loff[CPT];      // byte offset in the LDS image, or -1
-    __device__ __forceinline__ void init(long ld, int stride, int d, int tid) {
+    bool one[CPT];      // this chunk starts at the "ones" column (V tile: its first element is bf16 1.0, the rest 0)
+    __device__ __forceinline__ void init(long ld, int stride, int d, int tid, int ones_chunk = -1) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             int idx = tid + 256 * i;
@@ -118,6 +119,7 @@ struct TileMap {
             row[i] = (in && ch * 8 < d) ? r : 64;
             goff[i] = (int)(r * ld) + ch * 8;
             loff[i] = in ? r * stride + ch * 16 : -1;
+            one[i] = in && ch == ones_chunk;
         }
     }
 };
@@ -128,6 +130,7 @@ __device__ __forceinline__ void tile_load(TileRegs<NCH>& r, const TileMap<NCH>& 
     for (int i = 0; i < TileRegs<NCH>::CPT; ++i) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (mp.row[i] < nvalid) v = *(const uint4*)(src + mp.goff[i]);
+        if (mp.one[i]) v.x = 0x3F80u;
         r.v[i] = v;
     }
 }
@@ -148,9 +151,11 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
     constexpr int KSTRIDE = G::RSTRIDE;
     constexpr int VSTRIDE = VGeom<VT>::VSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                       // [64][KSTRIDE]
-    char* sV = sK + 64 * KSTRIDE;          // [64][VSTRIDE]
-    float* sBias = (float*)(sV + 64 * VSTRIDE);   // [64]
+    // K / V tiles and the key bias are double-buffered: tile kt+1 is written (from the registers its global loads
+    // landed in) while the other waves may still be multiplying tile kt, so the loop needs ONE barrier per tile
+    constexpr int TILE = 64 * KSTRIDE + 64 * VSTRIDE;
+    char* sKV = smem;                                   // [2][ K [64][KSTRIDE] | V [64][VSTRIDE] ]
+    float* sBiasAll = (float*)(smem + 2 * TILE);        // [2][68]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
         for (int r = 0; r < 16; ++r) O[vt][r] = 0.f;
     float m = -INFINITY, l = 0.f;
     // When the V tile has a spare column (32*VT > d) it is set to 1.0, so row d of O^T accumulates sum_k p -- the
-    // softmax denominator comes out of the PV MFMA for free (d = 40, 80; not 160).
-    const bool ones_col = 32 * VT > d;
+    // softmax denominator comes out of the PV MFMA for free (d = 40, 80; not 160).  The 1.0 is planted by the tile
+    // staging itself (TileMap::one), not by a separate write.
+    const bool ones_col = 32 * VT > d && (d >> 3) < G::NCH;
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
@@ -186,9 +192,9 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
     TileRegs<G::NCH> rK, rV;
     TileMap<G::NCH> mapK, mapV;
     mapK.init(p.ldk, KSTRIDE, d, tid);
-    mapV.init(p.ldv, VSTRIDE, d, tid);
+    mapV.init(p.ldv, VSTRIDE, d, tid, ones_col ? (d >> 3) : -1);
     // per-key additive bias of a tile (ragged last tile: -inf, masked keys: -FLT_MAX) and whether the tile has any
-    auto key_bias = [&](int key0) {
+    auto key_bias = [&](int key0, float* sBias) {
         if (tid < 64) {
             int key = key0 + tid;
             float bias = 0.f;
@@ -197,18 +203,19 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
             sBias[tid] = bias;
             unsigned long long any = __ballot(bias != 0.f);
             if (tid == 0) sBias[64] = any ? 1.f : 0.f;
-            if (ones_col) *(uint16_t*)(sV + tid * VSTRIDE + d * 2) = 0x3F80;      // bf16 1.0 (after tile_store)
         }
     };
     tile_load(rK, mapK, kb, min(64, p.M));
     tile_load(rV, mapV, vb, min(64, p.M));
-    tile_store(rK, mapK, sK);
-    tile_store(rV, mapV, sV);
-    __syncthreads();
-    key_bias(0);
+    tile_store(rK, mapK, sKV);
+    tile_store(rV, mapV, sKV + 64 * KSTRIDE);
+    key_bias(0, sBiasAll);
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
         const bool more = kt + 1 < ntiles;
+        const char* sK = sKV + (kt & 1) * TILE;
+        const char* sV = sK + 64 * KSTRIDE;
+        const float* sBias = sBiasAll + (kt & 1) * 68;
         if (more) {
             const int key1 = (kt + 1) * 64;
             tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, p.M - key1));
@@ -274,14 +281,13 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
                     O[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[vt], 0, 0, 0);
                 }
             }
-        __syncthreads();
-        if (more) {
-            tile_store(rK, mapK, sK);
-            tile_store(rV, mapV, sV);
-            __syncthreads();
-            key_bias((kt + 1) * 64);
-            __syncthreads();
+        if (more) {                                     // the other buffer: its last readers passed the previous barrier
+            char* nK = sKV + ((kt + 1) & 1) * TILE;
+            tile_store(rK, mapK, nK);
+            tile_store(rV, mapV, nK + 64 * KSTRIDE);
+            key_bias((kt + 1) * 64, sBiasAll + ((kt + 1) & 1) * 68);
         }
+        __syncthreads();
     }
     float ltot;
     if (ones_col) {
@@ -705,7 +711,12 @@ static int dkv_qsplit(int B, int H, int N, int M, int d) {
 // =============================================================================================
 template <int KS, int VT>
 static int launch_fwd(const AttnParams& p, hipStream_t s) {
-    size_t lds = 64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE + 68 * 4;
+    size_t lds = 2 * (64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE) + 2 * 68 * 4;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     dim3 grid((p.N + 127) / 128, p.B * p.H);
     hipLaunchKernelGGL((attn_fwd_kernel<KS, VT>), grid, dim3(256), lds, s, p);
     return adap_check_launch("attn_fwd");
