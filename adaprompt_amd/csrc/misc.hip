@@ -436,3 +436,41 @@ extern "C" int adap_axpy(const float* x, float* y, float a, long n, void* stream
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, a, n / 4);
     return adap_check_launch("axpy");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// y = a + b over [rows][C] with independent leading dimensions, written as f32 (packed) and, optionally, as the
+// bf16 operand copy: where the gradients of the two consumers of a skip connection meet (openaimodel.py:1018 keeps
+// every encoder activation for the decoder), replacing autograd's own add so that the sum arrives with its bf16
+// copy for the next data-gradient contraction.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                   long ldb, float* __restrict__ y32, uint16_t* __restrict__ y16,
+                                                   long rows, int C4) {
+    const long total = rows * C4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C4;
+        const int c = (int)(i - r * C4) * 4;
+        float4 x = *(const float4*)(a + r * lda + c), z = *(const float4*)(b + r * ldb + c);
+        float4 o = make_float4(x.x + z.x, x.y + z.y, x.z + z.z, x.w + z.w);
+        *(float4*)(y32 + r * (long)C4 * 4 + c) = o;
+        if (y16) {
+            uint2 w;
+            w.x = pack_bf16x2(o.x, o.y);
+            w.y = pack_bf16x2(o.z, o.w);
+            *(uint2*)(y16 + r * (long)C4 * 4 + c) = w;
+        }
+    }
+}
+
+extern "C" int adap_add2(const float* a, long lda, const float* b, long ldb, float* y32, void* y16, long rows, int C,
+                         void* stream) {
+    ADAP_REQUIRE(a && b && y32 && rows >= 0 && C > 0, ADAP_ERR_SHAPE, "add2: null pointer or empty");
+    ADAP_REQUIRE(C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 &&
+                     ((uintptr_t)y32 % 16) == 0 && (!y16 || ((uintptr_t)y16 % 8) == 0),
+                 ADAP_ERR_ALIGN, "add2: C and leading dims must be multiples of 4, pointers 16-byte aligned");
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(add2_kernel, dim3(grid_for(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                       y32, (uint16_t*)y16, rows, C / 4);
+    return adap_check_launch("add2");
+}

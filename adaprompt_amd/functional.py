@@ -122,8 +122,7 @@ class ResBlockFn(torch.autograd.Function):
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
         ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
         if sk is None:          # identity skip: dx + g straight into a new tensor (no clone of g)
-            gx, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True,
-                                         add_from=g if g.is_contiguous() else g.contiguous())
+            gx, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, add_from=g)
         else:
             gx, _ = ops.conv2d(gop, sk.bwd, sk.bwd.shape[1], 1)
             _, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, accumulate_into=gx)
@@ -195,9 +194,13 @@ class SpatialTransformerFn(torch.autograd.Function):
         P, heads = ctx.P, ctx.heads
         B, H, W, C = x.shape
         N = H * W
-        gop = _operand(g)
-        g = g.reshape(B, N, C) if g.is_contiguous() else g.contiguous().view(B, N, C)
-        gop = gop.reshape(B, N, C) if (gop.dtype == BF16 and gop.is_contiguous()) else g
+        gop = _operand(g)            # bf16 copy if the producer left one; g itself (f32) is only the final addend
+        if g.dim() == 4 and not g.is_contiguous():          # a channel slice out of a concat gradient: rows ld apart
+            ld = g.stride(-2)
+            gop = gop.as_strided((B, N, C), (N * ld, ld, 1)) if gop.stride(-2) == ld and gop.shape == g.shape \
+                else g.contiguous().view(B, N, C)
+        else:
+            gop = gop.reshape(B, N, C)
         # every f32 residual-stream gradient also gets a bf16 copy from the kernel that produces it, so the next
         # data-gradient contraction reads bf16 (LDS-DMA path) instead of converting f32 on the fly
         gt3, gt3h = _lin_bwd(gop, P["proj_out"], out_f32=True, out_bf16=True)     # [B,N,C]
@@ -235,7 +238,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         _, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=False, out_bf16=True)
         gnw, gnb = P["norm"]
         gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
-                                     add_from=g.view(B, H, W, C))          # x_in + proj_out(...): dx + g, no clone of g
+                                     add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None
 
 
@@ -303,4 +306,26 @@ class ConcatFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g[..., :ctx.ca], g[..., ctx.ca:]
+        g16 = _operand(g)
+        ga, gb = g[..., :ctx.ca], g[..., ctx.ca:]
+        if g16.dtype == BF16:                 # the consumer left a bf16 copy of the concat's gradient: slice it too
+            _stash16(ga, g16[..., :ctx.ca])
+            _stash16(gb, g16[..., ctx.ca:])
+        return ga, gb
+
+
+class SkipFn(torch.autograd.Function):
+    """An encoder activation that is used twice: by the next block and, later, by the decoder's concat
+    (openaimodel.py:985-1018: ``hs.append(h)`` / ``torch.cat([h, hs.pop()])``).  Forward is two views; backward adds
+    the two gradients in one kernel that also writes the bf16 operand copy of the sum (instead of autograd's add)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        return h.view_as(h), h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, g_main, g_skip):
+        _GRAD16.pop(g_main.data_ptr(), None)          # copies of the addends are not needed
+        _GRAD16.pop(g_skip.data_ptr(), None)
+        y32, y16 = ops.add2(g_main, g_skip)
+        return _stash16(y32, y16)

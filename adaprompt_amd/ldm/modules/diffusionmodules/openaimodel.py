@@ -359,7 +359,11 @@ class UNetModel(nn.Module):
         layer_idx = 0
         for module in self.input_blocks:
             h = run(module, h, layer_idx)
-            hs.append(h)
+            if torch.is_grad_enabled() and h.requires_grad:
+                h, h_skip = HF.SkipFn.apply(h)      # two consumers: their gradients meet in one fused add
+            else:
+                h_skip = h
+            hs.append(h_skip)
             if len(module) > 1:
                 grab(layer_idx, module[1], h)
             layer_idx += 1

@@ -493,3 +493,15 @@ def axpy_(y, x, a=1.0):
     assert x.is_contiguous() and y.is_contiguous() and x.dtype == F32 and y.dtype == F32
     _lib.call("adap_axpy", x.data_ptr(), y.data_ptr(), float(a), x.numel(), _stream())
     return y
+
+
+def add2(a, b, want_bf16=True):
+    """a + b for two f32 pixel-major tensors of one shape (arbitrary leading dimensions) -> (f32, bf16 | None), packed."""
+    assert a.dtype == F32 and b.dtype == F32 and a.shape == b.shape
+    C = a.shape[-1]
+    rows, lda = _rows_ld(a)
+    _, ldb = _rows_ld(b)
+    y32 = torch.empty(a.shape, device=a.device, dtype=F32)
+    y16 = torch.empty(a.shape, device=a.device, dtype=BF16) if want_bf16 else None
+    _lib.call("adap_add2", a.data_ptr(), lda, b.data_ptr(), ldb, y32.data_ptr(), _ptr(y16), rows, C, _stream())
+    return y32, y16

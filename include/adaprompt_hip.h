@@ -180,6 +180,10 @@ int adap_vae_softmax(const float* S, long lds, void* P, long ldp, const uint8_t*
 
 /* y += a * x (f32; n % 4 == 0). */
 int adap_axpy(const float* x, float* y, float a, long n, void* stream);
+/* y32 [rows][C] = a + b (rows of a / b lda / ldb apart), optionally also as bf16 (y16, same packed layout): the
+ * meeting point of the two gradients of a skip connection (openaimodel.py:1018), with the operand copy of the sum. */
+int adap_add2(const float* a, long lda, const float* b, long ldb, float* y32, void* y16, long rows, int C,
+              void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Optimiser step over flat fp32 buffers: Prodigy (ldm/prodigy.py:97-252) + the global gradient-norm clip that
