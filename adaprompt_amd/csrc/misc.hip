@@ -160,18 +160,24 @@ extern "C" int adap_timestep_embedding(const long long* t, float* out, int B, in
 // ---------------------------------------------------------------------------------------------
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
                                 const float* __restrict__ sa, const float* __restrict__ sb, float* __restrict__ out, int B,
-                                long per) {
+                                long per, int T) {
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < B * per; idx += (long)gridDim.x * blockDim.x) {
         int b = (int)(idx / per);
-        out[idx] = sa[t[b]] * x0[idx] + sb[t[b]] * noise[idx];
+        // a timestep outside the schedule must not become an out-of-bounds table read (a GPU fault): the sample
+        // turns into NaN instead, which no downstream check can miss (the reference raises an index error here)
+        const long long tt = t[b];
+        const bool ok = tt >= 0 && tt < T;
+        const float a = ok ? sa[tt] : __builtin_nanf(""), c = ok ? sb[tt] : __builtin_nanf("");
+        out[idx] = a * x0[idx] + c * noise[idx];
     }
 }
 
 extern "C" int adap_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
-                             const float* sqrt_1mac, float* out, int B, long per_sample, void* stream) {
+                             const float* sqrt_1mac, float* out, int B, long per_sample, int num_timesteps, void* stream) {
     ADAP_REQUIRE(x0 && noise && t && sqrt_ac && sqrt_1mac && out, ADAP_ERR_SHAPE, "q_sample: null pointer");
+    ADAP_REQUIRE(num_timesteps > 0, ADAP_ERR_SHAPE, "q_sample: num_timesteps must be the length of the schedule tables");
     hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(B * per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
-                       sqrt_ac, sqrt_1mac, out, B, per_sample);
+                       sqrt_ac, sqrt_1mac, out, B, per_sample, num_timesteps);
     return adap_check_launch("q_sample");
 }
 

@@ -223,7 +223,8 @@ class LatentDiffusion(DDPM):
     MAX_ACCUMU_BATCH_SIZE = 7
 
     def arc2face_distill_step(self, x_start, noise, t, cond, arc2face_prompt_emb, img_mask, fg_mask,
-                              num_denoising_steps=1, relative_ts=None, noises=None, batched_student=True):
+                              num_denoising_steps=1, relative_ts=None, noises=None, batched_student=True,
+                              teacher_out=None):
         """The ``use_arc2face_as_target`` branch.  The teacher (``self.arc2face``) rolls ``num_denoising_steps`` out
         without grad; the student re-denoises the teacher's predictions and is regressed on the teacher's eps with
         bg_pixel_weight 0; the per-step losses are summed and divided by sqrt(ND).  The reference's indexing is kept
@@ -237,8 +238,9 @@ class LatentDiffusion(DDPM):
         -> (loss, grads, model_outputs, aux): call ``torch.autograd.backward(model_outputs, grads)``; with
         ``batched_student`` both lists have one element and ``aux['model_outputs_per_step']`` holds the per-step views."""
         nd = int(num_denoising_steps)
-        teacher = self.arc2face(self, x_start, noise, t, arc2face_prompt_emb, num_denoising_steps=nd,
-                                relative_ts=relative_ts, noises=noises)
+        # ``teacher_out``: a rollout already computed for exactly these inputs (DistillPrefetcher, on a side stream)
+        teacher = teacher_out if teacher_out is not None else self.arc2face(
+            self, x_start, noise, t, arc2face_prompt_emb, num_denoising_steps=nd, relative_ts=relative_ts, noises=noises)
         noise_preds, pred_x0s, noises_, ts = teacher
         HB = x_start.shape[0]
         max_num_loss_steps = self.MAX_ACCUMU_BATCH_SIZE // HB
@@ -308,7 +310,7 @@ class LatentDiffusion(DDPM):
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
     def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
                     num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
-                    trim_to_half_batch=True, batched_student=True):
+                    trim_to_half_batch=True, batched_student=True, teacher_out=None):
         """``x_start``: a latent already encoded for this batch (e.g. by ``LatentPrefetcher`` on a side stream while
         the previous micro-batch's UNet pass was running); otherwise the batch is encoded here.
 
@@ -339,10 +341,11 @@ class LatentDiffusion(DDPM):
         img_mask = None if aug is None else torch.nn.functional.interpolate(aug[:, None].float(), size=hw, mode="nearest")
         fg_mask = None if fg is None else torch.nn.functional.interpolate(fg[:, None].float(), size=hw, mode="nearest")
         if use_arc2face_as_target:
-            t = self.shift_t_for_multistep(t, nd)
+            if teacher_out is None:
+                t = self.shift_t_for_multistep(t, nd)          # (a prefetched rollout was made with the shifted t)
             loss, grads, outs, aux = self.arc2face_distill_step(
                 x_start, noise, t, cond, batch["arc2face_prompt_emb"], img_mask, fg_mask, nd, relative_ts, noises,
-                batched_student=batched_student)
+                batched_student=batched_student, teacher_out=teacher_out)
             aux.update(x_start=x_start, t=t)
             return loss, grads, outs, aux
         c_emb, c_in, extra_info = cond
@@ -354,6 +357,9 @@ class LatentDiffusion(DDPM):
 
     def make_prefetcher(self):
         return LatentPrefetcher(self)
+
+    def make_distill_prefetcher(self):
+        return DistillPrefetcher(self)
 
     def training_step(self, batch, optimizer=None, reducer=None, scheduler=None, **step_kwargs):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
@@ -403,9 +409,18 @@ class LatentPrefetcher:
         self.stream = torch.cuda.Stream()
         self._pending = None
 
+    def _hold(self, *tensors):
+        """inputs allocated on the main stream are read LATER by side-stream kernels: tell the caching allocator, or a
+        temporary the caller drops right after submit() could be handed out again while those kernels still read it
+        (for the timestep tensor that means garbage gather indices -> an out-of-bounds access)."""
+        for x in tensors:
+            if torch.is_tensor(x) and x.is_cuda:
+                x.record_stream(self.stream)
+
     def submit(self, batch, post_noise=None):
         main = torch.cuda.current_stream()
         self.stream.wait_stream(main)                 # inputs written on the main stream are visible
+        self._hold(post_noise, *batch.values())
         with torch.cuda.stream(self.stream):
             x_start, _ = self.model.get_input(batch, post_noise)
             x_start = x_start.contiguous()
@@ -419,6 +434,43 @@ class LatentPrefetcher:
         torch.cuda.current_stream().wait_event(ev)
         x_start.record_stream(torch.cuda.current_stream())
         return x_start
+
+
+class DistillPrefetcher(LatentPrefetcher):
+    """The whole no-grad front of a distillation micro-batch on the side stream: VAE encode, trim to HALF_BS, shift t,
+    and the teacher's ND-step rollout -- none of it depends on the trainable weights, so it may run while the previous
+    micro-batch's student forward/backward (and optimiser step) occupy the main stream.  The teacher's passes run on
+    1-2 instances and leave most CUs idle; the student's batched pass fills them.
+
+        pf.submit(batch, post_noise, t, noise, nd);  x_start, t, noise, teacher_out = pf.get()
+        model.shared_step(batch, x_start=x_start, t=t, noise=noise, num_denoising_steps=nd,
+                          use_arc2face_as_target=True, trim_to_half_batch=False-equivalent handled by the caller ...)
+    """
+
+    def submit(self, batch, post_noise, t, noise, nd):
+        m = self.model
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        self._hold(post_noise, t, noise, *batch.values())
+        with torch.cuda.stream(self.stream):
+            x_start, _ = m.get_input(batch, post_noise)
+            x_start = x_start.contiguous()
+            hb = m.half_batch_size(x_start.shape[0], nd) if nd > 1 else x_start.shape[0]
+            x_start, t, noise = x_start[:hb].contiguous(), t[:hb].contiguous(), noise[:hb].contiguous()
+            t = m.shift_t_for_multistep(t, nd)
+            teacher = m.arc2face(m, x_start, noise, t, batch["arc2face_prompt_emb"][:hb], num_denoising_steps=nd)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._pending = (x_start, t, noise, teacher, hb, ev)
+
+    def get(self):
+        x_start, t, noise, teacher, hb, ev = self._pending
+        self._pending = None
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for ten in [x_start, t, noise] + [x for lst in teacher for x in lst]:
+            ten.record_stream(cur)
+        return x_start, t, noise, teacher, hb
 
 
 class Arc2FaceWrapper(nn.Module):
@@ -467,5 +519,8 @@ class Arc2FaceWrapper(nn.Module):
                 t_lb = t_i * float(np.power(0.5, np.power(nd - 1, -0.3)))
                 t_ub = t_i * float(np.power(0.7, np.power(nd - 1, -0.3)))
                 ts.append(((t_ub - t_lb) * rel + t_lb).long())
-                noises_.append(noises[i + 1] if noises is not None else torch.randn_like(x0_i))
+                # (the reference draws randn_like(pred_x0) on a contiguous NCHW tensor; drawing by shape keeps the values
+                # independent of the memory layout x0_i happens to have here, e.g. an NCHW view of a pixel-major latent)
+                noises_.append(noises[i + 1] if noises is not None
+                               else torch.randn(x0_i.shape, device=x0_i.device, dtype=x0_i.dtype))
         return noise_preds, x_starts[1:], noises_, ts

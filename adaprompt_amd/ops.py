@@ -408,8 +408,9 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
     t = t.to(torch.int64).contiguous()
     out = torch.empty_like(x0)
     B = x0.shape[0]
+    assert t.numel() == B and sqrt_ac.numel() == sqrt_1mac.numel()
     _lib.call("adap_q_sample", x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
-              out.data_ptr(), B, x0.numel() // B, _stream())
+              out.data_ptr(), B, x0.numel() // B, sqrt_ac.numel(), _stream())
     return out
 
 

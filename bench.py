@@ -349,21 +349,41 @@ def main():
         nd_seq = [LatentDiffusion.draw_num_denoising_steps(7, rs) for _ in range(12)]
         tctx = torch.randn(B, 21, 768, device=device, generator=gen) * 0.05
 
-        dpf = None if args.no_prefetch else ld.make_prefetcher()     # next micro-batch's VAE encode on a side stream:
-        if dpf is not None:                                          # it fills the CUs the teacher's bs 1-2 passes idle
-            dpf.submit(batches[0], torch.randn(B, 4, 64, 64, device=device, generator=gen))
+        # the no-grad front of the NEXT micro-batch (VAE encode + teacher rollout on 1-2 instances) runs on a side stream
+        # under the current micro-batch's student pass
+        dpf = None if args.no_prefetch else ld.make_distill_prefetcher()
+        seq_all = [1, 3, 5, 7] + nd_seq
+
+        def dsubmit(j):
+            if dpf is None or j >= len(seq_all):
+                return
+            b = dict(batches[j % 2])
+            b["arc2face_prompt_emb"] = tctx
+            dpf.submit(b, torch.randn(B, 4, 64, 64, device=device, generator=gen),
+                       torch.randint(0, 1000, (B,), device=device, generator=gen),
+                       torch.randn(B, 4, 64, 64, device=device, generator=gen), seq_all[j])
+
+        dstate = {"j": 0}
+        dsubmit(0)
 
         def dstep(i, nd):
             batch = dict(batches[i % 2])
             batch["arc2face_prompt_emb"] = tctx
-            t = torch.randint(0, 1000, (B,), device=device, generator=gen)
-            noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
-            x_start = None
+            j = dstate["j"]
+            dstate["j"] = j + 1
             if dpf is not None:
-                x_start = dpf.get()
-                dpf.submit(batches[(i + 1) % 2], torch.randn(B, 4, 64, 64, device=device, generator=gen))
-            loss, grads, outs, aux = ld.shared_step(batch, t=t, noise=noise, num_denoising_steps=nd,
-                                                    use_arc2face_as_target=True, x_start=x_start)
+                assert seq_all[j] == nd
+                x_start, t, noise, teacher_out, hb = dpf.get()
+                dsubmit(j + 1)
+                batch = {k: (v[:hb] if torch.is_tensor(v) and v.dim() > 0 else v) for k, v in batch.items()}
+                loss, grads, outs, aux = ld.shared_step(batch, t=t, noise=noise, num_denoising_steps=nd,
+                                                        use_arc2face_as_target=True, x_start=x_start,
+                                                        trim_to_half_batch=False, teacher_out=teacher_out)
+            else:
+                t = torch.randint(0, 1000, (B,), device=device, generator=gen)
+                noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+                loss, grads, outs, aux = ld.shared_step(batch, t=t, noise=noise, num_denoising_steps=nd,
+                                                        use_arc2face_as_target=True)
             reducer.wait()
             torch.autograd.backward(outs, grads)
             reducer.reduce()
@@ -384,7 +404,7 @@ def main():
         dd = time.perf_counter() - t1
         distill = {"workload": "config 2 iteration mix: VAE encode of 4 + Arc2Face teacher rollout (full SD-1.5 UNet on the "
                                "same kernels, no grad) of ND steps on HALF_BS instances + student fwd/bwd on the teacher's "
-                               "predictions (the student's ND passes batched into one); ND drawn from {1,3,5,7} p=(.4,.3,.2,.1), seed 0",
+                               "predictions (the student's ND passes batched into one; the next micro-batch's VAE encode + teacher rollout prefetched on a side stream); ND drawn from {1,3,5,7} p=(.4,.3,.2,.1), seed 0",
                    "nd_sequence": nd_seq, "micro_batches": len(nd_seq),
                    "images_per_sec": round(B * len(nd_seq) / dd, 2), "ms_per_micro_batch": round(1e3 * dd / len(nd_seq), 2),
                    "teacher_unet_passes": int(sum(nd_seq)), "student_unet_fwd_bwd_passes": int(student_passes)}

@@ -147,9 +147,10 @@ int adap_linear_small(const float* x, long ldx, const float* w, const float* bia
 /* timestep_embedding, util.py:154-174 (t int64 [B] -> [B][dim]). */
 int adap_timestep_embedding(const long long* t, float* out, int B, int dim, void* stream);
 
-/* q_sample, ddpm.py:416-419 with extract_into_tensor util.py:99-102. */
+/* q_sample, ddpm.py:416-419 with extract_into_tensor util.py:99-102.  sqrt_ac / sqrt_1mac hold num_timesteps
+ * entries; a t outside [0, num_timesteps) yields NaN for that sample instead of an out-of-bounds read. */
 int adap_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ac,
-                  const float* sqrt_1mac, float* out, int B, long per_sample, void* stream);
+                  const float* sqrt_1mac, float* out, int B, long per_sample, int num_timesteps, void* stream);
 
 /* DiagonalGaussianDistribution.sample + scale_factor, distributions.py:24-37, ddpm.py:955-962.
  * moments pixel-major [pixels][2*zch] (mean | logvar), noise / z [pixels][zch]. */

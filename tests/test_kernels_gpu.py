@@ -337,6 +337,11 @@ def test_q_sample_posterior_mse():
     got = ops.q_sample(x0, n, t, sa, sb)
     ref = sa[t].view(B, 1, 1, 1) * x0 + sb[t].view(B, 1, 1, 1) * n
     assert rel(got, ref) < 1e-6
+    # a timestep outside the schedule is not allowed to read past the tables: that sample comes back NaN, the others
+    # are untouched (the reference raises an IndexError at this point)
+    bad = ops.q_sample(x0, n, torch.tensor([0, 1000, -3, 999], device=dev()), sa, sb)
+    assert torch.isnan(bad[1]).all() and torch.isnan(bad[2]).all()
+    assert torch.equal(bad[0], got[0]) and torch.equal(bad[3], got[3])
     mom = rnd(B, 64, 64, 8, seed=3) * 3
     mom[..., 4:] *= 10
     z = ops.posterior_sample(mom, n, 0.18215)

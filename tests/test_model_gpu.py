@@ -413,6 +413,66 @@ def test_guided_denoise_cfg_pixel_recon_vs_oracle():
     assert rel_err(x_rec_nocfg.cpu(), O.predict_start_from_noise(sch, xn, t, eps)) < EPS_TOL
 
 
+def test_distill_prefetcher_matches_inline_path():
+    """The side-stream front of a distillation micro-batch (VAE encode + trim + t shift + teacher rollout,
+    DistillPrefetcher) must hand the student exactly what the inline path computes: same RNG stream, same kernels,
+    only another HIP stream -- bit-identical loss and gradient.  Inputs are dropped right after submit() on purpose:
+    the prefetcher has to keep them alive for the side stream (record_stream)."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion, Arc2FaceWrapper
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
+    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                         {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
+    ld.load_state_dict({**synth.synthetic_unet_state_dict(ucfg), **synth.synthetic_vae_state_dict(vdd)}, strict=False)
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    TP = "arc2face.unet."
+    teacher = Arc2FaceWrapper(unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
+    teacher.unet.load_state_dict({k[len(TP):]: v for k, v in synth.synthetic_unet_state_dict(ucfg, prefix=TP).items()})
+    ld.set_arc2face_teacher(teacher.to(dev()).eval())
+    B, nd = 4, 3
+    img = synth.synthetic_input("pf.img", (B, 512, 512, 3), 0, 0.5).clamp(-1, 1).to(dev())
+    batch = {"image": img, "fg_mask": ellipse_mask(B, 512, 512)[:, 0].to(dev()),
+             "aug_mask": border_mask(B, 512, 512, 32)[:, 0].to(dev()),
+             "arc2face_prompt_emb": synth.synthetic_input("pf.tctx", (B, 21, ucfg["context_dim"])).to(dev())}
+    ctx = synth.synthetic_input("pf.ctx", (16 * 2, 77, ucfg["context_dim"]))          # HALF_BS = 2 for ND = 3
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": False}
+
+    def inputs():
+        return (synth.synthetic_input("pf.pn", (B, 4, 64, 64)).to(dev()), torch.tensor([300, 720, 5, 999], device=dev()),
+                synth.synthetic_input("pf.noise", (B, 4, 64, 64)).to(dev()))
+
+    # inline
+    torch.manual_seed(11)
+    pn, t, noise = inputs()
+    c1 = ctx.to(dev()).clone().requires_grad_(True)
+    loss1, g1, o1, aux1 = ld.shared_step(batch, t=t, noise=noise, post_noise=pn, cond=(c1, None, extra),
+                                         num_denoising_steps=nd, use_arc2face_as_target=True)
+    torch.autograd.backward(o1, g1)
+    # prefetched
+    torch.manual_seed(11)
+    pf = ld.make_distill_prefetcher()
+    pn, t, noise = inputs()
+    pf.submit(batch, pn, t, noise, nd)
+    del pn, t, noise
+    junk = [torch.full((B, 4, 64, 64), float("nan"), device=dev()) for _ in range(8)]      # reuse freed blocks, if any
+    junk.append(torch.full((B,), 123456789, device=dev(), dtype=torch.long))
+    x_start, t2, noise2, teacher_out, hb = pf.get()
+    assert hb == 2
+    b2 = {k: v[:hb] for k, v in batch.items()}
+    c2 = ctx.to(dev()).clone().requires_grad_(True)
+    loss2, g2, o2, aux2 = ld.shared_step(b2, t=t2, noise=noise2, x_start=x_start, cond=(c2, None, extra),
+                                         num_denoising_steps=nd, use_arc2face_as_target=True,
+                                         trim_to_half_batch=False, teacher_out=teacher_out)
+    torch.autograd.backward(o2, g2)
+    del junk
+    for a, b in zip(aux1["teacher"][3], aux2["teacher"][3]):
+        assert torch.equal(a, b)
+    assert torch.equal(loss1, loss2)
+    assert torch.equal(c1.grad, c2.grad)
+
+
 def test_cpu_tensor_fails_loudly():
     unet = build_unet(NARROW)
     with pytest.raises(RuntimeError):
