@@ -390,3 +390,26 @@ def test_errors_are_loud():
     w = torch.zeros(1, 8, 12, device=dev(), dtype=torch.bfloat16)
     with pytest.raises(HipError):
         ops.conv2d(x, w, 8, 1)
+
+
+def test_add2_strided_and_bf16_copy():
+    """adap_add2: the meeting point of a skip connection's two gradients -- one contiguous, one a channel slice of a
+    wider tensor -- exact in f32, with the bf16 copy of the sum."""
+    B, H, C = 2, 16, 320
+    a = rnd(B, H, H, C, seed=1)
+    wide = rnd(B, H, H, C + 640, seed=2)
+    b = wide[..., 640:]                                    # rows 960 floats apart
+    y32, y16 = ops.add2(a, b)
+    assert torch.equal(y32, a + b)
+    assert torch.equal(y16, (a + b).to(torch.bfloat16))
+    y32b, none = ops.add2(b, a, want_bf16=False)
+    assert none is None and torch.equal(y32b, y32)
+
+
+def test_linear_small_more_than_eight_rows():
+    """the timestep-embedding MLP at the sampler's batch of 16: slices of 8 rows through the register-resident kernel."""
+    x = rnd(19, 320, seed=3)
+    w, bias = rnd(1280, 320, seed=4) * 0.05, rnd(1280, seed=5) * 0.1
+    got = ops.linear_small(x, w, bias, post_silu=True)
+    ref = F.silu(x @ w.t() + bias)
+    assert rel(got, ref) < 1e-5
