@@ -782,13 +782,18 @@ static int launch_ring(const ConvParams& p, hipStream_t stream) {
 // activation traffic L2 -> LDS from 9x to 1.33x; the gather variant was bound by exactly that feed rate (measured:
 // 2600-4300 cycles per K step against 1024 of MFMA, HBM traffic already compulsory-only).
 // =============================================================================================
-#define HALO_TH 8
-#define HALO_TW 32
-#define HALO_W (HALO_TW + 2)
-#define HALO_SLOTS ((HALO_TH + 2) * HALO_W)      // 340
+// patch shapes: WIDE = 8 x 32 pixels (window 10 x 34 = 340 slots), !WIDE = 16 x 16 (window 18 x 18 = 324 slots) for the
+// UNet's 16 x 16 level, whose rows are too short for the wide patch.  Either way 256 pixels and <= 384 staged slots.
 #define HALO_PASSES 6                            // 6 x 64 slots >= 340
-template <int BN, int ROLE>
+template <bool WIDE>
+struct HaloShape {
+    static constexpr int TH = WIDE ? 8 : 16, TW = WIDE ? 32 : 16;
+    static constexpr int W = TW + 2, SLOTS = (TH + 2) * W;
+};
+template <int BN, int ROLE, bool WIDE>
 __device__ __forceinline__ void halo_body(const ConvParams& p) {
+    constexpr int HALO_TH = HaloShape<WIDE>::TH, HALO_TW = HaloShape<WIDE>::TW, HALO_W = HaloShape<WIDE>::W;
+    constexpr int HALO_SLOTS = HaloShape<WIDE>::SLOTS;
     constexpr int WN = BN / 2;
     constexpr int MT = WN / 16;
     constexpr int PT = 4;
@@ -907,8 +912,8 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            int hc = (j & 1) * 16 + frow + kx;
-            int sl = (2 * wm + (j >> 1)) * HALO_W + hc;
+            int hc = (WIDE ? (j & 1) * 16 : 0) + frow + kx;
+            int sl = (WIDE ? 2 * wm + (j >> 1) : 4 * wm + j) * HALO_W + hc;
             aoff[kx][j] = sl * 128 + ((fchunk ^ (hc & 7)) << 4);
         }
     int woff[MT];
@@ -923,7 +928,7 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
     auto epilogue = [&](int c_bimg, int c_y0, int c_x0, int c_n0) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const int yy = c_y0 + 2 * wm + (j >> 1), xx = c_x0 + (j & 1) * 16 + frow;
+            const int yy = c_y0 + (WIDE ? 2 * wm + (j >> 1) : 4 * wm + j), xx = c_x0 + (WIDE ? (j & 1) * 16 : 0) + frow;
             const int m = (c_bimg * p.Hin + yy) * p.Win + xx;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -1062,25 +1067,26 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
     if (ROLE != 0 || !(p.dbg & 4)) epilogue(cur.bimg, cur.y0, cur.x0, cur.n0);
 }
 
-template <int BN, bool PP>
+template <int BN, bool PP, bool WIDE>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
-    if (!PP) halo_body<BN, 0>(p);
-    else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) halo_body<BN, 1>(p);   // waves 0-3
-    else halo_body<BN, 2>(p);                                                              // waves 4-7
+    if (!PP) halo_body<BN, 0, WIDE>(p);
+    else if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) halo_body<BN, 1, WIDE>(p);   // waves 0-3
+    else halo_body<BN, 2, WIDE>(p);                                                              // waves 4-7
 }
 
-template <int BN>
+template <int BN, bool WIDE>
 static int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr bool PP = BN == 128;      // ping-pong halves (see halo_body); the 160-wide tile spills with them
     size_t lds = 2 * HALO_PASSES * 64 * 128 + 3 * BN * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, PP, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
         attr_set = true;
     }
     // one workgroup per CU at a time (144 KB of LDS each), one tile per workgroup
     const int nwg = p.ntiles_m * p.ntiles_n;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PP>), dim3(nwg, 1, p.ksplit), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, PP, WIDE>), dim3(nwg, 1, p.ksplit), dim3(512), lds, stream, p);
     if (p.ksplit > 1) launch_reduce(p, stream);
     return adap_check_launch("conv3x3_halo");
 }
@@ -1112,11 +1118,18 @@ static bool choose_big(long M, int Cout, int ktiles_total, int x_dtype, int nbat
     return up == 0 && x_dtype == 1 && nbatch == 1 && Cout > 64 && M >= 4096 && ktiles_total >= 5;
 }
 
-// the stencil-window variant: 3x3 / stride 1 / pad 1 on bf16 activations whose image tiles into 8 x 32 patches
+// patch shape of the stencil-window kernel for an H x W image: 1 = 8 x 32 (wide), 2 = 16 x 16 (square), 0 = neither tiles it
+static int halo_shape(int H, int W) {
+    if (H % 8 == 0 && W % 32 == 0) return 1;
+    if (H % 16 == 0 && W % 16 == 0) return 2;
+    return 0;
+}
+
+// the stencil-window variant: 3x3 / stride 1 / pad 1 on bf16 activations whose image tiles into 256-pixel patches
 static bool choose_halo(int Hin, int Win, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int stride, int pad, int up,
                         int x_dtype, int nbatch) {
     return KH == 3 && KW == 3 && stride == 1 && pad == 1 && up == 0 && x_dtype == 1 && nbatch == 1 && Hout == Hin &&
-           Wout == Win && Hin % HALO_TH == 0 && Win % HALO_TW == 0 && Cout > 64 && Cin >= 64 && Cin % 64 == 0;
+           Wout == Win && halo_shape(Hin, Win) != 0 && Cout > 64 && Cin >= 64 && Cin % 64 == 0;
 }
 
 // channel tile of the stencil-window kernel: the ping-pong schedule exists for the 128-wide tile only (the 160-wide one
@@ -1133,7 +1146,7 @@ static int choose_bn_halo(int Cout) {
 
 static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
     int bn = choose_bn_halo(Cout);
-    long blocks = (long)B * (H / HALO_TH) * (W / HALO_TW) * ((Cout + bn - 1) / bn);
+    long blocks = (long)B * (H * W / 256) * ((Cout + bn - 1) / bn);
     int nchunks = (Cin + BK - 1) / BK;
     if (blocks >= 200 || nchunks < 2) return 1;
     int ks = (int)((256 + blocks - 1) / blocks);
@@ -1168,7 +1181,7 @@ extern "C" long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin,
     int ks0 = choose_ksplit(M, Cout, kt, false);
     int ks1 = choose_big(M, Cout, kt, 1, 1, 0) ? choose_ksplit(M, Cout, kt, true) : 1;
     int ks = ks0 > ks1 ? ks0 : ks1;
-    if (KH == 3 && KW == 3 && Hout % HALO_TH == 0 && Wout % HALO_TW == 0 && Cout > 64 && Cin >= 64) {
+    if (KH == 3 && KW == 3 && halo_shape(Hout, Wout) != 0 && Cout > 64 && Cin >= 64) {
         int ks2 = choose_ksplit_halo(B, Hout, Wout, Cin, Cout);
         if (ks2 > ks) ks = ks2;
     }
@@ -1286,9 +1299,13 @@ extern "C" int adap_conv2d_nhwc(
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (halo) {
         g_last_variant = 4000 + bn;
-        p.ntiles_m = B * (Hin / HALO_TH) * (Win / HALO_TW);
-        if (bn == 160) return launch_halo<160>(p, s);
-        return launch_halo<128>(p, s);
+        p.ntiles_m = B * (Hin * Win / 256);
+        if (halo_shape(Hin, Win) == 1) {
+            if (bn == 160) return launch_halo<160, true>(p, s);
+            return launch_halo<128, true>(p, s);
+        }
+        if (bn == 160) return launch_halo<160, false>(p, s);
+        return launch_halo<128, false>(p, s);
     }
     if (use_big) {
         g_last_variant = 2000 + bn;

@@ -64,6 +64,10 @@ CONV_CASES = [
     (2, 320, 2560, 64, 64, 1, 1, 0, 0, True),      # GEGLU projection shape
     (4, 128, 128, 64, 64, 3, 2, 0, 0, True),       # stride 2, asymmetric pad, big tile
     (2, 320, 320, 32, 32, 3, 1, 1, 1, True),       # fused nearest x2 upsample, big tile
+    # stencil-window kernel, 16 x 16 patches (rows too short for the 8 x 32 patch): ping-pong 128-wide tile + split-K
+    (4, 1280, 1280, 16, 16, 3, 1, 1, 0, True),     # UNet 16x16 level
+    (1, 128, 256, 32, 16, 3, 1, 1, 0, True),       # two square patches stacked, no split
+    (2, 2560, 1280, 16, 16, 3, 1, 1, 0, True),     # concat input, long K
 ]
 
 
