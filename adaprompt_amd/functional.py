@@ -174,7 +174,8 @@ class SpatialTransformerFn(torch.autograd.Function):
         ff1, ff2 = P["ff1"], P["ff2"]
         _, hh = ops.linear(n3, ff1.fwd, 8 * C, bias=ff1.bias, out_f32=False, out_bf16=True)
         gg = ops.geglu_fwd(hh)
-        t3, _ = ops.linear(gg, ff2.fwd, C, bias=ff2.bias, residual=t2)
+        # t3 only feeds proj_out, whose matrix-core operand is bf16 anyway: write it as bf16 only
+        _, t3 = ops.linear(gg, ff2.fwd, C, bias=ff2.bias, residual=t2, out_f32=False, out_bf16=True)
         pout = P["proj_out"]
         out, _ = ops.linear(t3, pout.fwd, C, bias=pout.bias, residual=x.view(B, N, C))
         ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
