@@ -185,12 +185,13 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
     if e0 is not None:
         # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
         v = _lib.call_long("adap_conv2d_last_variant")
-        # the symbol names rocprofv3 --stats lists (last template argument: ring = ONE_TAP, halo = ping-pong schedule)
+        # the symbol names rocprofv3 --stats lists (ring: ..., ONE_TAP; halo: ..., ping-pong schedule, wide patch)
         one_tap = "true" if (KH == 1 and stride == 1 and pad == 0 and up == 0) else "false"
         kname = {0: "conv_gemm_kernel<{bn}, true>", 1: "conv_gemm_kernel<{bn}, false>",
                  2: "conv_gemm_ring_kernel<256, {bn}, 3, {ot}>", 3: "conv_gemm_ring_kernel<128, {bn}, 4, {ot}>",
-                 4: "conv3x3_halo_kernel<{bn}, {pp}>"}[v // 1000].format(bn=v % 1000, ot=one_tap,
-                                                                      pp="true" if v % 1000 == 128 else "false")
+                 4: "conv3x3_halo_kernel<{bn}, {pp}, {wide}>"}[v // 1000].format(
+                     bn=v % 1000, ot=one_tap, pp="true" if v % 1000 == 128 else "false",
+                     wide="true" if (H % 8 == 0 and W % 32 == 0) else "false")     # 8x32 patches, else 16x16
         TIMER.stop(kname, 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0,
                    f"M={B * Ho * Wo} N={Cout} K={Cin}x{KH * KH} s{stride} up{up} {'f32' if x.dtype == F32 else 'bf16'}")
     return y32, y16
