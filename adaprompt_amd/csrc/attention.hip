@@ -145,8 +145,10 @@ __device__ __forceinline__ void tile_store(const TileRegs<NCH>& r, const TileMap
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int KS, int VT>
-__global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnParams p) {
+// QB = 32-row query blocks per wave.  QB = 2 (long sequences): every K fragment and every transposed V fragment read
+// from LDS feeds two MFMAs instead of one, and the two blocks' softmax chains are independent work inside one wave.
+template <int KS, int VT, int QB>
+__global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int KSTRIDE = G::RSTRIDE;
     constexpr int VSTRIDE = VGeom<VT>::VSTRIDE;
@@ -160,27 +162,33 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-    const int q = blockIdx.x * 128 + wave * 32 + c;
+    const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
 
     // Q fragments stay exactly the caller's bf16 values: scale*log2(e) is applied in f32 inside the exponent's fma
     // (pre-multiplying Q would round q*cs to bf16 again and cost ~2e-4 of LSE accuracy for ~1% of a step)
-    bf16x8 qf[KS];
+    bf16x8 qf[QB][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        int ch = 2 * s + h;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q < p.N && ch * 8 < d) v = *(const uint4*)(p.q + ((size_t)b * p.N + q) * p.ldq + head * d + ch * 8);
-        qf[s] = __builtin_bit_cast(bf16x8, v);
-    }
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            int ch = 2 * s + h, q = q0 + 32 * qb;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.N && ch * 8 < d) v = *(const uint4*)(p.q + ((size_t)b * p.N + q) * p.ldq + head * d + ch * 8);
+            qf[qb][s] = __builtin_bit_cast(bf16x8, v);
+        }
 
-    f32x16 O[VT];
+    f32x16 O[QB][VT];
 #pragma unroll
-    for (int vt = 0; vt < VT; ++vt)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[vt][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[qb][vt][r] = 0.f;
+    float m[QB], l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m[qb] = -INFINITY; l[qb] = 0.f; }
     // When the V tile has a spare column (32*VT > d) it is set to 1.0, so row d of O^T accumulates sum_k p -- the
     // softmax denominator comes out of the PV MFMA for free (d = 40, 80; not 160).  The 1.0 is planted by the tile
     // staging itself (TileMap::one), not by a separate write.
@@ -221,64 +229,77 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
             tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, p.M - key1));
             tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, p.M - key1));
         }
-        f32x16 S[2];
+        f32x16 S[QB][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[t][r] = 0.f;
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[qb][t][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
-                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[t], 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    S[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][s], S[qb][t], 0, 0, 0);
             }
         }
-        if (sBias[64] != 0.f) {                         // wave-uniform: ragged / masked tile
+        const bool biased = sBias[64] != 0.f;           // wave-uniform: ragged / masked tile
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (biased) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
+                        S[qb][t][4 * g] += bv.x; S[qb][t][4 * g + 1] += bv.y;
+                        S[qb][t][4 * g + 2] += bv.z; S[qb][t][4 * g + 3] += bv.w;
+                    }
+            }
+            float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
-                    S[t][4 * g] += bv.x; S[t][4 * g + 1] += bv.y; S[t][4 * g + 2] += bv.z; S[t][4 * g + 3] += bv.w;
-                }
-        }
-        float mx = -INFINITY;
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m[qb], mx * cs);   // running max in the exp2 domain (cs > 0)
+            if (__any(mnew != m[qb])) {                 // wave-uniform: skip the O rescale while no row's max moves
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+                for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx * cs);           // running max in the exp2 domain (cs > 0)
-        if (__any(mnew != m)) {                         // wave-uniform: skip the O rescale while no row's max moves
-            const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-#pragma unroll
-            for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) O[vt][r] *= alpha;
-            l *= alpha;
-            m = mnew;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) S[t][r] = __builtin_amdgcn_exp2f(fmaf(S[t][r], cs, -m));
-        float psum = 0.f;
-        if (!ones_col) {
+                    for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
+                l[qb] *= alpha;
+                m[qb] = mnew;
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) psum += S[t][r];
-            l += psum;
+                for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(fmaf(S[qb][t][r], cs, -m[qb]));
+            if (!ones_col) {
+                float psum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) psum += S[qb][t][r];
+                l[qb] += psum;
+            }
         }
         // O^T += V^T P^T
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
-                bf16x8 pf = acc_to_frag(S[t], sh);
+                bf16x8 pf[QB];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) pf[qb] = acc_to_frag(S[qb][t], sh);
 #pragma unroll
                 for (int vt = 0; vt < VT; ++vt) {
                     bf16x8 vf = lds_tr_frag(sV, VSTRIDE, 32 * t + 16 * sh, 32 * vt, lane);
-                    O[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, O[vt], 0, 0, 0);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], O[qb][vt], 0, 0, 0);
                 }
             }
         if (more) {                                     // the other buffer: its last readers passed the previous barrier
@@ -289,36 +310,40 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_fwd_kernel(AttnPa
         }
         __syncthreads();
     }
-    float ltot;
-    if (ones_col) {
-        // row d of O^T lives in tile d/32, register (rin&3) + 4*(rin>>3) of the lane half (rin>>2)&1, rin = d%32
-        const int vt0 = d >> 5, rin = d & 31, hh = (rin >> 2) & 1, reg = (rin & 3) + 4 * (rin >> 3);
-        float lv = 0.f;
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt)
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + 32 * qb;
+        float ltot;
+        if (ones_col) {
+            // row d of O^T lives in tile d/32, register (rin&3) + 4*(rin>>3) of the lane half (rin>>2)&1, rin = d%32
+            const int vt0 = d >> 5, rin = d & 31, hh = (rin >> 2) & 1, reg = (rin & 3) + 4 * (rin >> 3);
+            float lv = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (vt == vt0 && r == reg) lv = O[vt][r];
-        ltot = __shfl(lv, c + 32 * hh, 64);
-    } else {
-        ltot = l + __shfl_xor(l, 32, 64);
-    }
-    const float inv = 1.0f / ltot;
-    if (q < p.N) {
-        uint16_t* orow = p.o + ((size_t)b * p.N + q) * p.ldo + head * d;
+            for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-        for (int vt = 0; vt < VT; ++vt)
+                for (int r = 0; r < 16; ++r)
+                    if (vt == vt0 && r == reg) lv = O[qb][vt][r];
+            ltot = __shfl(lv, c + 32 * hh, 64);
+        } else {
+            ltot = l[qb] + __shfl_xor(l[qb], 32, 64);
+        }
+        const float inv = 1.0f / ltot;
+        if (q < p.N) {
+            uint16_t* orow = p.o + ((size_t)b * p.N + q) * p.ldo + head * d;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int d0 = 32 * vt + 8 * g + 4 * h;
-                if (d0 < d) {
-                    uint2 w;
-                    w.x = pack_bf16x2(O[vt][4 * g] * inv, O[vt][4 * g + 1] * inv);
-                    w.y = pack_bf16x2(O[vt][4 * g + 2] * inv, O[vt][4 * g + 3] * inv);
-                    *(uint2*)(orow + d0) = w;
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int d0 = 32 * vt + 8 * g + 4 * h;
+                    if (d0 < d) {
+                        uint2 w;
+                        w.x = pack_bf16x2(O[qb][vt][4 * g] * inv, O[qb][vt][4 * g + 1] * inv);
+                        w.y = pack_bf16x2(O[qb][vt][4 * g + 2] * inv, O[qb][vt][4 * g + 3] * inv);
+                        *(uint2*)(orow + d0) = w;
+                    }
                 }
-            }
-        if (h == 0 && p.lse) p.lse[((size_t)b * p.H + head) * p.N + q] = (m + log2f(ltot)) * 0.6931471805599453f;
+            if (h == 0 && p.lse) p.lse[((size_t)b * p.H + head) * p.N + q] = (m[qb] + log2f(ltot)) * 0.6931471805599453f;
+        }
     }
 }
 
@@ -709,17 +734,24 @@ static int dkv_qsplit(int B, int H, int N, int M, int d) {
 // =============================================================================================
 // host dispatch
 // =============================================================================================
-template <int KS, int VT>
-static int launch_fwd(const AttnParams& p, hipStream_t s) {
+template <int KS, int VT, int QB>
+static int launch_fwd_q(const AttnParams& p, hipStream_t s) {
     size_t lds = 2 * (64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE) + 2 * 68 * 4;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, VT, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((p.N + 127) / 128, p.B * p.H);
-    hipLaunchKernelGGL((attn_fwd_kernel<KS, VT>), grid, dim3(256), lds, s, p);
+    dim3 grid((p.N + 128 * QB - 1) / (128 * QB), p.B * p.H);
+    hipLaunchKernelGGL((attn_fwd_kernel<KS, VT, QB>), grid, dim3(256), lds, s, p);
     return adap_check_launch("attn_fwd");
+}
+
+template <int KS, int VT>
+static int launch_fwd(const AttnParams& p, hipStream_t s) {
+    // two query blocks per wave when that still leaves >= 2 workgroups per CU's worth of work (the 64x64 level)
+    if (KS <= 4 && (long)((p.N + 255) / 256) * p.B * p.H >= 512) return launch_fwd_q<KS, VT, 2>(p, s);
+    return launch_fwd_q<KS, VT, 1>(p, s);
 }
 
 template <int KS, int VT>

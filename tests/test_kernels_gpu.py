@@ -247,6 +247,9 @@ ATTN_CASES = [
     (2, 8, 96, 40, 8, False),            # narrow test model dims
     (2, 8, 96, 96, 16, True),
     (1, 8, 64, 64, 32, False),
+    # the 64x64 level at full size: enough workgroups for the two-query-blocks-per-wave forward variant
+    (4, 8, 4096, 4096, 40, True),
+    (4, 8, 4096, 77, 40, False),
 ]
 
 
