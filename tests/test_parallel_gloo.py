@@ -79,3 +79,43 @@ def test_single_process_reducer_is_a_noop():
     red.reduce()
     red.wait()
     assert torch.equal(red.flat, g) and red.world == 1
+
+
+def _worker_shared_flat(rank, world, port, q):
+    """the optimiser-owned buffer form (GradReducer(flat=...)): gradients are views of a padded flat buffer somebody
+    else allocated (adaprompt_amd.ldm.prodigy.Prodigy.grad_buffer on the GPU); padding stays zero through the exchange."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from adaprompt_amd.parallel import GradReducer, init_distributed
+    init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)                          # 15 + 3 values
+    flat = torch.zeros(15 + 1 + 3 + 1)                   # groups padded to multiples of 4, as the optimiser lays them out
+    lin.weight.grad = flat[0:15].view(3, 5)
+    lin.bias.grad = flat[16:19]
+    red = GradReducer(list(lin.parameters()), flat=flat, bucket_bytes=32)
+    assert red.flat.data_ptr() == flat.data_ptr()
+    lin(torch.full((2, 5), float(rank + 1))).sum().backward()
+    mine = flat.clone()
+    red.reduce()
+    red.wait()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    ok = torch.allclose(flat, torch.stack(both).mean(0), rtol=1e-6, atol=1e-7)
+    q.put((rank, bool(ok), float(flat[15]), float(flat[19])))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_on_a_shared_flat_buffer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shared_flat, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, pad0, pad1 in res:
+        assert ok and pad0 == 0.0 and pad1 == 0.0, (rank, ok, pad0, pad1)
