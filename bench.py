@@ -333,6 +333,59 @@ def main():
                     "others": {**{k: fam(v, "TFLOP/s") for k, v in summ.items() if k != dom and (k.startswith("conv") or "attention" in k)},
                                **{k: fam(v, "GB/s") for k, v in summ.items() if k.startswith("groupnorm")}}}
 
+    # ---- the north star's two named aggregates, measured in isolation on the step's own modules (HIP events, 20
+    # launches each): self-attention at the 64x64 level against the bf16 MFMA peak, and one 320->320 ResBlock at
+    # 64x64 against the HBM peak over its COMPULSORY bytes (read x, write out, both 3x3 weight sets, the
+    # embedding row; everything between stays on chip in the ideal).  The second number is reported because the
+    # north star asks for it; with 60 GFLOP per 49 MB the block sits far on the compute side of the ridge, so its
+    # HBM fraction is structurally tiny (DESIGN.md section 3 / SURVEY 7 "roofline honesty").
+    aggregates = None
+    if rank == 0 and not args.no_roofline:
+        def timed(fn, n=20):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n * 1e-3
+        C, N = 320, 4096
+        qkv = (torch.randn(B, N, 3 * C, device=device, generator=gen)).to(torch.bfloat16)
+        q_, k_, v_ = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        o_, lse_ = ops.attention_fwd(q_, k_, v_, 8)
+        do_ = torch.randn(B, N, C, device=device, generator=gen).to(torch.bfloat16)
+        t_f = timed(lambda: ops.attention_fwd(q_, k_, v_, 8))
+        t_b = timed(lambda: ops.attention_bwd(q_, k_, v_, o_, do_, lse_, 8))
+        fl = 4.0 * B * 8 * N * N * 40
+        rb = ld.model.diffusion_model.input_blocks[1][0]
+        xr = torch.randn(B, 64, 64, C, device=device, generator=gen)
+        er = torch.randn(B, 4 * C, device=device, generator=gen)
+        with torch.no_grad():
+            t_rf = timed(lambda: rb(xr, er))
+        xg = xr.clone().requires_grad_(True)
+        go = torch.randn(B, 64, 64, C, device=device, generator=gen)
+
+        def rb_fb():
+            xg.grad = None
+            rb(xg, er).backward(go)
+        t_rfb = timed(rb_fb)
+        rb_bytes = 4.0 * (2 * B * 64 * 64 * C + 2 * 9 * C * C + B * 4 * C)
+        rb_flops = 2.0 * 2 * B * 64 * 64 * C * C * 9
+        aggregates = {
+            "attention_self_64x64": {"shape": f"B{B} h8 N{N} d40", "fwd_us": round(t_f * 1e6, 1), "bwd_us": round(t_b * 1e6, 1),
+                                     "fwd_tflops": round(fl / t_f / 1e12, 1), "bwd_tflops": round(2.5 * fl / t_b / 1e12, 1),
+                                     "fwd_frac_of_bf16_mfma_peak": round(fl / t_f / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                     "bwd_frac_of_bf16_mfma_peak": round(2.5 * fl / t_b / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "resblock_320_64x64": {"fwd_us": round(t_rf * 1e6, 1), "fwd_bwd_us": round(t_rfb * 1e6, 1),
+                                   "compulsory_bytes_fwd": int(rb_bytes),
+                                   "fwd_frac_of_hbm_peak": round(rb_bytes / t_rf / 8e12, 4),
+                                   "fwd_tflops": round(rb_flops / t_rf / 1e12, 1),
+                                   "fwd_frac_of_bf16_mfma_peak": round(rb_flops / t_rf / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+        }
+        del qkv, o_, lse_, do_, xr, er, xg, go
+
     # ---- extra leg, reported beside `value`: config 2's actual iteration mix -- VAE encode of 4, then the
     # Arc2Face teacher rolls ND in {1,3,5,7} steps out on HALF_BS instances and the student is distilled on them
     distill = None
@@ -476,6 +529,8 @@ def main():
             res["roofline"] = roofline
         if cpu is not None:
             res["cpu_baseline"] = cpu
+        if aggregates is not None:
+            res["north_star_aggregates"] = aggregates
         if distill is not None:
             res["config2_distill_mix"] = distill
         if ddim is not None:
