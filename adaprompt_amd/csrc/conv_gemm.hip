@@ -1074,6 +1074,239 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvParams p) {
     else halo_body<BN, 2, WIDE>(p);                                                              // waves 4-7
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant of the stencil-window kernel.  The 512-thread kernel above owns a whole CU (144 KB of
+// LDS), so a tile's prologue (first window + weights in flight) and epilogue (192 KB of stores per tile, all CUs at
+// once) overlap with nothing.  Here a workgroup is FOUR waves (one per SIMD) on the same 256 px x 128 ch tile, each wave
+// 64 px x 128 ch (128 accumulator registers), K slices of 32 channels (64-B LDS rows): 2 x 24 KB window + 3 x 8 KB
+// weight ring = 72 KB, so two workgroups share a CU and one's prologue / epilogue / barrier waits run under the
+// other's MFMAs.  L2 -> LDS bytes per flop are unchanged (same tile), LDS reads drop from 16 to 12 ds_read_b128 per
+// 32 MFMAs (the weight fragments are shared by 4 pixel tiles... the window fragments by 8 channel tiles).
+// 64-B rows: a ds_read_b128 fragment covers 16 consecutive rows x 4 chunks = 1 KB; the hardware's 16-lane groups mix
+// rows {0-3, 12-15} of one chunk with rows {4-11} of the next, which collide 2-way on (row mod 4); XOR-ing the chunk
+// with 2 where bit 2 of the row key (window column / weight row) is set separates them for every alignment.
+template <int BN, bool WIDE>
+__device__ __forceinline__ void win32_body(const ConvParams& p) {
+    constexpr int HALO_TH = HaloShape<WIDE>::TH, HALO_TW = HaloShape<WIDE>::TW, HALO_W = HaloShape<WIDE>::W;
+    constexpr int HALO_SLOTS = HaloShape<WIDE>::SLOTS;
+    constexpr int MT = BN / 16;                           // every wave holds all BN channels of its 64 pixels
+    constexpr int PT = 4;
+    constexpr int A_STAGE = HALO_PASSES * 64 * 64;        // 384 slots x 64 B = 24 KB
+    constexpr int B_STAGE = BN * 64;
+    constexpr int BPASS = (BN + 63) / 64;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                       // [2][384 slots][64 B]
+    char* sB = smem + 2 * A_STAGE;         // [3][BN][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..3 = pixel quarter
+
+    const int tiles_x = p.Win / HALO_TW, tiles_y = p.Hin / HALO_TH;
+    const int nwg = p.ntiles_m * p.ntiles_n;
+    if ((int)blockIdx.x >= nwg) return;
+
+    int ch_begin = 0, ch_end = p.ktiles_per_tap;          // split-K plan is in 64-channel units (host)
+    if (p.ksplit > 1) {
+        int per = (p.ktiles_per_tap + p.ksplit - 1) / p.ksplit;
+        ch_begin = blockIdx.z * per;
+        ch_end = min(p.ktiles_per_tap, ch_begin + per);
+    }
+    if (ch_end <= ch_begin) return;
+    const int c32_begin = 2 * ch_begin, nch = 2 * (ch_end - ch_begin);     // 32-channel slices
+
+    // staging: a DMA instruction moves 1 KB = 16 rows x 64 B; thread -> row (tid >> 2) of each 64-row pass, chunk tid & 3
+    const int srow = tid >> 2;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tn = bid % p.ntiles_n;
+    int tm = bid / p.ntiles_n;
+    const int tx = tm % tiles_x;
+    tm /= tiles_x;
+    const int ty = tm % tiles_y;
+    const int bimg = tm / tiles_y;
+    const int y0 = ty * HALO_TH, x0 = tx * HALO_TW, n0 = tn * BN;
+    unsigned a_base[HALO_PASSES], b_base[BPASS];
+#pragma unroll
+    for (int i = 0; i < HALO_PASSES; ++i) {
+        int sidx = 64 * i + srow;
+        int hr = sidx / HALO_W, hc = sidx - hr * HALO_W;
+        int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+        bool ok = sidx < HALO_SLOTS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        int lchunk = (lane & 3) ^ ((hc >> 1) & 2);
+        a_base[i] = ok ? (unsigned)((((bimg * p.Hin + iy) * p.Win + ix) * (int)p.ldx + lchunk * 8) * 2) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+        int r = srow + 64 * i;
+        int n = n0 + r;
+        int wchunk = (lane & 3) ^ ((r >> 1) & 2);
+        b_base[i] = (r < BN && n < p.Cout) ? (unsigned)((n * p.Cin + wchunk * 8) * 2) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    auto stage_a = [&](int buf, int c32) {                  // HALO_PASSES DMA instructions per wave
+        char* base = sA + buf * A_STAGE + wv * 1024;
+#pragma unroll
+        for (int i = 0; i < HALO_PASSES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(base + i * 4096), 16,
+                                                     a_base[i] + (unsigned)(c32 * 64), 0, 0, 0);
+    };
+    auto stage_b = [&](int buf, int c32, int tap) {         // BPASS DMA instructions per wave
+        const unsigned tapw = (unsigned)((tap * p.Cout * p.Cin + c32 * 32) * 2);
+        char* base = sB + buf * B_STAGE + wv * 1024;
+#pragma unroll
+        for (int i = 0; i < BPASS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(base + i * 4096), 16, b_base[i] + tapw, 0, 0, 0);
+    };
+    static_assert(BN % 64 == 0, "every wave stages BPASS weight pieces");
+    constexpr int nB = BPASS;
+
+    f32x4 acc[MT][PT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+    // fragment offsets: the key depends on the window column only, (hc + 16) has the same key, so of the 4 pixel
+    // fragments and 9 taps only the three kx variants live in registers; everything else is an immediate
+    int aoff[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        int hc = frow + kx;
+        int sl = (WIDE ? 2 * wv : 4 * wv) * HALO_W + hc;
+        aoff[kx] = sl * 64 + ((fchunk ^ ((hc >> 1) & 2)) << 4);
+    }
+    const int woff = frow * 64 + ((fchunk ^ ((frow >> 1) & 2)) << 4);      // + i * 1024 (16 rows keep the key)
+
+    bf16x8 fw[MT], fx[PT];
+    for (int ci = 0; ci < nch; ++ci) {
+        if (ci == 0) {
+            stage_a(0, c32_begin);
+            stage_b(0, c32_begin, 0);
+            stage_b(1, c32_begin, 1);
+        }
+        const bool last_chunk = ci + 1 == nch;
+        const char* a = sA + (ci & 1) * A_STAGE;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool more_steps = tap < 8 || !last_chunk;
+            if ((tap == 1 || tap == 2) && !last_chunk) {
+                if (nB == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (nB == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else if (more_steps) {
+                if (nB == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (nB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!(p.dbg & 1)) {
+                const int nb = (tap + 2) % 3;
+                if (tap + 2 < 9) stage_b(nb, c32_begin + ci, tap + 2);
+                else if (!last_chunk) stage_b(nb, c32_begin + ci + 1, tap + 2 - 9);
+                if (tap == 0 && !last_chunk) stage_a((ci + 1) & 1, c32_begin + ci + 1);
+            }
+            if (p.dbg & 2) continue;
+            const char* b = sB + (tap % 3) * B_STAGE;
+            const char* at = a + (tap / 3) * (HALO_W * 64) + aoff[tap % 3];
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                fx[j] = *(const bf16x8*)(at + (WIDE ? (j >> 1) * (HALO_W * 64) + (j & 1) * (16 * 64) : j * (HALO_W * 64)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fw[i] = *(const bf16x8*)(b + woff + i * 1024);
+            // All twelve fragment reads are issued before the first MFMA: left alone, the compiler reloads ONE weight
+            // register quad just in time and exposes the LDS latency eight times per step.  The empty asm pins the
+            // first eight fragments (and, by its memory clobber, the issue of the other four) ahead of the first half
+            // of the MFMAs; the second half waits only for the rest.
+            static_assert(MT == 8, "fragment pinning below is written for the 128-channel tile");
+            asm volatile("" : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]), "+v"(fx[3]), "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]),
+                         "+v"(fw[3]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(fw[4]), "+v"(fw[5]), "+v"(fw[6]), "+v"(fw[7]));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 4; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (p.dbg & 4) return;
+    const int M = p.B * p.Hin * p.Win;
+    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int yy = y0 + (WIDE ? 2 * wv + (j >> 1) : 4 * wv + j), xx = x0 + (WIDE ? (j & 1) * 16 : 0) + frow;
+        const int m = (bimg * p.Hin + yy) * p.Win + xx;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int c0 = n0 + i * 16 + fchunk * 4;
+            if (c0 < p.Cout) {
+                if (slab) {
+                    *(float4*)(slab + (size_t)m * p.Cout + c0) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+                    if (p.bias) {
+                        float4 t = *(const float4*)(p.bias + c0);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    }
+                    if (p.chan_add) {
+                        float4 t = *(const float4*)(p.chan_add + (size_t)bimg * p.ld_ca + c0);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    }
+                    if (p.residual) {
+                        float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    }
+                    if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.y16) {
+                        uint2 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BN, bool WIDE>
+__global__ __launch_bounds__(256, 2) void conv3x3_win32_kernel(ConvParams p) {
+    win32_body<BN, WIDE>(p);
+}
+
+template <int BN, bool WIDE>
+static int launch_win32(const ConvParams& p, hipStream_t stream) {
+    size_t lds = 2 * HALO_PASSES * 64 * 64 + 3 * BN * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_win32_kernel<BN, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    const int nwg = p.ntiles_m * p.ntiles_n;
+    hipLaunchKernelGGL((conv3x3_win32_kernel<BN, WIDE>), dim3(nwg, 1, p.ksplit), dim3(256), lds, stream, p);
+    if (p.ksplit > 1) launch_reduce(p, stream);
+    return adap_check_launch("conv3x3_win32");
+}
+
 template <int BN, bool WIDE>
 static int launch_halo(const ConvParams& p, hipStream_t stream) {
     constexpr bool PP = BN == 128;      // ping-pong halves (see halo_body); the 160-wide tile spills with them
@@ -1199,7 +1432,7 @@ static bool narrow_tiles_enabled() {
 
 // which kernel the last adap_conv2d_nhwc call of this thread dispatched to (bench.py's per-kernel roofline):
 // 1000*variant + BN, variant 0 = conv_gemm_kernel f32 activations, 1 = conv_gemm_kernel bf16, 2 = conv_gemm_ring_kernel<256,.,3>,
-// 3 = conv_gemm_ring_kernel<128,.,4>, 4 = conv3x3_halo_kernel
+// 3 = conv_gemm_ring_kernel<128,.,4>, 4 = conv3x3_halo_kernel, 5 = conv3x3_win32_kernel
 static thread_local int g_last_variant = -1;
 extern "C" int adap_conv2d_last_variant(void) { return g_last_variant; }
 
@@ -1300,6 +1533,23 @@ extern "C" int adap_conv2d_nhwc(
     if (halo) {
         g_last_variant = 4000 + bn;
         p.ntiles_m = B * (Hin * Win / 256);
+        // The four-wave kernel (two workgroups per CU) overlaps prologue + epilogue, a large share of a short-K tile: in
+        // isolation +10 % on 128->128 @512^2 and +7 % on 640->640 @32^2 (<= 4 slices of 64 channels per workgroup), -6 %
+        // on 512->512 @128^2 (long K: the ping-pong kernel's steady state is better).  Inside the training step, where
+        // the VAE encode of the next micro-batch already shares the CUs from a second stream, the same rule measured 1 %
+        // SLOWER end to end (110.4 vs 111.5 img/s, two interleaved runs each), so it stays opt-in:
+        // ADAP_WIN32 = 0 never (default), 1 for <= 4 slices per workgroup, 2 always.
+        static int win32 = -1;
+        if (win32 < 0) {
+            const char* e = getenv("ADAP_WIN32");
+            win32 = e ? atoi(e) : 0;
+        }
+        const int slices_per_wg = (p.ktiles_per_tap + p.ksplit - 1) / p.ksplit;
+        if (bn == 128 && (win32 == 2 || (win32 == 1 && slices_per_wg <= 4))) {
+            g_last_variant = 5000 + bn;
+            if (halo_shape(Hin, Win) == 1) return launch_win32<128, true>(p, s);
+            return launch_win32<128, false>(p, s);
+        }
         if (halo_shape(Hin, Win) == 1) {
             if (bn == 160) return launch_halo<160, true>(p, s);
             return launch_halo<128, true>(p, s);

@@ -189,7 +189,7 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
         one_tap = "true" if (KH == 1 and stride == 1 and pad == 0 and up == 0) else "false"
         kname = {0: "conv_gemm_kernel<{bn}, true>", 1: "conv_gemm_kernel<{bn}, false>",
                  2: "conv_gemm_ring_kernel<256, {bn}, 3, {ot}>", 3: "conv_gemm_ring_kernel<128, {bn}, 4, {ot}>",
-                 4: "conv3x3_halo_kernel<{bn}, {pp}, {wide}>"}[v // 1000].format(
+                 4: "conv3x3_halo_kernel<{bn}, {pp}, {wide}>", 5: "conv3x3_win32_kernel<{bn}, {wide}>"}[v // 1000].format(
                      bn=v % 1000, ot=one_tap, pp="true" if v % 1000 == 128 else "false",
                      wide="true" if (H % 8 == 0 and W % 32 == 0) else "false")     # 8x32 patches, else 16x16
         TIMER.stop(kname, 2.0 * B * Ho * Wo * Cout * Cin * KH * KH, e0,
