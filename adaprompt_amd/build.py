@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadaprompt_hip.so")
-SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip"]
+SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip", "wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
 
 

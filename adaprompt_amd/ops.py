@@ -507,3 +507,69 @@ def add2(a, b, want_bf16=True):
     y16 = torch.empty(a.shape, device=a.device, dtype=BF16) if want_bf16 else None
     _lib.call("adap_add2", a.data_ptr(), lda, b.data_ptr(), ldb, y32.data_ptr(), _ptr(y16), rows, C, _stream())
     return y32, y16
+
+
+# --------------------------------------------------------------------------------------------
+# weight gradients (unfreeze_model: True)
+# --------------------------------------------------------------------------------------------
+
+def _byte_ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), device=device, dtype=torch.uint8)
+
+
+def conv2d_bwd_weight(x, dy, dw, dbias=None, KH=1, stride=1, pad=0, up=0, accumulate=True):
+    """dw f32 [Cout, Cin, KH, KH] (+)= the weight gradient of conv2d(x) -> dy; dbias f32 [Cout] (+)= sum of dy.
+    x [B,H,W,Cin], dy [B,Ho,Wo,Cout] pixel-major, f32 or bf16.  ``dw`` None: bias gradient only."""
+    assert x.dim() == 4 and dy.dim() == 4 and x.shape[0] == dy.shape[0]
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    xr, ldx = _rows_ld(x)
+    yr, ldy = _rows_ld(dy)
+    assert xr == B * H * W and yr == B * Ho * Wo
+    if dw is not None:
+        assert dw.dtype == F32 and dw.is_contiguous() and dw.numel() == Cout * Cin * KH * KH, (dw.shape, Cout, Cin, KH)
+    if dbias is not None:
+        assert dbias.dtype == F32 and dbias.is_contiguous() and dbias.numel() == Cout
+    nb = _lib.size_query("adap_conv2d_bwd_weight_workspace_bytes", B, Ho, Wo, Cin, Cout, KH, KH)
+    assert nb >= 0, "conv2d_bwd_weight: problem too large"
+    ws = _byte_ws(nb, x.device)
+    _lib.call("adap_conv2d_bwd_weight", x.data_ptr(), _dt(x), ldx, dy.data_ptr(), _dt(dy), ldy, _ptr(dw), _ptr(dbias),
+              B, H, W, Cin, Ho, Wo, Cout, KH, KH, stride, pad, up, int(bool(accumulate)), ws.data_ptr(), ws.numel(), _stream())
+
+
+def linear_bwd_weight(x, dy, dw, dbias=None, accumulate=True):
+    """dw f32 [O, I] (+)= dy^T x over all rows; x [..., I], dy [..., O] (f32 or bf16, channel dim contiguous)."""
+    xr, ldx = _rows_ld(x)
+    yr, ldy = _rows_ld(dy)
+    assert xr == yr, (x.shape, dy.shape)
+    I, O = x.shape[-1], dy.shape[-1]
+    x4 = x.as_strided((1, xr, 1, I), (xr * ldx, ldx, ldx, 1))
+    y4 = dy.as_strided((1, yr, 1, O), (yr * ldy, ldy, ldy, 1))
+    conv2d_bwd_weight(x4, y4, dw, dbias, 1, 1, 0, 0, accumulate)
+
+
+def colsum(dy, out, seg_rows=None, accumulate=True):
+    """out f32 [nseg, C] (+)= per-segment column sums of dy [..., C] (segments of ``seg_rows`` consecutive rows)."""
+    rows, ld = _rows_ld(dy)
+    C = dy.shape[-1]
+    seg_rows = rows if seg_rows is None else seg_rows
+    assert rows % seg_rows == 0 and out.dtype == F32 and out.is_contiguous() and out.numel() == rows // seg_rows * C
+    ws = torch.empty(_lib.size_query("adap_colsum_workspace_floats", rows, seg_rows, C), device=dy.device, dtype=F32)
+    _lib.call("adap_colsum", dy.data_ptr(), _dt(dy), ld, rows, seg_rows, C, out.data_ptr(), int(bool(accumulate)),
+              ws.data_ptr(), _stream())
+
+
+def norm_affine_bwd(dy, x, gamma, beta, mean, rstd, kind, act, dgamma, dbeta, accumulate=True):
+    """dgamma / dbeta f32 [C] (+)= the affine gradients of GroupNorm32 (kind 0; x [B,...,C], mean/rstd [B,32]) or
+    LayerNorm (kind 1; mean/rstd [rows]); ``dy`` is the gradient of the norm's output, after SiLU when act == 1."""
+    rows, ldx = _rows_ld(x)
+    yr, ldy = _rows_ld(dy)
+    C = x.shape[-1]
+    assert rows == yr and dy.shape[-1] == C
+    HW = rows // x.shape[0] if kind == 0 else 1
+    for t in (dgamma, dbeta):
+        assert t is None or (t.dtype == F32 and t.is_contiguous() and t.numel() == C)
+    ws = torch.empty(_lib.size_query("adap_colsum_workspace_floats", rows, rows, C), device=x.device, dtype=F32)
+    _lib.call("adap_norm_affine_bwd", dy.data_ptr(), _dt(dy), ldy, x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), _ptr(beta),
+              mean.data_ptr(), rstd.data_ptr(), kind, act, _ptr(dgamma), _ptr(dbeta), int(bool(accumulate)), ws.data_ptr(),
+              rows, HW, C, _stream())

@@ -217,6 +217,34 @@ int adap_prodigy_finish(double* state, const double* workspace, int nslots, doub
 int adap_prodigy_update(float* p, const float* m, const float* v, long n, const double* state, double eps,
                         double weight_decay_decoupled, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Weight gradients (`unfreeze_model: True`, ddpm.py:775-786: the UNet's own parameters train; what torch autograd's
+ * conv2d / linear / group_norm / layer_norm backward computes for nn.Conv2d openaimodel.py:229-247, nn.Linear
+ * attention.py:157-165, GroupNorm32 util.py:217-219, nn.LayerNorm attention.py:267-269).
+ *
+ * adap_conv2d_bwd_weight: dw f32 [Cout][Cin][KH][KW] (OIHW; a Linear is KH = KW = 1 with Hout = rows, Wout = 1),
+ * dbias f32 [Cout] or NULL, from x [B][Hin][Win][Cin] and dy [B][Hout][Wout][Cout] (f32 or bf16, row pitches ldx /
+ * lddy); stride / pad / up as in adap_conv2d_nhwc (up 0 or 1).  accumulate != 0 adds to dw / dbias.  workspace: 256-byte
+ * aligned device scratch of adap_conv2d_bwd_weight_workspace_bytes(...) bytes (transposed operands + split-K slabs). */
+long adap_conv2d_bwd_weight_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW);
+int adap_conv2d_bwd_weight(const void* x, int x_dtype, long ldx, const void* dy, int dy_dtype, long lddy,
+                           float* dw, float* dbias, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                           int KH, int KW, int stride, int pad, int up, int accumulate, void* workspace,
+                           long workspace_bytes, void* stream);
+/* out[seg][c] (+)= sum over the seg_rows rows of segment seg of dy[row][c] (rows % seg_rows == 0): bias gradients
+ * (one segment) and d emb_out of a ResBlock (one segment per image, openaimodel.py:264-268).  workspace:
+ * adap_colsum_workspace_floats(rows, seg_rows, C) floats.  Two-stage, fixed order, fp64 finish. */
+long adap_colsum_workspace_floats(long rows, long seg_rows, int C);
+int adap_colsum(const void* dy, int dy_dtype, long lddy, long rows, long seg_rows, int C, float* out,
+                int accumulate, float* workspace, void* stream);
+/* dgamma[c] (+)= sum dz * xhat, dbeta[c] (+)= sum dz over all rows, dz = dy (act 0) or dy * silu'(xhat*gamma+beta)
+ * (act 1).  kind 0: GroupNorm32, mean / rstd [B][32], rows = B*HW; kind 1: LayerNorm, mean / rstd [rows].
+ * workspace: adap_colsum_workspace_floats(rows, rows, C) floats. */
+int adap_norm_affine_bwd(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx,
+                         const float* gamma, const float* beta, const float* mean, const float* rstd, int kind,
+                         int act, float* dgamma, float* dbeta, int accumulate, float* workspace, long rows, int HW,
+                         int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
