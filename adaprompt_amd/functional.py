@@ -74,6 +74,53 @@ def clear_grad_copies():
     _GRAD16.clear()
 
 
+# ---------------------------------------------------------------------------------------------
+# weight gradients (`unfreeze_model: True`): a block's parameter tensors travel in P["train"] = {layer: (weight, bias)};
+# the block's backward adds their gradients straight into ``param.grad`` (a view of the optimiser's flat gradient
+# buffer when Prodigy.grad_buffer() set one up) -- autograd never sees the parameters, only the activation tape.
+# ---------------------------------------------------------------------------------------------
+def train_of(**layers):
+    """{name: (weight, bias)} of the given modules if any of their parameters trains (`unfreeze_model: True`,
+    ddpm.py:775-786), else None: the block Functions then also produce weight gradients (functional._dw_*)."""
+    out, any_grad = {}, False
+    for name, m in layers.items():
+        if m is None:
+            continue
+        w, b = m.weight, getattr(m, "bias", None)
+        out[name] = (w, b)
+        any_grad = any_grad or w.requires_grad or (b is not None and b.requires_grad)
+    return out if any_grad else None
+
+
+def _acc(param):
+    if param is None or not param.requires_grad:
+        return None
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+    return param.grad
+
+
+def _dw_conv(T, key, x, dy, K=1, stride=1, pad=0, up=0):
+    w, b = T[key]
+    dw, db = _acc(w), _acc(b)
+    if dw is not None or db is not None:
+        ops.conv2d_bwd_weight(x, dy, dw, db, K, stride, pad, up, accumulate=True)
+
+
+def _dw_lin(T, key, x, dy):
+    w, b = T[key]
+    dw, db = _acc(w), _acc(b)
+    if dw is not None or db is not None:
+        ops.linear_bwd_weight(x, dy, dw, db, accumulate=True)
+
+
+def _dw_norm(T, key, dy, x, gamma, beta, mean, rstd, kind, act):
+    w, b = T[key]
+    dg, db = _acc(w), _acc(b)
+    if dg is not None or db is not None:
+        ops.norm_affine_bwd(dy, x, gamma, beta, mean, rstd, kind, act, dg, db, accumulate=True)
+
+
 def _conv_bwd_data(g, pk, K, pad, bf16=False):
     """dX of a stride-1 conv: the same implicit GEMM with the flipped/transposed pack.  ``bf16``: the result only
     feeds a GroupNorm backward, so it is written as bf16 (half the traffic of both kernels)."""
@@ -107,13 +154,15 @@ class ResBlockFn(torch.autograd.Function):
             skip, _ = ops.conv2d(x, sk.fwd, sk.O4, 1, bias=sk.bias)
         out, _ = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip)
         ctx.P = P
-        ctx.save_for_backward(x, h1, m1, r1, m2, r2)
+        train = P.get("train") is not None          # weight gradients also need the two normalised activations
+        ctx.save_for_backward(x, h1, m1, r1, m2, r2, a1 if train else None, a2 if train else None)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, h1, m1, r1, m2, r2 = ctx.saved_tensors
+        x, h1, m1, r1, m2, r2, a1, a2 = ctx.saved_tensors
         P = ctx.P
+        T = P.get("train")
         g1w, g1b = P["gn1"]
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
@@ -121,12 +170,23 @@ class ResBlockFn(torch.autograd.Function):
         ga2 = _conv_bwd_data(gop, c2, 3, 1, bf16=True)
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
         ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
+        g_emb = None
+        if ctx.needs_input_grad[1]:     # d emb_out[b][c] = sum over the image's pixels of d h1 (openaimodel.py:264-268)
+            g_emb = torch.empty(x.shape[0], gh1.shape[-1], device=x.device, dtype=F32)
+            ops.colsum(gh1, g_emb, seg_rows=gh1.shape[1] * gh1.shape[2], accumulate=False)
+        if T is not None:
+            _dw_conv(T, "conv2", a2, gop, 3, 1, 1)
+            _dw_norm(T, "gn2", ga2, h1, g2w, g2b, m2, r2, 0, 1)
+            _dw_conv(T, "conv1", a1, gh1, 3, 1, 1)
+            _dw_norm(T, "gn1", ga1, x, g1w, g1b, m1, r1, 0, 1)
+            if sk is not None:
+                _dw_conv(T, "skip", x, gop, 1)
         if sk is None:          # identity skip: dx + g straight into a new tensor (no clone of g)
             gx, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, add_from=g)
         else:
             gx, _ = ops.conv2d(gop, sk.bwd, sk.bwd.shape[1], 1)
             _, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, accumulate_into=gx)
-        return _stash16(gx, gx16), None, None
+        return _stash16(gx, gx16), g_emb, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -180,8 +240,9 @@ class SpatialTransformerFn(torch.autograd.Function):
         out, _ = ops.linear(t3, pout.fwd, C, bias=pout.bias, residual=x.view(B, N, C))
         ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
         ctx.key_mask = key_mask
+        tr = P.get("train") is not None      # weight gradients also need each contraction's input operand
         ctx.save_for_backward(x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh,
-                              ctx_k, ctx_v)
+                              ctx_k, ctx_v, *((xn, n1, n2, n3, gg, t3) if tr else (None,) * 6))
         out = out.view(B, H, W, C)
         if capture:
             ctx.mark_non_differentiable(*cap)
@@ -191,8 +252,9 @@ class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         (x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh, ctx_k,
-         ctx_v) = ctx.saved_tensors
+         ctx_v, xn, n1, n2, n3, gg, t3) = ctx.saved_tensors
         P, heads = ctx.P, ctx.heads
+        T = P.get("train")
         B, H, W, C = x.shape
         N = H * W
         gop = _operand(g)            # bf16 copy if the producer left one; g itself (f32) is only the final addend
@@ -209,6 +271,11 @@ class SpatialTransformerFn(torch.autograd.Function):
         _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)           # bf16 [B,N,4C]
         ghh = ops.geglu_bwd(ggg, hh)                                               # bf16 [B,N,8C]
         gn3, _ = _lin_bwd(ghh, P["ff1"])
+        if T is not None:
+            _dw_lin(T, "proj_out", t3, gop)
+            _dw_lin(T, "ff2", gg, gt3h)
+            _dw_lin(T, "ff1", n3, ghh)
+            _dw_norm(T, "norm3", gn3, t2, P["norm3"][0], None, l3m, l3r, 1, 0)
         gt2, gt2h = ops.layernorm_bwd(gn3, t2, P["norm3"][0], l3m, l3r, accumulate_into=gt3, want_bf16=True)
         # cross attention
         _, go2 = _lin_bwd(gt2h, P["to_out2"], out_f32=False, out_bf16=True)
@@ -218,6 +285,12 @@ class SpatialTransformerFn(torch.autograd.Function):
         ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
                           dv=dkv2[..., C:])
         gn2, _ = _lin_bwd(dq2, P["q2"])
+        if T is not None:
+            _dw_lin(T, "to_out2", o2, gt2h)
+            _dw_lin(T, "q2", n2, dq2)
+            _dw_lin(T, "k2", ctx_k, dkv2[..., :C])
+            _dw_lin(T, "v2", ctx_v, dkv2[..., C:])
+            _dw_norm(T, "norm2", gn2, t1, P["norm2"][0], None, l2m, l2r, 1, 0)
         gt1, gt1h = ops.layernorm_bwd(gn2, t1, P["norm2"][0], l2m, l2r, accumulate_into=gt2, want_bf16=True)
         g_ck = g_cv = None
         if ctx.same_ctx:
@@ -234,10 +307,19 @@ class SpatialTransformerFn(torch.autograd.Function):
         ops.attention_bwd(qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:], o1, go1, lse1, heads, ctx.key_mask,
                           dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:])
         gn1, _ = _lin_bwd(dqkv1, P["qkv1"])
+        if T is not None:
+            _dw_lin(T, "to_out1", o1, gt1h)
+            _dw_lin(T, "q1", n1, dqkv1[..., :C])
+            _dw_lin(T, "k1", n1, dqkv1[..., C:2 * C])
+            _dw_lin(T, "v1", n1, dqkv1[..., 2 * C:])
+            _dw_norm(T, "norm1", gn1, t0, P["norm1"][0], None, l1m, l1r, 1, 0)
         gt0, gt0h = ops.layernorm_bwd(gn1, t0, P["norm1"][0], l1m, l1r, accumulate_into=gt1, want_bf16=True)
         # proj_in, GroupNorm
         _, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=False, out_bf16=True)
         gnw, gnb = P["norm"]
+        if T is not None:
+            _dw_lin(T, "proj_in", xn.view(B, N, C), gt0h)
+            _dw_norm(T, "norm", gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, 0)
         gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None
@@ -251,8 +333,9 @@ class ConvFn(torch.autograd.Function):
     openaimodel.py:138-164) or Upsample (nearest x2 then conv; openaimodel.py:95-123)."""
 
     @staticmethod
-    def forward(ctx, x, pk, mode):
-        ctx.pk, ctx.mode, ctx.in_hw = pk, mode, (x.shape[1], x.shape[2])
+    def forward(ctx, x, pk, mode, train=None):
+        ctx.pk, ctx.mode, ctx.in_hw, ctx.train = pk, mode, (x.shape[1], x.shape[2]), train
+        ctx.save_for_backward(x if train is not None else None)
         if mode == "down":
             y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 2, 1, bias=pk.bias)
         elif mode == "up":
@@ -266,6 +349,9 @@ class ConvFn(torch.autograd.Function):
         pk, mode = ctx.pk, ctx.mode
         if mode == "same":
             g = _operand(g)
+        if ctx.train is not None:
+            (x,) = ctx.saved_tensors
+            _dw_conv(ctx.train, "conv", x, g, 3, 2 if mode == "down" else 1, 1, 1 if mode == "up" else 0)
         if mode == "down":
             gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], 3, 1, 1, up=2, out_hw=ctx.in_hw)
         elif mode == "up":
@@ -273,28 +359,52 @@ class ConvFn(torch.autograd.Function):
         else:
             gx, gx16 = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], 3, 1, 1, out_f32=True, out_bf16=True)
             _stash16(gx, gx16)
-        return gx, None, None
+        return gx, None, None, None
 
 
 class OutHeadFn(torch.autograd.Function):
     """``out``: GroupNorm32(1e-5) -> SiLU -> conv3x3 320->4 (openaimodel.py:693-697)."""
 
     @staticmethod
-    def forward(ctx, h, gn, pk):
+    def forward(ctx, h, gn, pk, train=None):
         _, a, m, r = ops.groupnorm_fwd(h, gn[0], gn[1], 1e-5, 1)
         y, _ = ops.conv2d(a, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
-        ctx.gn, ctx.pk = gn, pk
-        ctx.save_for_backward(h, m, r)
+        ctx.gn, ctx.pk, ctx.train = gn, pk, train
+        ctx.save_for_backward(h, m, r, a if train is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        h, m, r = ctx.saved_tensors
+        h, m, r, a = ctx.saved_tensors
         pk = ctx.pk
-        g16 = ops.pad_cast_bf16(g.contiguous(), pk.bwd.shape[2])          # 4 -> 8 channels for the K dim
+        g = g.contiguous()
+        g16 = ops.pad_cast_bf16(g, pk.bwd.shape[2])          # 4 -> 8 channels for the K dim
         ga = _conv_bwd_data(g16, pk, 3, 1, bf16=True)
+        if ctx.train is not None:
+            _dw_conv(ctx.train, "conv", a, g, 3, 1, 1)
+            _dw_norm(ctx.train, "gn", ga, h, ctx.gn[0], ctx.gn[1], m, r, 0, 1)
         gh, _ = ops.groupnorm_bwd(ga, h, ctx.gn[0], ctx.gn[1], m, r, 1)
-        return gh, None, None
+        return gh, None, None, None
+
+
+class InConvFn(torch.autograd.Function):
+    """``input_blocks.0.0`` when the UNet trains: conv3x3 4 -> 320 on the noisy latent.  The latent itself gets no
+    gradient (it is data); ``anchor`` is any tensor that requires grad, so that autograd calls this backward -- and with
+    it, because the output now requires grad, every later block's -- even when no context gradient is wanted."""
+
+    @staticmethod
+    def forward(ctx, x, pk, train, anchor):
+        x16 = ops.pad_cast_bf16(x, pk.I8)
+        y, _ = ops.conv2d(x16, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
+        ctx.train = train
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        _dw_conv(ctx.train, "conv", x, _operand(g), 3, 1, 1)
+        return None, None, None, None
 
 
 class ConcatFn(torch.autograd.Function):

@@ -103,6 +103,12 @@ class SpatialTransformer(nn.Module):
             "ff2": wc.get("ff2", b.ff.net[2].weight, b.ff.net[2].bias),
             "proj_out": wc.get("proj_out", self.proj_out.weight, self.proj_out.bias),
         }
+        P["train"] = None
+        if torch.is_grad_enabled():
+            P["train"] = HF.train_of(norm=self.norm, proj_in=self.proj_in, norm1=b.norm1, norm2=b.norm2, norm3=b.norm3,
+                                   q1=b.attn1.to_q, k1=b.attn1.to_k, v1=b.attn1.to_v, to_out1=b.attn1.to_out[0],
+                                   q2=b.attn2.to_q, k2=b.attn2.to_k, v2=b.attn2.to_v, to_out2=b.attn2.to_out[0],
+                                   ff1=b.ff.net[0].proj, ff2=b.ff.net[2], proj_out=self.proj_out)
         if same_ctx:
             P["kv2"] = wc.get("kv2", [b.attn2.to_k.weight, b.attn2.to_v.weight])
         else:

@@ -18,6 +18,7 @@ from functools import partial
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .... import functional as HF
 from .... import ops
@@ -56,7 +57,7 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[-1] == self.channels
-        return HF.ConvFn.apply(x, self._wc.get("conv", self.conv.weight, self.conv.bias), "up")
+        return HF.ConvFn.apply(x, self._wc.get("conv", self.conv.weight, self.conv.bias), "up", HF.train_of(conv=self.conv))
 
 
 class Downsample(nn.Module):
@@ -72,7 +73,7 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[-1] == self.channels
-        return HF.ConvFn.apply(x, self._wc.get("op", self.op.weight, self.op.bias), "down")
+        return HF.ConvFn.apply(x, self._wc.get("op", self.op.weight, self.op.bias), "down", HF.train_of(conv=self.op))
 
 
 class ResBlock(TimestepBlock):
@@ -99,17 +100,26 @@ class ResBlock(TimestepBlock):
         """x pixel-major [B,H,W,C]; ``emb_out`` = emb_layers(emb) when the UNet has already computed
         all blocks' projections in one launch, else it is computed here."""
         if emb_out is None:
-            emb_out = ops.linear_small(emb, self.emb_layers[1].weight, self.emb_layers[1].bias, pre_silu=True)
+            lin = self.emb_layers[1]
+            if torch.is_grad_enabled() and (emb.requires_grad or lin.weight.requires_grad):
+                # the time-embedding path trains: [B,1280] x [1280,Cout], left to torch autograd (not a hot op)
+                emb_out = F.linear(F.silu(emb), lin.weight, lin.bias)
+            else:
+                emb_out = ops.linear_small(emb, lin.weight, lin.bias, pre_silu=True)
         wc = self._wc
         sk = None
-        if not isinstance(self.skip_connection, nn.Identity):
+        identity = isinstance(self.skip_connection, nn.Identity)
+        if not identity:
             sk = wc.get("skip", self.skip_connection.weight, self.skip_connection.bias)
         P = {"gn1": (self.in_layers[0].weight, self.in_layers[0].bias),
              "gn2": (self.out_layers[0].weight, self.out_layers[0].bias),
              "conv1": wc.get("conv1", self.in_layers[2].weight, self.in_layers[2].bias),
              "conv2": wc.get("conv2", self.out_layers[3].weight, self.out_layers[3].bias),
-             "skip": sk}
-        return HF.ResBlockFn.apply(x, emb_out, P)
+             "skip": sk,
+             "train": HF.train_of(gn1=self.in_layers[0], conv1=self.in_layers[2], gn2=self.out_layers[0],
+                                conv2=self.out_layers[3], skip=None if identity else self.skip_connection)
+             if torch.is_grad_enabled() else None}
+        return HF.ResBlockFn.apply(x, emb_out.float().contiguous() if emb_out.dtype != torch.float32 else emb_out, P)
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
@@ -134,6 +144,9 @@ class _InConv(nn.Conv2d):
         pk = self._wc.get("w", self.weight, self.bias)
         if x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the noisy latent is not on the training hot path")
+        train = HF.train_of(conv=self) if torch.is_grad_enabled() else None
+        if train is not None:
+            return HF.InConvFn.apply(x, pk, train, self.weight if self.weight.requires_grad else self.bias)
         x16 = ops.pad_cast_bf16(x, pk.I8)
         y, _ = ops.conv2d(x16, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
         return y
@@ -338,9 +351,15 @@ class UNetModel(nn.Module):
 
         t_emb = timestep_embedding(timesteps, self.model_channels)
         te = self.time_embed
-        emb = ops.linear_small(ops.linear_small(t_emb, te[0].weight, te[0].bias, post_silu=True), te[2].weight,
-                               te[2].bias)
-        emb_outs = self._emb_projections(emb)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in te.parameters()):
+            emb = F.linear(F.silu(F.linear(t_emb, te[0].weight, te[0].bias)), te[2].weight, te[2].bias)
+        else:
+            emb = ops.linear_small(ops.linear_small(t_emb, te[0].weight, te[0].bias, post_silu=True), te[2].weight,
+                                   te[2].bias)
+        # frozen: every ResBlock's projection of emb in one launch; training: per block under autograd (ResBlock.forward)
+        trains_emb = torch.is_grad_enabled() and (emb.requires_grad or any(
+            b.emb_layers[1].weight.requires_grad for b in self._resblocks()))
+        emb_outs = None if trains_emb else self._emb_projections(emb)
 
         def run(seq, h, layer_idx):
             return seq(h, emb, partial(get_layer_context, layer_idx), mask=img_mask, emb_outs=emb_outs)
@@ -383,7 +402,8 @@ class UNetModel(nn.Module):
             self.set_cross_attn_flags(ca_flag_dict=old, ca_layer_indices=idxs)
 
         o = self.out
-        eps = HF.OutHeadFn.apply(h, (o[0].weight, o[0].bias), self._wc.get("out", o[2].weight, o[2].bias))
+        eps = HF.OutHeadFn.apply(h, (o[0].weight, o[0].bias), self._wc.get("out", o[2].weight, o[2].bias),
+                                 HF.train_of(gn=o[0], conv=o[2]) if torch.is_grad_enabled() else None)
         return eps.permute(0, 3, 1, 2)                                    # back to the reference's NCHW
 
 

@@ -20,12 +20,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def build_unet(cfg):
+def build_unet(cfg, train=False):
+    """``train=False``: the shipped config (`unfreeze_model: False`, yaml:26) -- gradients go to the context only."""
     from adaprompt_amd.ldm.util import instantiate_from_config
     m = instantiate_from_config({"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(cfg)})
     P = "model.diffusion_model."          # tensors are seeded by their full checkpoint name
     sd = {k[len(P):]: v for k, v in synth.synthetic_unet_state_dict(cfg, prefix=P).items()}
     m.load_state_dict(sd, strict=True)
+    m.requires_grad_(train)
     return m.to(dev()).eval()
 
 
@@ -99,6 +101,67 @@ def test_unet_narrow_mixhijk():
 def test_unet_sd15_full_size_vs_reference_golden():
     """the 859.5 M-parameter SD-1.5 UNet on the output of the reference's UNetModel (config 1) + grad wrt context"""
     run_unet_case(dict(synth.SD15_UNET), "sd15_recon", load_golden("unet_sd15_recon"), True, subs_grad=True)
+
+
+def test_unet_narrow_weight_gradients_vs_oracle():
+    """`unfreeze_model: True` (ddpm.py:775-786): every one of the UNet's parameters receives its gradient from the HIP
+    backward (conv / Linear dW and bias, GroupNorm / LayerNorm affine, the time-embedding MLP), compared tensor by tensor
+    with autograd through the fp32 oracle fed the same upstream gradient; the context gradient stays that of the frozen
+    run (the data-gradient path is untouched)."""
+    from oracle import ldm_oracle as O
+    cfg = dict(NARROW)
+    B = 2
+    P = "model.diffusion_model."
+    usd = synth.synthetic_unet_state_dict(cfg, prefix=P)
+    x = synth.synthetic_input("unet.wg.x", (B, 4, 64, 64))
+    t = torch.tensor([120, 870])
+    ctx = synth.synthetic_input("unet.wg.ctx", (16 * B, 77, cfg["context_dim"]))
+    im = border_mask(B, 64, 64, 6)
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": False, "placeholder2indices": None, "img_mask": im}
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in usd.items()}
+    ctx_ref = ctx.clone().requires_grad_(True)
+    eps_ref = O.unet_forward(sd_ref, cfg, x, t, ctx_ref, dict(extra), prefix=P)
+    g_eps = synth.synthetic_input("unet.wg.gw", tuple(eps_ref.shape))
+    eps_ref.backward(g_eps)
+
+    def run(train):
+        unet = build_unet(cfg, train=train)
+        c = ctx.to(dev()).clone().requires_grad_(True)
+        e = dict(extra, img_mask=im.to(dev()))
+        eps = unet(x.to(dev()), t.to(dev()), context=c, context_in=None, extra_info=e)
+        eps.backward(g_eps.to(dev()))
+        return unet, c.grad
+
+    unet, gctx = run(True)
+    _, gctx_frozen = run(False)
+    # Not bit-identical: the training run computes the time-embedding MLP under torch autograd (rocBLAS) instead of the
+    # few-row HIP kernel; last-bit differences there flip bf16 roundings of the first activations and the two runs end up
+    # with independent rounding noise (measured: eps differs by 8e-3 between them, each is 9e-3 from the oracle).  What
+    # must hold is that the training run is as close to the oracle as the frozen one.
+    e_tr, e_fr = rel_err(gctx.cpu(), ctx_ref.grad), rel_err(gctx_frozen.cpu(), ctx_ref.grad)
+    print(f"[unet weight grads] context gradient vs oracle: training run {e_tr:.2e}, frozen run {e_fr:.2e}, "
+          f"between them {rel_err(gctx.cpu(), gctx_frozen.cpu()):.2e}")
+    assert e_tr < 1.25 * e_fr + 1e-3
+    assert rel_err(gctx.cpu(), ctx_ref.grad) < 5e-2
+    num = den = 0.0
+    worst = (0.0, None)
+    n = 0
+    for name, p in unet.named_parameters():
+        ref = sd_ref[P + name].grad
+        assert ref is not None, name
+        assert p.grad is not None, f"no gradient reached {name}"
+        got = p.grad.detach().float().cpu().reshape(ref.shape)
+        e = rel_err(got, ref)
+        if e > worst[0]:
+            worst = (e, name)
+        num += float((got.double() - ref.double()).pow(2).sum())
+        den += float(ref.double().pow(2).sum())
+        assert e < 8e-2, (name, e, float(ref.norm()))
+        n += 1
+    tot = (num / den) ** 0.5
+    print(f"[unet weight grads] {n} tensors, global rel L2 {tot:.3e}, worst {worst[1]} {worst[0]:.3e}")
+    assert n == len(sd_ref) and tot < 3e-2
 
 
 def build_vae(dd):
