@@ -191,6 +191,9 @@ class Prodigy(torch.optim.Optimizer):
             dec = float(g["weight_decay"]) if (g["weight_decay"] != 0 and g0["decouple"]) else 0.0
             _lib.call("adap_prodigy_update", self._flat[o:].data_ptr(), self._m[o:].data_ptr(),
                       self._v[o:].data_ptr(), k, st, float(g["eps"]), dec, s)
+        # the kernels wrote the parameters through raw pointers: tell torch, so that anything keyed on Tensor._version
+        # (the bf16 weight packs of a training UNet, functional.WeightCache) is rebuilt
+        torch.autograd.graph.increment_version([p for p, _, _ in self._views])
         return loss
 
     def zero_grad(self, set_to_none=False):

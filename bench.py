@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-ddim", action="store_true",
                     help="skip the extra leg that times config 5 (50-step DDIM at bs=8 with guidance + VAE decode)")
+    ap.add_argument("--no-unfrozen", action="store_true",
+                    help="skip the `unfreeze_model: True` leg (weight gradients + 4.5 GB optimiser / all-reduce payload)")
     ap.add_argument("--no-distill-mix", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
     args = ap.parse_args()
@@ -500,6 +502,67 @@ def main():
                 "images_per_sec": round(nb / dd_, 3), "finite": bool(torch.isfinite(img).all())}
         del dec, sampler, c, uc, img
 
+    # ---- config 3's second payload: `unfreeze_model: True` -- the UNet's 859.5 M parameters train too.
+    # Every block backward also produces weight gradients (csrc/wgrad.hip), Prodigy steps over hook + UNet + a
+    # CLIP-text-sized stand-in bucket (123 M, the third member of the reference's model group, ddpm.py:5179), and the
+    # per-micro-batch all-reduce carries all of it (~4.5 GB).  Runs last: it moves the UNet's weights.
+    unfrozen = None
+    if not args.no_unfrozen:
+        for p_ in ld.model.parameters():
+            p_.requires_grad_(True)
+        clip_standin = torch.nn.Parameter(torch.zeros(123_060_480, device=device))
+        groups = [{"params": list(hook.parameters())}, {"params": list(ld.model.parameters()) + [clip_standin]}]
+        del opt, reducer, sched
+        torch.cuda.empty_cache()
+        opt_u = Prodigy(groups, lr=1.0, betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, weight_decay=0.0)
+        all_u = [q for g_ in groups for q in g_["params"]]
+        red_u = GradReducer(all_u, flat=opt_u.grad_buffer)
+        sched_u = prodigy_linear_schedule(opt_u, max_steps=60000, warm_up_steps=500, scheduler_cycles=1)
+        pf_u = ld.make_prefetcher()
+
+        def usubmit(j):
+            pf_u.submit(batches[j % 2], torch.randn(B, 4, 64, 64, device=device, generator=gen))
+
+        def ustep(i):
+            t = torch.randint(0, 1000, (B,), device=device, generator=gen)
+            noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+            x_start = pf_u.get()
+            usubmit(i + 1)
+            loss, grad, out, aux = ld.shared_step(batches[i % 2], t=t, noise=noise, x_start=x_start)
+            red_u.wait()
+            out.backward(grad)
+            red_u.reduce()
+            if (i + 1) % ld.manual_accumulate_grad_batches == 0:
+                red_u.wait()
+                opt_u.step(clip_norm=ld.grad_clip)
+                red_u.zero()
+                sched_u.step()
+            return loss
+
+        usubmit(0)
+        UW, UK = 2, 6
+        for i in range(UW):
+            ustep(i)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(UW, UW + UK):
+            lu = ustep(i)
+        red_u.wait()
+        sync()
+        du = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([du], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            du = float(tt.item())
+        nparam = sum(q.numel() for q in all_u)
+        unfrozen = {"workload": "config 3, second payload: the same micro-batch with `unfreeze_model: True` -- weight gradients of "
+                                "all 686 UNet tensors, Prodigy over hook + UNet + a 123 M CLIP-text stand-in, all of it all-reduced",
+                    "trainable_params": nparam, "grad_allreduce_bytes": 4 * nparam if world > 1 else 0,
+                    "steps": UK, "ms_per_step": round(1e3 * du / UK, 2), "images_per_sec": round(world * B * UK / du, 2),
+                    "final_loss": round(float(lu), 5), "finite": bool(torch.isfinite(opt_u.param_buffer).all())}
+        del opt_u, red_u, sched_u, pf_u, clip_standin, groups, all_u
+        opt = reducer = sched = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
@@ -535,6 +598,8 @@ def main():
             res["config2_distill_mix"] = distill
         if ddim is not None:
             res["config5_ddim"] = ddim
+        if unfrozen is not None:
+            res["config3_unfrozen"] = unfrozen
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

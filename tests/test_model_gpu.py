@@ -164,6 +164,37 @@ def test_unet_narrow_weight_gradients_vs_oracle():
     assert n == len(sd_ref) and tot < 3e-2
 
 
+def test_unfrozen_unet_optimizer_step_rebuilds_weight_packs():
+    """after Prodigy has moved the UNet's parameters (raw-pointer kernels on its flat buffer) the next forward must use
+    the new weights: the bf16 packs are keyed on Tensor._version, which the step bumps.  A fresh module loaded with
+    the stepped state dict must give the bit-identical output."""
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    cfg = dict(NARROW)
+    B = 1
+    unet = build_unet(cfg, train=True)
+    x = synth.synthetic_input("unet.st.x", (B, 4, 64, 64)).to(dev())
+    t = torch.tensor([400]).to(dev())
+    ctx = synth.synthetic_input("unet.st.ctx", (16 * B, 77, cfg["context_dim"])).to(dev())
+    g = synth.synthetic_input("unet.st.g", (B, 4, 64, 64)).to(dev())
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": False, "placeholder2indices": None, "img_mask": None}
+    opt = Prodigy(list(unet.parameters()), lr=1.0, d0=1e-3)
+    opt.grad_buffer                                   # parameters and gradients move into the flat buffers
+    v0 = unet.out[2].weight._version
+    eps0 = unet(x, t, context=ctx, context_in=None, extra_info=dict(extra))
+    eps0.backward(g)
+    assert float(opt.grad_buffer.abs().sum()) > 0     # the block backward wrote into the optimiser's flat buffer
+    opt.step()
+    opt.zero_grad()
+    assert unet.out[2].weight._version > v0
+    eps1 = unet(x, t, context=ctx, context_in=None, extra_info=dict(extra))
+    assert rel_err(eps1.detach().cpu(), eps0.detach().cpu()) > 1e-3          # the weights moved
+    fresh = build_unet(cfg, train=True)
+    fresh.load_state_dict(unet.state_dict())
+    eps2 = fresh(x, t, context=ctx, context_in=None, extra_info=dict(extra))
+    assert torch.equal(eps1, eps2)
+
+
 def build_vae(dd):
     from adaprompt_amd.ldm.models.autoencoder import AutoencoderKL
     m = AutoencoderKL(dict(dd), None, 4)
