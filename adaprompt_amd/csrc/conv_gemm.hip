@@ -1587,23 +1587,42 @@ extern "C" int adap_conv2d_nhwc(
 //   mode 0: forward     out[t][o][i]      = w[o][i][ky][kx],  t = ky*KW + kx   (Cin padded to cin_pad with zeros)
 //   mode 1: data-grad   out[t][i][o]      = w[o][i][KH-1-ky][KW-1-kx]          (roles of Cin/Cout swapped, taps flipped)
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int O, int I,
-                                   int KH, int KW, int mode, int rows, int cols) {
-    // out is [taps][rows][cols]
-    long n = (long)KH * KW * rows * cols;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
-        int c = idx % cols;
-        long t2 = idx / cols;
-        int r = t2 % rows;
-        int t = t2 / rows;
-        int ky = t / KW, kx = t % KW;
+// out [taps][rows][cols] bf16 from w [O][I][KH][KW] f32.  mode 0: out[t][o][i] = w[o][i][t] (forward pack);
+// mode 1: out[t][i][o] = w[o][i][taps-1-t] (data-gradient pack: roles swapped, taps flipped).  A workgroup stages a
+// 32 (o) x 32 (i) x taps block through LDS so that both the f32 reads (runs of 32*taps floats per o) and the bf16 writes
+// (runs of 32 along the packed layout's fast dim) are contiguous -- a training UNet repacks all 859.5 M weights after
+// every optimiser step, and the element-wise gather this replaces ran at 1/7 of the HBM rate on the 3x3 layers.
+#define PK_T 32
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int O, int I,
+                                                          int taps, int mode, int rows, int cols) {
+    extern __shared__ float pk_tile[];              // [PK_T o][PK_T i * taps (+1 pad)]
+    const int pitch = PK_T * taps + 1;
+    const int o0 = blockIdx.y * PK_T, i0 = blockIdx.x * PK_T;
+    const int t = threadIdx.x;
+    const int run = PK_T * taps;
+    for (int idx = t; idx < PK_T * run; idx += 256) {
+        const int oo = idx / run, e = idx - oo * run;
+        const int ii = e / taps;
         float v = 0.f;
+        if (o0 + oo < O && i0 + ii < I) v = w[((long)(o0 + oo) * I + i0) * taps + e];
+        pk_tile[oo * pitch + e] = v;
+    }
+    __syncthreads();
+    // mode 0: the output's (row, col) = (o, i); mode 1: (i, o)
+    for (int idx = t; idx < taps * PK_T * PK_T; idx += 256) {
+        const int cc = idx % PK_T;
+        const int rr = (idx / PK_T) % PK_T;
+        const int tp = idx / (PK_T * PK_T);
+        int r, c;
+        float v;
         if (mode == 0) {
-            if (r < O && c < I) v = w[(((long)r * I + c) * KH + ky) * KW + kx];
+            r = o0 + rr; c = i0 + cc;
+            v = pk_tile[rr * pitch + cc * taps + tp];
         } else {
-            if (r < I && c < O) v = w[(((long)c * I + r) * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)];
+            r = i0 + rr; c = o0 + cc;
+            v = pk_tile[cc * pitch + rr * taps + (taps - 1 - tp)];
         }
-        out[idx] = f32_to_bf16(v);
+        if (r < rows && c < cols) out[((long)tp * rows + r) * cols + c] = f32_to_bf16(v);
     }
 }
 
@@ -1613,10 +1632,14 @@ extern "C" int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O,
     ADAP_REQUIRE(mode == 0 || mode == 1, ADAP_ERR_UNSUPPORTED, "pack_weight: mode %d", mode);
     ADAP_REQUIRE(mode == 0 ? (rows >= O && cols >= I) : (rows >= I && cols >= O), ADAP_ERR_SHAPE,
                  "pack_weight: rows/cols too small");
-    long n = (long)KH * KW * rows * cols;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                       (uint16_t*)out_bf16, O, I, KH, KW, mode, rows, cols);
+    const int taps = KH * KW;
+    ADAP_REQUIRE(taps >= 1 && taps <= 9, ADAP_ERR_UNSUPPORTED, "pack_weight: %d taps", taps);
+    // tiles cover the PADDED extents (rows/cols beyond O/I are written as zeros)
+    const int Op = mode == 0 ? rows : cols, Ip = mode == 0 ? cols : rows;
+    dim3 grid((Ip + PK_T - 1) / PK_T, (Op + PK_T - 1) / PK_T);
+    ADAP_REQUIRE(grid.y <= 65535, ADAP_ERR_SHAPE, "pack_weight: too many output channels");
+    const size_t lds = (size_t)PK_T * (PK_T * taps + 1) * sizeof(float);
+    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), lds, (hipStream_t)stream, w_oihw, (uint16_t*)out_bf16, O, I, taps,
+                       mode, rows, cols);
     return adap_check_launch("pack_weight");
 }

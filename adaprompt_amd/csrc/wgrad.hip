@@ -121,6 +121,35 @@ __global__ __launch_bounds__(256) void wg_scatter_kernel(const float* __restrict
     }
 }
 
+// dW[co][ci][tap] (+)= Tt[tap*Cin + ci][co]: the contraction ran with the (tap, ci) index as its ROW dimension (see
+// adap_conv2d_bwd_weight).  32 co x 32 ci x taps block through LDS: reads are runs of 32 co, writes runs of 32*taps.
+__global__ __launch_bounds__(256) void wg_scatter_t_kernel(const float* __restrict__ Tt, float* __restrict__ dw, int Cout, int Cin,
+                                                           int taps, int accumulate) {
+    extern __shared__ float sc_tile[];              // [32 co][32 ci * taps + 1]
+    const int pitch = 32 * taps + 1;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int t = threadIdx.x;
+    for (int idx = t; idx < taps * 32 * 32; idx += 256) {
+        const int cc = idx & 31;
+        const int ii = (idx >> 5) & 31;
+        const int tp = idx >> 10;
+        float v = 0.f;
+        if (co0 + cc < Cout && ci0 + ii < Cin) v = Tt[((long)tp * Cin + ci0 + ii) * Cout + co0 + cc];
+        sc_tile[cc * pitch + ii * taps + tp] = v;
+    }
+    __syncthreads();
+    const int run = 32 * taps;
+    for (int idx = t; idx < 32 * run; idx += 256) {
+        const int cc = idx / run, e = idx - cc * run;
+        const int ii = e / taps;
+        if (co0 + cc < Cout && ci0 + ii < Cin) {
+            const long o = ((long)(co0 + cc) * Cin + ci0) * taps + e;
+            const float v = sc_tile[cc * pitch + e];
+            dw[o] = accumulate ? dw[o] + v : v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column reductions over pixel rows.  rows are grouped in `nseg` segments of `seg_rows` (one segment = everything, or
 // one image); per segment and channel:  s1 = sum dz,  s2 = sum dz * xhat   (kind < 0: plain column sum of dy, s1 only)
@@ -179,6 +208,98 @@ __global__ __launch_bounds__(256) void wg_colred_kernel(RedParams p) {
     }
 }
 
+// The same reduction for 16-byte-aligned rows of C % 8 == 0 channels (every layer of the UNet but the 4-channel
+// latent): a workgroup owns up to 512 channels x one row chunk, a thread 8 consecutive channels (one 16-B bf16 or
+// two 16-B f32 loads per row) of every 4th row -- whole 1 KB row segments per wave instead of 4-byte elements.
+template <bool DYB, bool XB>
+__global__ __launch_bounds__(256) void wg_colred8_kernel(RedParams p) {
+    __shared__ float red[4][64][17];
+    const int t = threadIdx.x, oct = t & 63, rl = t >> 6;
+    const int c = (blockIdx.x * 64 + oct) * 8;
+    const int split = blockIdx.y, seg = blockIdx.z;
+    const long chunk = (p.seg_rows + p.nsplit - 1) / p.nsplit;
+    const long r0 = (long)split * chunk, r1 = min(p.seg_rows, r0 + chunk);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    if (c < p.C) {
+        float ga[8], be[8], mu[8], rs[8];
+        const int cpg = p.kind == 0 ? p.C / 32 : 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ga[e] = p.kind >= 0 ? p.gamma[c + e] : 0.f;
+            be[e] = (p.kind >= 0 && p.beta) ? p.beta[c + e] : 0.f;
+            mu[e] = 0.f;
+            rs[e] = 0.f;
+        }
+        long last_b = -1;
+#pragma unroll 2
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const long row = (long)seg * p.seg_rows + r;
+            float dz[8];
+            if (DYB) {
+                unpack_bf16x8(*(const uint4*)((const uint16_t*)p.dy + row * p.lddy + c), dz);
+            } else {
+                const float4 a = *(const float4*)((const float*)p.dy + row * p.lddy + c);
+                const float4 d = *(const float4*)((const float*)p.dy + row * p.lddy + c + 4);
+                dz[0] = a.x; dz[1] = a.y; dz[2] = a.z; dz[3] = a.w; dz[4] = d.x; dz[5] = d.y; dz[6] = d.z; dz[7] = d.w;
+            }
+            if (p.kind >= 0) {
+                float xv[8];
+                if (XB) {
+                    unpack_bf16x8(*(const uint4*)((const uint16_t*)p.x + row * p.ldx + c), xv);
+                } else {
+                    const float4 a = *(const float4*)((const float*)p.x + row * p.ldx + c);
+                    const float4 d = *(const float4*)((const float*)p.x + row * p.ldx + c + 4);
+                    xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = d.x; xv[5] = d.y; xv[6] = d.z; xv[7] = d.w;
+                }
+                if (p.kind == 0) {
+                    const long b = row / p.HW;
+                    if (b != last_b) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const long si = b * 32 + (c + e) / cpg;
+                            mu[e] = p.mean[si];
+                            rs[e] = p.rstd[si];
+                        }
+                        last_b = b;
+                    }
+                } else {
+                    const float m = p.mean[row], q = p.rstd[row];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { mu[e] = m; rs[e] = q; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (xv[e] - mu[e]) * rs[e];
+                    if (p.act) {
+                        const float z = xh * ga[e] + be[e];
+                        const float sg = 1.0f / (1.0f + __expf(-z));
+                        dz[e] *= sg * (1.0f + z * (1.0f - sg));
+                    }
+                    s2[e] += dz[e] * xh;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1[e] += dz[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[rl][oct][e] = s1[e];
+        red[rl][oct][8 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int idx = t; idx < 64 * 16; idx += 256) {
+        const int o = idx >> 4, k = idx & 15;
+        const int cc = (blockIdx.x * 64 + o) * 8 + (k & 7);
+        if (cc < p.C) {
+            const float v = ((red[0][o][k] + red[1][o][k]) + red[2][o][k]) + red[3][o][k];
+            p.part[(((long)seg * p.nsplit + split) * 2 + (k >> 3)) * p.C + cc] = v;
+        }
+    }
+}
+
 // out1[seg][c] (+)= sum_split part[seg][split][0][c]; out2 likewise from [1] (either may be NULL)
 __global__ __launch_bounds__(256) void wg_colred_finish_kernel(const float* __restrict__ part, float* __restrict__ out1,
                                                                float* __restrict__ out2, int C, int nsplit, int nseg,
@@ -198,7 +319,8 @@ __global__ __launch_bounds__(256) void wg_colred_finish_kernel(const float* __re
 }
 
 static int colred_nsplit(long seg_rows) {
-    long n = (seg_rows + 255) / 256;          // <= 256 rows (64 per row lane) per workgroup
+    const long per = seg_rows <= 8192 ? 64 : 128;      // rows per workgroup (16 / 32 per row lane)
+    long n = (seg_rows + per - 1) / per;
     if (n < 1) n = 1;
     if (n > 256) n = 256;
     return (int)n;
@@ -215,7 +337,18 @@ static int launch_colred(RedParams p, long rows, long seg_rows, float* out1, flo
     p.seg_rows = seg_rows;
     p.nsplit = colred_nsplit(seg_rows);
     p.part = workspace;
-    hipLaunchKernelGGL(wg_colred_kernel, dim3((p.C + 63) / 64, p.nsplit, nseg), dim3(256), 0, s, p);
+    const int ady = p.dyb ? 8 : 4, ax = p.xb ? 8 : 4;
+    const bool vec = p.C % 8 == 0 && p.lddy % ady == 0 && ((uintptr_t)p.dy % 16) == 0 &&
+                     (p.kind < 0 || (p.ldx % ax == 0 && ((uintptr_t)p.x % 16) == 0));
+    if (vec) {
+        dim3 grid((p.C / 8 + 63) / 64, p.nsplit, nseg);
+        if (p.dyb && p.xb) hipLaunchKernelGGL((wg_colred8_kernel<true, true>), grid, dim3(256), 0, s, p);
+        else if (p.dyb) hipLaunchKernelGGL((wg_colred8_kernel<true, false>), grid, dim3(256), 0, s, p);
+        else if (p.xb) hipLaunchKernelGGL((wg_colred8_kernel<false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wg_colred8_kernel<false, false>), grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(wg_colred_kernel, dim3((p.C + 63) / 64, p.nsplit, nseg), dim3(256), 0, s, p);
+    }
     const long total = (long)nseg * p.C;
     hipLaunchKernelGGL(wg_colred_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, out1, out2,
                        p.C, p.nsplit, nseg, accumulate);
@@ -260,8 +393,8 @@ extern "C" int adap_norm_affine_bwd(const void* dy, int dy_dtype, long lddy, con
 // conv / linear weight gradient
 // ---------------------------------------------------------------------------------------------
 struct WgPlan {
-    long M, Mp, off_dyt, off_xt, off_t, off_sk, off_cs, total;
-    int taps, N;
+    long M, Mp, off_dyt, off_xt, off_t, off_sk, off_cs, total, skf;
+    int taps, N, swap;
 };
 
 static WgPlan wg_plan(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int want_bias) {
@@ -270,11 +403,17 @@ static WgPlan wg_plan(int B, int Hout, int Wout, int Cin, int Cout, int KH, int 
     q.M = (long)B * Hout * Wout;
     q.Mp = (q.M + 7) & ~7L;
     q.N = q.taps * Cin;
+    // Which operand supplies the contraction's ROWS: the implicit-GEMM family has its 256-row LDS-DMA ring kernel for
+    // >= 4096 rows.  Cout is at most 1280 (10240 for the GEGLU projection), taps*Cin reaches 23040 -- so when that side
+    // is the long one it becomes the row dimension and the result comes out transposed ([tap*Cin + ci][co]).
+    q.swap = (q.N >= 4096 && q.N > Cout && Cout % 4 == 0) ? 1 : 0;
     long o = 0;
     q.off_dyt = o; o += align256(2L * Cout * q.Mp);
     q.off_xt = o; o += align256(2L * q.N * q.Mp);
-    q.off_t = o; o += q.taps > 1 ? align256(4L * Cout * q.N) : 0;
-    q.off_sk = o; o += align256(4L * adap_conv2d_workspace_floats(1, Cout, 1, (int)q.Mp, q.N, 1, 1));
+    q.off_t = o; o += (q.taps > 1 || q.swap) ? align256(4L * Cout * q.N) : 0;
+    q.skf = q.swap ? adap_conv2d_workspace_floats(1, q.N, 1, (int)q.Mp, Cout, 1, 1)
+                   : adap_conv2d_workspace_floats(1, Cout, 1, (int)q.Mp, q.N, 1, 1);
+    q.off_sk = o; o += align256(4L * q.skf);
     q.off_cs = o; o += want_bias ? align256(4L * adap_colsum_workspace_floats(q.M, q.M, Cout)) : 0;
     q.total = o;
     return q;
@@ -328,11 +467,21 @@ extern "C" int adap_conv2d_bwd_weight(const void* x, int x_dtype, long ldx, cons
     if (rc) return rc;
     rc = launch_transpose(x, x_dtype, ldx, B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, up, q.M, q.Mp, xt, s);
     if (rc) return rc;
+    float* skws = q.skf > 0 ? (float*)(ws + q.off_sk) : nullptr;
+    if (q.swap) {
+        float* Tt = (float*)(ws + q.off_t);
+        rc = adap_conv2d_nhwc(xt, 1, q.Mp, dyt, nullptr, nullptr, 0, nullptr, 0, Tt, Cout, nullptr, 0, 1, q.N, 1, (int)q.Mp, q.N,
+                              1, Cout, 1, 1, 1, 0, 0, 1.0f, 0, skws, 1, 0, 0, 0, 0, stream);
+        if (rc) return rc;
+        dim3 grid((Cin + 31) / 32, (Cout + 31) / 32);
+        hipLaunchKernelGGL(wg_scatter_t_kernel, grid, dim3(256), (size_t)32 * (32 * q.taps + 1) * sizeof(float), s, Tt, dw, Cout,
+                           Cin, q.taps, accumulate);
+        return adap_check_launch("wgrad scatter");
+    }
     float* T = q.taps > 1 ? (float*)(ws + q.off_t) : dw;
     const float* residual = (q.taps == 1 && accumulate) ? dw : nullptr;
-    const long skf = adap_conv2d_workspace_floats(1, Cout, 1, (int)q.Mp, q.N, 1, 1);
     rc = adap_conv2d_nhwc(dyt, 1, q.Mp, xt, nullptr, nullptr, 0, residual, q.N, T, q.N, nullptr, 0, 1, Cout, 1, (int)q.Mp, Cout,
-                          1, q.N, 1, 1, 1, 0, 0, 1.0f, 0, skf > 0 ? (float*)(ws + q.off_sk) : nullptr, 1, 0, 0, 0, 0, stream);
+                          1, q.N, 1, 1, 1, 0, 0, 1.0f, 0, skws, 1, 0, 0, 0, 0, stream);
     if (rc) return rc;
     if (q.taps > 1) {
         const long total = (long)Cout * q.N;

@@ -100,9 +100,9 @@ def _acc(param):
     return param.grad
 
 
-def _dw_conv(T, key, x, dy, K=1, stride=1, pad=0, up=0):
+def _dw_conv(T, key, x, dy, K=1, stride=1, pad=0, up=0, with_bias=True):
     w, b = T[key]
-    dw, db = _acc(w), _acc(b)
+    dw, db = _acc(w), (_acc(b) if with_bias else None)
     if dw is not None or db is not None:
         ops.conv2d_bwd_weight(x, dy, dw, db, K, stride, pad, up, accumulate=True)
 
@@ -171,16 +171,32 @@ class ResBlockFn(torch.autograd.Function):
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
         ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
         g_emb = None
-        if ctx.needs_input_grad[1]:     # d emb_out[b][c] = sum over the image's pixels of d h1 (openaimodel.py:264-268)
+        db1 = _acc(T["conv1"][1]) if T is not None else None
+        if ctx.needs_input_grad[1] or db1 is not None:
+            # d emb_out[b][c] = sum over the image's pixels of d h1 (openaimodel.py:264-268); conv1's bias gradient is its
+            # sum over the batch
             g_emb = torch.empty(x.shape[0], gh1.shape[-1], device=x.device, dtype=F32)
             ops.colsum(gh1, g_emb, seg_rows=gh1.shape[1] * gh1.shape[2], accumulate=False)
+            if db1 is not None:
+                db1.add_(g_emb.sum(0))
         if T is not None:
-            _dw_conv(T, "conv2", a2, gop, 3, 1, 1)
+            _dw_conv(T, "conv2", a2, gop, 3, 1, 1, with_bias=False)
             _dw_norm(T, "gn2", ga2, h1, g2w, g2b, m2, r2, 0, 1)
-            _dw_conv(T, "conv1", a1, gh1, 3, 1, 1)
+            _dw_conv(T, "conv1", a1, gh1, 3, 1, 1, with_bias=False)
             _dw_norm(T, "gn1", ga1, x, g1w, g1b, m1, r1, 0, 1)
             if sk is not None:
-                _dw_conv(T, "skip", x, gop, 1)
+                _dw_conv(T, "skip", x, gop, 1, with_bias=False)
+            # conv2 and the 1x1 skip see the same output gradient: one column sum serves both bias gradients
+            dbs = [d for d in (_acc(T["conv2"][1]), _acc(T["skip"][1]) if sk is not None else None) if d is not None]
+            if len(dbs) == 1:
+                ops.colsum(gop, dbs[0], accumulate=True)
+            elif len(dbs) == 2:
+                tmp = torch.empty(1, gop.shape[-1], device=x.device, dtype=F32)
+                ops.colsum(gop, tmp, accumulate=False)
+                dbs[0].add_(tmp[0])
+                dbs[1].add_(tmp[0])
+            if not ctx.needs_input_grad[1]:
+                g_emb = None
         if sk is None:          # identity skip: dx + g straight into a new tensor (no clone of g)
             gx, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, add_from=g)
         else:

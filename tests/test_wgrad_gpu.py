@@ -43,6 +43,8 @@ CONV_CASES = [
     (2, 16, 16, 64, 4, 3, 1, 1, 0, "bf16", "f32"),        # out conv: Cout = 4
     (2, 12, 20, 40, 72, 1, 1, 0, 0, "bf16", "bf16"),      # 1x1, ragged tiles
     (3, 10, 6, 24, 40, 3, 1, 1, 0, "bf16", "bf16"),       # M = 180: not a multiple of 64
+    (1, 8, 8, 512, 72, 3, 1, 1, 0, "bf16", "bf16"),       # taps*Cin = 4608 >= 4096: (tap, ci) becomes the row dimension
+    (1, 16, 16, 4104, 40, 1, 1, 0, 0, "bf16", "f32"),     # the same for a 1x1 (ragged: 4104 = 128*32 + 8)
 ]
 
 
@@ -79,7 +81,8 @@ def test_conv2d_bwd_weight(case):
     assert torch.equal(dw2, dw3)
 
 
-@pytest.mark.parametrize("rows,I,O", [(308, 768, 320), (2 * 77, 768, 1280), (4096, 320, 960), (1000, 40, 24)])
+@pytest.mark.parametrize("rows,I,O", [(308, 768, 320), (2 * 77, 768, 1280), (4096, 320, 960), (1000, 40, 24),
+                                      (512, 5120, 1280)])
 def test_linear_bwd_weight(rows, I, O):
     from adaprompt_amd import ops
     g = torch.Generator().manual_seed(7)
