@@ -1609,20 +1609,23 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
     __syncthreads();
     // mode 0: the output's (row, col) = (o, i); mode 1: (i, o)
-    for (int idx = t; idx < taps * PK_T * PK_T; idx += 256) {
-        const int cc = idx % PK_T;
-        const int rr = (idx / PK_T) % PK_T;
-        const int tp = idx / (PK_T * PK_T);
+    // two adjacent columns per thread: one 4-byte store (cols is even: a multiple of 8 or of 4)
+    for (int idx = t; idx < taps * PK_T * (PK_T / 2); idx += 256) {
+        const int cc = (idx % (PK_T / 2)) * 2;
+        const int rr = (idx / (PK_T / 2)) % PK_T;
+        const int tp = idx / (PK_T * (PK_T / 2));
         int r, c;
-        float v;
+        float v0, v1;
         if (mode == 0) {
             r = o0 + rr; c = i0 + cc;
-            v = pk_tile[rr * pitch + cc * taps + tp];
+            v0 = pk_tile[rr * pitch + cc * taps + tp];
+            v1 = pk_tile[rr * pitch + (cc + 1) * taps + tp];
         } else {
             r = i0 + rr; c = o0 + cc;
-            v = pk_tile[cc * pitch + rr * taps + (taps - 1 - tp)];
+            v0 = pk_tile[cc * pitch + rr * taps + (taps - 1 - tp)];
+            v1 = pk_tile[(cc + 1) * pitch + rr * taps + (taps - 1 - tp)];
         }
-        if (r < rows && c < cols) out[((long)tp * rows + r) * cols + c] = f32_to_bf16(v);
+        if (r < rows && c < cols) *(uint32_t*)(out + ((long)tp * rows + r) * cols + c) = pack_bf16x2(v0, v1);
     }
 }
 
@@ -1634,6 +1637,7 @@ extern "C" int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O,
                  "pack_weight: rows/cols too small");
     const int taps = KH * KW;
     ADAP_REQUIRE(taps >= 1 && taps <= 9, ADAP_ERR_UNSUPPORTED, "pack_weight: %d taps", taps);
+    ADAP_REQUIRE(cols % 2 == 0 && ((uintptr_t)out_bf16 % 4) == 0, ADAP_ERR_ALIGN, "pack_weight: cols=%d must be even", cols);
     // tiles cover the PADDED extents (rows/cols beyond O/I are written as zeros)
     const int Op = mode == 0 ? rows : cols, Ip = mode == 0 ? cols : rows;
     dim3 grid((Ip + PK_T - 1) / PK_T, (Op + PK_T - 1) / PK_T);

@@ -300,21 +300,32 @@ __global__ __launch_bounds__(256) void wg_colred8_kernel(RedParams p) {
     }
 }
 
-// out1[seg][c] (+)= sum_split part[seg][split][0][c]; out2 likewise from [1] (either may be NULL)
+// out1[seg][c] (+)= sum_split part[seg][split][0][c]; out2 likewise from [1] (either may be NULL).
+// grid (ceil(C/64), nseg), block 256 = 4 split lanes x 64 channels: lane l sums splits l, l+4, ... in fp64, the four
+// lane sums are added in fixed order.
 __global__ __launch_bounds__(256) void wg_colred_finish_kernel(const float* __restrict__ part, float* __restrict__ out1,
                                                                float* __restrict__ out2, int C, int nsplit, int nseg,
                                                                int accumulate) {
-    const long total = (long)nseg * C;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long seg = i / C;
-        const int c = (int)(i - seg * C);
-        double a = 0.0, b = 0.0;
-        for (int s = 0; s < nsplit; ++s) {
+    __shared__ double red[2][4][64];
+    const int t = threadIdx.x, cl = t & 63, sl = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long seg = blockIdx.y;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int s = sl; s < nsplit; s += 4) {
             a += (double)part[((seg * nsplit + s) * 2 + 0) * C + c];
             b += (double)part[((seg * nsplit + s) * 2 + 1) * C + c];
         }
-        if (out1) out1[i] = accumulate ? out1[i] + (float)a : (float)a;
-        if (out2) out2[i] = accumulate ? out2[i] + (float)b : (float)b;
+    }
+    red[0][sl][cl] = a;
+    red[1][sl][cl] = b;
+    __syncthreads();
+    if (t < 128 && c < C) {
+        const int which = t >> 6;
+        const double v = ((red[which][0][cl] + red[which][1][cl]) + red[which][2][cl]) + red[which][3][cl];
+        float* out = which ? out2 : out1;
+        const long i = seg * C + c;
+        if (out) out[i] = accumulate ? out[i] + (float)v : (float)v;
     }
 }
 
@@ -349,9 +360,8 @@ static int launch_colred(RedParams p, long rows, long seg_rows, float* out1, flo
     } else {
         hipLaunchKernelGGL(wg_colred_kernel, dim3((p.C + 63) / 64, p.nsplit, nseg), dim3(256), 0, s, p);
     }
-    const long total = (long)nseg * p.C;
-    hipLaunchKernelGGL(wg_colred_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, out1, out2,
-                       p.C, p.nsplit, nseg, accumulate);
+    hipLaunchKernelGGL(wg_colred_finish_kernel, dim3((p.C + 63) / 64, nseg), dim3(256), 0, s, workspace, out1, out2, p.C,
+                       p.nsplit, nseg, accumulate);
     return adap_check_launch("wgrad column reduction");
 }
 
