@@ -850,6 +850,7 @@ extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long l
 // (openaimodel.py:947-952), so this is a small direct kernel: one wave per query row, lanes over
 // keys, K^T of the (batch, head) in LDS.
 // =============================================================================================
+#define CAP_ROWS 16
 __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __restrict__ q, long ldq,
                                                            const uint16_t* __restrict__ k, long ldk,
                                                            float* __restrict__ score, float* __restrict__ prob,
@@ -870,7 +871,9 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
     }
     __syncthreads();
     const float qs = sqrtf(scale);
-    const int rows_per_block = 64;
+    // 16 query rows per workgroup (4 per wave): the loop below is a chain of dependent LDS reads, so what it needs is
+    // many waves per CU, not long ones -- with 64 rows the 16x16 level launched 128 four-wave workgroups, one per CU
+    const int rows_per_block = CAP_ROWS;
     for (int rr = w; rr < rows_per_block; rr += 4) {
         const int n = blockIdx.x * rows_per_block + rr;
         if (n >= N) break;            // uniform per wave
@@ -891,6 +894,7 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
                 const float4* kr = (const float4*)(sK + key * dp);
                 const float4* qr = (const float4*)(sQ + w * d);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
                 for (int c4 = 0; c4 < d / 4; ++c4) {
                     float4 kv = kr[c4], qv = qr[c4];
                     a0 += kv.x * qv.x; a1 += kv.y * qv.y; a2 += kv.z * qv.z; a3 += kv.w * qv.w;
@@ -930,7 +934,7 @@ extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, lo
         hipFuncSetAttribute((const void*)attn_capture_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    dim3 grid((N + 63) / 64, B * H);
+    dim3 grid((N + CAP_ROWS - 1) / CAP_ROWS, B * H);
     hipLaunchKernelGGL(attn_capture_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)q, ldq,
                        (const uint16_t*)k, ldk, attnscore, attn, q_scaled, B, H, N, M, d, scale);
     return adap_check_launch("attention_capture");
