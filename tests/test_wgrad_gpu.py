@@ -163,3 +163,36 @@ def test_layernorm_affine_bwd():
     ops.norm_affine_bwd(dy.to(dev), x.to(dev), gamma.to(dev), None, mean, rstd, 1, 0, dga, dbe, accumulate=False)
     assert _rel(dga.cpu(), ga.grad) < 1e-4
     assert _rel(dbe.cpu(), be.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,K", [(4, 16, 1280, 1280, 3), (4, 64, 320, 320, 3), (4, 32, 1920, 640, 3),
+                                            (4, 64, 320, 2560, 1)])
+def test_conv2d_bwd_weight_full_size_vs_torch_gpu(B, H, Cin, Cout, K):
+    """BASELINE sizes (bs = 4): the UNet's own layer shapes against torch's conv2d weight gradient in fp32 on the same
+    device (too large for the CPU fp64 reference), on bf16-representable operands so that only the accumulation order
+    differs; plus the size-independent property that the gradient is linear in dy."""
+    from adaprompt_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, H, H, Cin, device=dev, generator=g).bfloat16()
+    dy1 = torch.randn(B, H, H, Cout, device=dev, generator=g).bfloat16()
+    dy2 = torch.randn(B, H, H, Cout, device=dev, generator=g).bfloat16()
+
+    def hip(dy):
+        dw = torch.zeros(Cout, Cin, K, K, device=dev)
+        ops.conv2d_bwd_weight(x, dy, dw, None, K, 1, K // 2, 0, accumulate=False)
+        return dw
+
+    w = torch.zeros(Cout, Cin, K, K, device=dev, requires_grad=True)
+    prev = torch.backends.cudnn.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    try:
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, padding=K // 2)
+        y.backward(dy1.float().permute(0, 3, 1, 2))
+    finally:
+        torch.backends.cudnn.allow_tf32 = prev
+    d1 = hip(dy1)
+    assert _rel(d1, w.grad) < 1e-3
+    # linearity: dW(dy1 + dy2) = dW(dy1) + dW(dy2) up to the bf16 rounding of the summed operand
+    d2, d12 = hip(dy2), hip((dy1.float() + dy2.float()).bfloat16())
+    assert _rel(d12, d1 + d2) < 6e-3
