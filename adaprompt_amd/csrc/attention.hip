@@ -939,3 +939,129 @@ extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, lo
                        (const uint16_t*)k, ldk, attnscore, attn, q_scaled, B, H, N, M, d, scale);
     return adap_check_launch("attention_capture");
 }
+
+// =============================================================================================
+// Gradient of the captured side outputs (the recon iteration's cross-layer consistency loss reads `attnscore` WITH
+// gradient, ddpm.py:3246-3270, 4259-4387; stage 2 also `q`):
+//   attnscore = scale * q k^T        ->  dq += scale * dS k,   dk += scale * dS^T q
+//   q_scaled  = q * dim_head^-1/4    ->  dq += dim_head^-1/4 * dQs
+// dq / dk are the bf16 gradients the flash backward has already written; the contributions are added in f32 and the
+// sum is rounded once.  No atomics: every output element is owned by one thread (dq: one wave per query row, lanes
+// over channels; dk: a workgroup per (batch, head, 16 keys), every thread walking all N queries).
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_capture_bwd_dq_kernel(const float* __restrict__ ds, const float* __restrict__ dqs,
+                                                                  const uint16_t* __restrict__ k, long ldk,
+                                                                  uint16_t* __restrict__ dq, long lddq, int B, int H, int N,
+                                                                  int M, int d, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sK = (float*)smem;              // [M][d]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    if (ds) {
+        for (int idx = tid; idx < M * d; idx += 256) {
+            int key = idx / d, c = idx - key * d;
+            sK[idx] = bf16_to_f32(k[((size_t)b * M + key) * ldk + head * d + c]);
+        }
+    }
+    __syncthreads();
+    const float qs = sqrtf(scale);
+    for (int rr = w; rr < CAP_ROWS; rr += 4) {
+        const int n = blockIdx.x * CAP_ROWS + rr;
+        if (n >= N) break;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if (ds) {
+            const float* row = ds + (((size_t)b * H + head) * N + n) * M;
+            float dv[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) dv[kk] = (lane + 64 * kk < M) ? row[lane + 64 * kk] : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int mbase = 64 * kk;
+                if (mbase >= M) break;
+                const int mend = min(64, M - mbase);
+                for (int mm = 0; mm < mend; ++mm) {
+                    const float g = __shfl(dv[kk], mm, 64);
+                    const float* kr = sK + (mbase + mm) * d;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (lane + 64 * j < d) acc[j] += g * kr[lane + 64 * j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) {
+                float v = scale * acc[j];
+                if (dqs) v += qs * dqs[(((size_t)b * H + head) * N + n) * d + c];
+                uint16_t* o = dq + ((size_t)b * N + n) * lddq + head * d + c;
+                *o = f32_to_bf16(bf16_to_f32(*o) + v);
+            }
+        }
+    }
+}
+
+#define CAPB_KEYS 16
+__global__ __launch_bounds__(256) void attn_capture_bwd_dk_kernel(const float* __restrict__ ds, const uint16_t* __restrict__ q,
+                                                                  long ldq, uint16_t* __restrict__ dk, long lddk, int B, int H,
+                                                                  int N, int M, int d, float scale) {
+    const int tid = threadIdx.x, cl = tid & 63, kl = tid >> 6;          // 64 channel lanes x 4 key lanes
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    const int m0 = blockIdx.x * CAPB_KEYS;
+    float acc[4][3];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[kk][j] = 0.f;
+    const float* dsb = ds + ((size_t)b * H + head) * N * M;
+    const uint16_t* qb = q + (size_t)b * N * ldq + head * d;
+    for (int n = 0; n < N; ++n) {
+        float qv[3], g[4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qv[j] = (cl + 64 * j < d) ? bf16_to_f32(qb[(size_t)n * ldq + cl + 64 * j]) : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int m = m0 + kl + 4 * kk;
+            g[kk] = m < M ? dsb[(size_t)n * M + m] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[kk][j] += g[kk] * qv[j];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int m = m0 + kl + 4 * kk;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = cl + 64 * j;
+            if (c < d) {
+                uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
+                *o = f32_to_bf16(bf16_to_f32(*o) + scale * acc[kk][j]);
+            }
+        }
+    }
+}
+
+extern "C" int adap_attention_capture_bwd(const float* d_attnscore, const float* d_q_scaled, const void* q, long ldq,
+                                          const void* k, long ldk, void* dq16, long lddq, void* dk16, long lddk, int B, int H,
+                                          int N, int M, int d, float scale, void* stream) {
+    ADAP_REQUIRE((d_attnscore || d_q_scaled) && q && k && dq16, ADAP_ERR_SHAPE, "attention_capture_bwd: null pointer");
+    ADAP_REQUIRE(!d_attnscore || dk16, ADAP_ERR_SHAPE, "attention_capture_bwd: d_attnscore needs dk");
+    ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture_bwd: M=%d (cross-attention only, <= 192)", M);
+    ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture_bwd: d=%d", d);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = d_attnscore ? (size_t)M * d * 4 : 0;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)attn_capture_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_capture_bwd_dq_kernel, dim3((N + CAP_ROWS - 1) / CAP_ROWS, B * H), dim3(256), lds, s, d_attnscore,
+                       d_q_scaled, (const uint16_t*)k, ldk, (uint16_t*)dq16, lddq, B, H, N, M, d, scale);
+    if (d_attnscore)
+        hipLaunchKernelGGL(attn_capture_bwd_dk_kernel, dim3((M + CAPB_KEYS - 1) / CAPB_KEYS, B * H), dim3(256), 0, s, d_attnscore,
+                           (const uint16_t*)q, ldq, (uint16_t*)dk16, lddk, B, H, N, M, d, scale);
+    return adap_check_launch("attention_capture_bwd");
+}

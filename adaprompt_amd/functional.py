@@ -261,18 +261,24 @@ class SpatialTransformerFn(torch.autograd.Function):
                               ctx_k, ctx_v, *((xn, n1, n2, n3, gg, t3) if tr else (None,) * 6))
         out = out.view(B, H, W, C)
         if capture:
-            ctx.mark_non_differentiable(*cap)
+            # attnscore and q*d^-1/4 stay in the graph (the cross-layer consistency loss of the recon iteration reads
+            # attnscore with gradient, ddpm.py:3246-3270); the probabilities are a monitoring output only.
+            # Unused side outputs must cost nothing in backward: their gradients arrive as None, not as zeros.
+            ctx.set_materialize_grads(False)
+            ctx.mark_non_differentiable(cap[1])
             return (out,) + tuple(cap)
         return out
 
     @staticmethod
-    def backward(ctx, g, *unused):
+    def backward(ctx, g, g_score=None, _g_prob=None, g_qs=None):
         (x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh, ctx_k,
          ctx_v, xn, n1, n2, n3, gg, t3) = ctx.saved_tensors
         P, heads = ctx.P, ctx.heads
         T = P.get("train")
         B, H, W, C = x.shape
         N = H * W
+        if g is None:                       # only a side output was used downstream
+            g = torch.zeros_like(x)
         gop = _operand(g)            # bf16 copy if the producer left one; g itself (f32) is only the final addend
         if g.dim() == 4 and not g.is_contiguous():          # a channel slice out of a concat gradient: rows ld apart
             ld = g.stride(-2)
@@ -300,6 +306,10 @@ class SpatialTransformerFn(torch.autograd.Function):
         dkv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
         ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
                           dv=dkv2[..., C:])
+        if g_score is not None or g_qs is not None:      # gradients of the captured attnscore / q side outputs
+            ops.attention_capture_bwd(None if g_score is None else g_score.contiguous(),
+                                      None if g_qs is None else g_qs.contiguous(), q2, kv2[..., :C], dq2,
+                                      dkv2[..., :C], heads)
         gn2, _ = _lin_bwd(dq2, P["q2"])
         if T is not None:
             _dw_lin(T, "to_out2", o2, gt2h)

@@ -362,6 +362,20 @@ def attention_capture(q, k, heads, want_q=True):
     return score, prob, qs
 
 
+def attention_capture_bwd(d_score, d_qs, q, k, dq, dk, heads):
+    """add the gradients of the captured side outputs into the bf16 ``dq`` [B,N,C] / ``dk`` [B,M,C] of the same layer:
+    d_score f32 [B,h,N,M] (gradient of attnscore) and / or d_qs f32 [B,h,N,d] (gradient of q * d^-1/4)."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    d = C // heads
+    assert dq.dtype == BF16 and dq.shape == q.shape and (d_score is None or (dk is not None and dk.dtype == BF16))
+    for t, shp in ((d_score, (B, heads, N, M)), (d_qs, (B, heads, N, d))):
+        assert t is None or (t.dtype == F32 and tuple(t.shape) == shp and t.is_contiguous()), (None if t is None else t.shape, shp)
+    _lib.call("adap_attention_capture_bwd", _ptr(d_score), _ptr(d_qs), q.data_ptr(), _rows_ld(q)[1], k.data_ptr(),
+              _rows_ld(k)[1], dq.data_ptr(), _rows_ld(dq)[1], _ptr(dk), 0 if dk is None else _rows_ld(dk)[1], B, heads, N, M, d,
+              float(d) ** -0.5, _stream())
+
+
 # --------------------------------------------------------------------------------------------
 # misc
 # --------------------------------------------------------------------------------------------

@@ -131,6 +131,13 @@ int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const v
  * q_scaled = q * scale^0.5 [B][H][N][d] f32 (any of them may be NULL).  M <= 192. */
 int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
                            float* q_scaled, int B, int H, int N, int M, int d, float scale, void* stream);
+/* Gradient of those side outputs (ddpm.py:3246-3270: the recon iteration's cross-layer consistency loss reads
+ * `attnscore` with gradient; stage 2 also `q`): dq16 / dk16 are the bf16 gradients adap_attention_bwd has written for
+ * the same layer, and receive  += scale * dS k  (+ dim_head^-1/4 * dQs)  and  += scale * dS^T q  (f32 sum, rounded
+ * once).  d_attnscore f32 [B][H][N][M] and d_q_scaled f32 [B][H][N][d], either may be NULL. */
+int adap_attention_capture_bwd(const float* d_attnscore, const float* d_q_scaled, const void* q, long ldq,
+                               const void* k, long ldk, void* dq16, long lddq, void* dk16, long lddk, int B, int H,
+                               int N, int M, int d, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEGLU, attention.py:32-40: h = [a | gate] bf16 [rows][2*inner] -> a * gelu(gate) bf16 [rows][inner].

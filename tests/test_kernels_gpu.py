@@ -420,3 +420,35 @@ def test_linear_small_more_than_eight_rows():
     got = ops.linear_small(x, w, bias, post_silu=True)
     ref = F.silu(x @ w.t() + bias)
     assert rel(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,M,d", [(2, 256, 77, 160), (1, 1024, 77, 80), (2, 100, 154, 40), (1, 64, 5, 40)])
+def test_attention_capture_bwd(B, N, M, d):
+    """gradients of the captured attnscore / q*d^-1/4 side outputs added into the layer's bf16 dq / dk
+    (ddpm.py:3246-3270 reads attnscore with gradient); reference: the same contraction in fp64."""
+    H = 8
+    g = torch.Generator().manual_seed(21)
+    q = torch.randn(B, N, H * d, generator=g).bfloat16()
+    k = torch.randn(B, M, H * d, generator=g).bfloat16()
+    ds = torch.randn(B, H, N, M, generator=g) * 0.1
+    dqs = torch.randn(B, H, N, d, generator=g)
+    dq0 = torch.randn(B, N, H * d, generator=g).bfloat16()
+    dk0 = torch.randn(B, M, H * d, generator=g).bfloat16()
+    scale = d ** -0.5
+    qh = q.double().view(B, N, H, d).permute(0, 2, 1, 3)
+    kh = k.double().view(B, M, H, d).permute(0, 2, 1, 3)
+    dq_ref = scale * (ds.double() @ kh) + d ** -0.25 * dqs.double()                    # [B,H,N,d]
+    dk_ref = scale * (ds.double().transpose(2, 3) @ qh)                                  # [B,H,M,d]
+    dq_ref = dq0.double() + dq_ref.permute(0, 2, 1, 3).reshape(B, N, H * d)
+    dk_ref = dk0.double() + dk_ref.permute(0, 2, 1, 3).reshape(B, M, H * d)
+    dev = torch.device("cuda:0")
+    dq, dk = dq0.to(dev).clone(), dk0.to(dev).clone()
+    ops.attention_capture_bwd(ds.to(dev), dqs.to(dev), q.to(dev), k.to(dev), dq, dk, H)
+    # the sum is rounded to bf16 once: half an ulp of the result
+    assert rel(dq.float().cpu(), dq_ref.float()) < 3e-3
+    assert rel(dk.float().cpu(), dk_ref.float()) < 3e-3
+    # q-only gradient (stage 2 reads q without attnscore in some losses): dk untouched
+    dq2, dk2 = dq0.to(dev).clone(), dk0.to(dev).clone()
+    ops.attention_capture_bwd(None, dqs.to(dev), q.to(dev), k.to(dev), dq2, None, H)
+    ref2 = dq0.double() + (d ** -0.25 * dqs.double()).permute(0, 2, 1, 3).reshape(B, N, H * d)
+    assert rel(dq2.float().cpu(), ref2.float()) < 3e-3
