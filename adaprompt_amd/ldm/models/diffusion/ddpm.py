@@ -20,6 +20,7 @@ from functools import partial
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .... import ops
 from ...modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
@@ -218,6 +219,48 @@ class LatentDiffusion(DDPM):
         fg = None if fg_mask is None else fg_mask.reshape(mo.shape[:-1])
         loss, grad = ops.masked_mse(mo.detach(), tg, im, fg, fg_pixel_weight, bg_pixel_weight)
         return loss, grad.permute(0, 3, 1, 2)
+
+    # ---- cross-layer consistency of the subject / background attention maps (ddpm.py:4259-4387) ---------------
+    XLAYER_WEIGHTS = {8: 0.5, 12: 1., 16: 1., 17: 1., 18: 1., 19: 0.5, 20: 0.5, 21: 0.5, 22: 0.25, 23: 0.25, 24: 0.25}
+    XLAYER_BELOW = {8: 7, 12: 8, 16: 12, 17: 16, 18: 17, 19: 18, 20: 19, 21: 20, 22: 21, 23: 22, 24: 23}
+
+    def calc_fg_bg_xlayer_consist_loss(self, ca_attnscores, subj_indices, bg_indices, SSB_SIZE):
+        """ca_attnscores {layer_idx: attnscore [B, heads, N, 77]} as captured by the UNet (WITH gradient);
+        subj_indices / bg_indices: (instance idx, token idx) of the subject / background embeddings in the prompts.
+        Per aligned layer: the score map of the subject tokens (mean over heads, sum over the K embeddings) against the
+        map of the layer below it (``XLAYER_BELOW``), the finer one bilinearly resized to the coarser, demeaned cosine
+        with a sign-preserving squared reference, weighted by the normalised ``XLAYER_WEIGHTS``.  -> (fg, bg) losses."""
+        from ...util import calc_ref_cosine_loss, normalize_dict_values, normalized_sum
+        layer_w = normalize_dict_values(dict(LatentDiffusion.XLAYER_WEIGHTS))
+        below = LatentDiffusion.XLAYER_BELOW
+
+        def first_instances(idx):
+            k = len(idx[0]) // len(torch.unique(idx[0]))            # embeddings per instance
+            return (idx[0][:SSB_SIZE * k], idx[1][:SSB_SIZE * k]), k
+
+        groups = [first_instances(subj_indices)]
+        if bg_indices is not None:
+            groups.append(first_instances(bg_indices))
+        sums = [[] for _ in groups]
+        for layer, score in ca_attnscores.items():
+            if layer not in layer_w:
+                continue
+            fine, coarse = score, ca_attnscores[below[layer]]
+            if coarse.shape[2] > fine.shape[2]:
+                fine, coarse = coarse, fine
+            hf, hc = int(np.sqrt(fine.shape[2])), int(np.sqrt(coarse.shape[2]))
+            for gi, ((bi, ti), k) in enumerate(groups):
+                # [B, heads, N, 77] -> rows (instance, token) -> [SSB, k, heads, N] -> head mean, token sum -> [SSB, N]
+                m_fine = fine[bi, :, :, ti].reshape(SSB_SIZE, k, *fine.shape[1:3]).mean(dim=2).sum(dim=1)
+                m_coarse = coarse[bi, :, :, ti].reshape(SSB_SIZE, k, *coarse.shape[1:3]).mean(dim=2).sum(dim=1)
+                m_fine = F.interpolate(m_fine.reshape(SSB_SIZE, 1, hf, hf), size=(hc, hc), mode="bilinear",
+                                       align_corners=False).reshape(SSB_SIZE, hc * hc)
+                sums[gi].append(layer_w[layer] * calc_ref_cosine_loss(
+                    m_fine, m_coarse, exponent=2, do_demean_first=True, first_n_dims_to_flatten=1, ref_grad_scale=1,
+                    aim_to_align=True))
+        loss_fg = normalized_sum(sums[0])
+        loss_bg = normalized_sum(sums[1]) if len(groups) > 1 else normalized_sum([])
+        return loss_fg, loss_bg
 
     # ---- Arc2Face distillation: teacher rollout + multi-step student loss (ddpm.py:2950-3039) ------------------
     MAX_ACCUMU_BATCH_SIZE = 7

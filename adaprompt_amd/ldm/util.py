@@ -71,3 +71,144 @@ def prodigy_linear_schedule(opt, max_steps, warm_up_steps, scheduler_cycles=1):
             milestones.append(milestones[-1] + steps)
         schedulers.append(PolynomialLR(opt, power=1, total_iters=steps * 1.1))
     return SequentialLR2(opt, schedulers=schedulers, milestones=milestones)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Regulariser helpers of the recon iteration (reference ldm/util.py: ortho_subtract :280, demean :425,
+# calc_ref_cosine_loss :437, ScaleGrad / gen_gradient_scaler :1084-1131, normalize_dict_values :1423,
+# normalized_sum :2110, calc_prompt_emb_delta_loss :2037).  Host-side torch on small tensors (token embeddings,
+# [instances, pixels] score maps): same names, arguments and return values as the reference.
+# ----------------------------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+def ortho_subtract(a, b, on_last_n_dims=1, return_align_coeffs=False):
+    """the component of ``a`` orthogonal to ``b`` over the last ``on_last_n_dims`` dims (w = <a,b> / (<b,b> + 1e-6))."""
+    assert a.ndim == b.ndim, "Tensors a and b must have the same number of dimensions"
+    shape = None
+    if on_last_n_dims > 1:
+        full = torch.broadcast_shapes(a.shape, b.shape)
+        a, b = a.expand(full), b.expand(full)
+        shape = a.shape
+        a = a.reshape(*shape[:-on_last_n_dims], -1)
+        b = b.reshape(*shape[:-on_last_n_dims], -1)
+    coeff = torch.einsum("...d,...d->...", a, b) / (torch.einsum("...d,...d->...", b, b) + 1e-6)
+    out = a - coeff[..., None] * b
+    if shape is not None:
+        out = out.reshape(shape)
+        coeff = coeff.reshape(*shape[:-on_last_n_dims], *([1] * on_last_n_dims))
+    return (out, coeff) if return_align_coeffs else out
+
+
+def demean(x, demean_dims=(-1,)):
+    if demean_dims is None:
+        return x
+    return x - x.mean(dim=tuple(demean_dims), keepdim=True)
+
+
+class ScaleGrad(torch.autograd.Function):
+    """identity whose backward multiplies the gradient by ``alpha``."""
+
+    @staticmethod
+    def forward(ctx, input_, alpha_, debug=False):
+        ctx.alpha = float(alpha_)
+        return input_.view_as(input_)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output * ctx.alpha, None, None
+
+
+class GradientScaler(nn.Module):
+    def __init__(self, alpha=1., debug=False):
+        super().__init__()
+        self._alpha = float(alpha)
+
+    def forward(self, input_):
+        return ScaleGrad.apply(input_, self._alpha)
+
+
+def gen_gradient_scaler(alpha, debug=False):
+    """alpha == 1: identity; 0 < alpha: GradientScaler; alpha == 0: torch.detach."""
+    if alpha == 1:
+        return nn.Identity()
+    if alpha > 0:
+        return GradientScaler(alpha, debug=debug)
+    assert alpha == 0
+    return torch.detach
+
+
+def calc_ref_cosine_loss(delta, ref_delta, batch_mask=None, emb_mask=None, exponent=2, do_demean_first=False,
+                         first_n_dims_to_flatten=3, ref_grad_scale=0, aim_to_align=True, margin=0, debug=False):
+    """Mean over the counted samples of a (weighted) mean over rows of 1 - cos(delta, ref^exponent) -- or of
+    max(0, cos) when ``aim_to_align`` is False -- with ref^exponent sign preserving, both optionally demeaned over the
+    last dim, rows selected / weighted by ``emb_mask`` and the reference's gradient scaled by ``ref_grad_scale``."""
+    B = delta.shape[0]
+    if batch_mask is None:
+        batch_mask = torch.ones(B, device=delta.device)
+    else:
+        assert batch_mask.shape == (B,)
+        if batch_mask.sum() == 0:
+            return 0
+    scaler = gen_gradient_scaler(ref_grad_scale)
+    sign = 1.0 if aim_to_align else -1.0
+    total = 0
+    for i in range(B):
+        rows, ref_rows, weights = delta[i:i + 1], ref_delta[i:i + 1], None
+        lead = rows.shape[:first_n_dims_to_flatten]
+        if emb_mask is None:
+            rows = rows.reshape(lead.numel(), -1)
+            ref_rows = ref_rows.reshape(rows.shape)
+        else:
+            weights = emb_mask[i:i + 1].squeeze(-1).expand(lead)
+            selected = weights > 0                      # padded / suffix tokens carry no loss
+            rows, ref_rows, weights = rows[selected], ref_rows[selected], weights[selected]
+        if do_demean_first:
+            rows, ref_rows = demean(rows), demean(ref_rows)
+        ref_rows = scaler(ref_rows)
+        target = ref_rows * ref_rows.abs().pow(exponent - 1)
+        per_row = F.cosine_embedding_loss(rows, target, torch.full_like(rows[:, 0], sign), reduction="none")
+        sample = per_row.mean() if weights is None else (per_row * weights).sum() / (weights.sum() + 1e-8)
+        sample = sample * batch_mask[i]
+        if margin > 0:
+            sample = torch.clamp(sample - margin, min=0)
+        total = total + sample
+    return total / batch_mask.sum()
+
+
+def normalize_dict_values(d):
+    total = np.sum(list(d.values()))
+    if total == 0:
+        return d
+    return {k: v / total for k, v in d.items()}
+
+
+def to_float(x):
+    return x.item() if isinstance(x, torch.Tensor) else x
+
+
+def normalized_sum(losses_list, norm_pow=0):
+    plain = sum(losses_list)
+    if norm_pow == 0 or len(losses_list) == 0:
+        return plain
+    rescaled = sum(l / np.power(np.abs(to_float(l)) + 1e-8, norm_pow) for l in losses_list)
+    return rescaled * to_float(plain) / (to_float(rescaled) + 1e-8)
+
+
+def calc_prompt_emb_delta_loss(static_embeddings, prompt_emb_mask, cls_delta_grad_scale=0.05):
+    """static_embeddings [4*BS, 16, 77, 768]: subject-single, subject-comp, class-single, class-comp blocks;
+    prompt_emb_mask [4*BS, 77, 1].  The (ortho-subtracted) subject delta comp - single is pulled towards the class
+    delta; tokens weigh (m_single + m_comp)^2 / 4 with the start token excluded.  Zeroes ``prompt_emb_mask[:, 0]`` in
+    place, as the reference does."""
+    subj_single, subj_comp, cls_single, cls_comp = static_embeddings.chunk(4)
+    token_weights = None
+    if prompt_emb_mask is not None:
+        prompt_emb_mask[:, 0] = 0
+        m_single, m_comp = prompt_emb_mask.chunk(4)[:2]          # the class prompts have the same masks
+        token_weights = ((m_single + m_comp).pow(2) / 4).unsqueeze(1)
+    return calc_ref_cosine_loss(ortho_subtract(subj_comp, subj_single), ortho_subtract(cls_comp, cls_single),
+                                emb_mask=token_weights, do_demean_first=True, first_n_dims_to_flatten=3,
+                                ref_grad_scale=cls_delta_grad_scale, aim_to_align=True)

@@ -191,6 +191,59 @@ def run_anneal():
          anneal_values=np.array(av, dtype=np.float64), anneal_array=np.array(aa, dtype=np.float64))
 
 
+def run_regs():
+    """the recon iteration's regulariser helpers, ldm/util.py: ortho_subtract :280, demean :425, calc_ref_cosine_loss :437,
+    normalized_sum :2110, normalize_dict_values :1423, calc_prompt_emb_delta_loss :2037 -- values AND gradients."""
+    from ldm.util import (calc_prompt_emb_delta_loss, calc_ref_cosine_loss, normalize_dict_values, normalized_sum,
+                          ortho_subtract)
+    with torch.enable_grad():
+        _run_regs(calc_prompt_emb_delta_loss, calc_ref_cosine_loss, normalize_dict_values, normalized_sum, ortho_subtract)
+
+
+def _run_regs(calc_prompt_emb_delta_loss, calc_ref_cosine_loss, normalize_dict_values, normalized_sum, ortho_subtract):
+    out = {}
+    a = synth.synthetic_input("regs.a", (3, 5, 7, 24))
+    b = synth.synthetic_input("regs.b", (3, 5, 7, 24)) + 0.3 * a
+    out["ortho"] = ortho_subtract(a, b)
+    # calc_ref_cosine_loss over its switches; gradients w.r.t. both arguments
+    cases = [dict(exponent=2, do_demean_first=True, first_n_dims_to_flatten=3, ref_grad_scale=0.05, aim_to_align=True),
+             dict(exponent=2, do_demean_first=False, first_n_dims_to_flatten=3, ref_grad_scale=0, aim_to_align=True),
+             dict(exponent=3, do_demean_first=True, first_n_dims_to_flatten=2, ref_grad_scale=1, aim_to_align=False),
+             dict(exponent=2, do_demean_first=True, first_n_dims_to_flatten=1, ref_grad_scale=1, aim_to_align=True),
+             dict(exponent=2, do_demean_first=True, first_n_dims_to_flatten=3, ref_grad_scale=0.1, aim_to_align=True,
+                  margin=0.2)]
+    emb_mask = (synth.synthetic_input("regs.m", (3, 1, 7, 1)) > -0.3).float() * 0.5 + \
+               (synth.synthetic_input("regs.m2", (3, 1, 7, 1)) > 0.2).float() * 0.5
+    batch_mask = torch.tensor([1.0, 0.0, 1.0])
+    for ci, kw in enumerate(cases):
+        for mi, (em, bm) in enumerate(((None, None), (emb_mask, None), (emb_mask, batch_mask))):
+            if kw["first_n_dims_to_flatten"] != 3 and em is not None:
+                continue
+            d = a.clone().requires_grad_(True)
+            r = b.clone().requires_grad_(True)
+            loss = calc_ref_cosine_loss(d, r, batch_mask=bm, emb_mask=em, **kw)
+            loss.backward()
+            out[f"cos{ci}_{mi}_loss"] = loss.detach()
+            out[f"cos{ci}_{mi}_gd"] = d.grad
+            out[f"cos{ci}_{mi}_gr"] = r.grad if r.grad is not None else torch.zeros_like(r)
+    # calc_prompt_emb_delta_loss: [4*BS, 16, 77, 16] embeddings, mask 1 / 0.5 (padding) as the embedder produces
+    BS = 2
+    emb = synth.synthetic_input("regs.emb", (4 * BS, 16, 77, 16)).requires_grad_(True)
+    pm = torch.ones(4 * BS, 77, 1)
+    for i, n in enumerate((20, 31, 26, 31, 20, 31, 26, 31)):        # single / comp prompt lengths; the rest is padding
+        pm[i, n:] = 0.5
+    loss = calc_prompt_emb_delta_loss(emb, pm.clone())
+    loss.backward()
+    out["pdelta_loss"], out["pdelta_grad"], out["pdelta_mask"] = loss.detach(), emb.grad, pm
+    loss0 = calc_prompt_emb_delta_loss(emb.detach(), None)
+    out["pdelta_loss_nomask"] = loss0
+    nd = normalize_dict_values({8: 0.5, 12: 1.0, 16: 1.0, 19: 0.5, 22: 0.25})
+    out["ndict_keys"], out["ndict_vals"] = np.array(list(nd.keys())), np.array(list(nd.values()), dtype=np.float64)
+    ls = [torch.tensor(0.3), torch.tensor(1.7), torch.tensor(0.02)]
+    out["nsum0"], out["nsum05"] = normalized_sum(ls), normalized_sum(ls, norm_pow=0.5)
+    save("regs_util", **out)
+
+
 def run_decoder_and_ddim(model, util, full):
     """VAE Decoder + post_quant_conv (model.py:502-608, autoencoder.py:330-333) and the DDIM schedule helpers
     (util.py:46-77)."""
@@ -397,6 +450,7 @@ def main():
     # ---------------- optimiser: Prodigy.step + grad-norm clip + LR schedule (ldm/prodigy.py, ldm/util.py:26-41) ------
     run_prodigy()
     run_anneal()
+    run_regs()
     run_decoder_and_ddim(model, util, args.full)
 
     if args.full:
