@@ -1002,32 +1002,44 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dq_kernel(const float* _
 }
 
 #define CAPB_KEYS 16
+#define CAPB_ROWS 128
+// dk, stage 1: partial[bh][chunk][m][c] = sum over the chunk's 128 query rows of dS[n][m] * q[n][c].  A workgroup owns
+// (batch*head, row chunk, 16 keys); its dS slice sits in LDS (broadcast reads), q rows stream from global (64 lanes =
+// 64 consecutive channels).  Cutting N into chunks is what fills the chip -- one workgroup per (batch*head, 16 keys)
+// walking all 4096 rows with dependent loads took 4 ms per layer.  Stage 2 adds the chunks in fixed order.
 __global__ __launch_bounds__(256) void attn_capture_bwd_dk_kernel(const float* __restrict__ ds, const uint16_t* __restrict__ q,
-                                                                  long ldq, uint16_t* __restrict__ dk, long lddk, int B, int H,
-                                                                  int N, int M, int d, float scale) {
+                                                                  long ldq, float* __restrict__ part, int B, int H, int N,
+                                                                  int M, int d) {
+    __shared__ float sD[CAPB_ROWS][CAPB_KEYS];
     const int tid = threadIdx.x, cl = tid & 63, kl = tid >> 6;          // 64 channel lanes x 4 key lanes
-    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
-    const int m0 = blockIdx.x * CAPB_KEYS;
+    const int bh = blockIdx.z, b = bh / H, head = bh - b * H;
+    const int m0 = blockIdx.x * CAPB_KEYS, n0 = blockIdx.y * CAPB_ROWS;
+    const int nchunks = gridDim.y;
+    const float* dsb = ds + ((size_t)b * H + head) * N * M;
+    for (int idx = tid; idx < CAPB_ROWS * CAPB_KEYS; idx += 256) {
+        const int r = idx / CAPB_KEYS, mm = idx - r * CAPB_KEYS;
+        const int n = n0 + r, m = m0 + mm;
+        sD[r][mm] = (n < N && m < M) ? dsb[(size_t)n * M + m] : 0.f;
+    }
+    __syncthreads();
     float acc[4][3];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[kk][j] = 0.f;
-    const float* dsb = ds + ((size_t)b * H + head) * N * M;
-    const uint16_t* qb = q + (size_t)b * N * ldq + head * d;
-    for (int n = 0; n < N; ++n) {
-        float qv[3], g[4];
+    const uint16_t* qb = q + ((size_t)b * N + n0) * ldq + head * d;
+    const int rows = min(CAPB_ROWS, N - n0);
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+        float qv[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) qv[j] = (cl + 64 * j < d) ? bf16_to_f32(qb[(size_t)n * ldq + cl + 64 * j]) : 0.f;
+        for (int j = 0; j < 3; ++j) qv[j] = (cl + 64 * j < d) ? bf16_to_f32(qb[(size_t)r * ldq + cl + 64 * j]) : 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int m = m0 + kl + 4 * kk;
-            g[kk] = m < M ? dsb[(size_t)n * M + m] : 0.f;
+            const float g = sD[r][kl + 4 * kk];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[kk][j] += g * qv[j];
         }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[kk][j] += g[kk] * qv[j];
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -1036,21 +1048,41 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dk_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int c = cl + 64 * j;
-            if (c < d) {
-                uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
-                *o = f32_to_bf16(bf16_to_f32(*o) + scale * acc[kk][j]);
-            }
+            if (c < d) part[(((size_t)bh * nchunks + blockIdx.y) * M + m) * d + c] = acc[kk][j];
         }
     }
 }
 
+// dk, stage 2: dk16[b][m][head*d + c] += scale * sum_chunk partial (fixed order; f32 sum rounded once)
+__global__ __launch_bounds__(256) void attn_capture_bwd_dk_finish_kernel(const float* __restrict__ part, uint16_t* __restrict__ dk,
+                                                                         long lddk, int B, int H, int M, int d, int nchunks,
+                                                                         float scale) {
+    const long total = (long)B * H * M * d;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % d);
+        long r = i / d;
+        const int m = (int)(r % M);
+        const long bh = r / M;
+        const int b = (int)(bh / H), head = (int)(bh - (long)b * H);
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += part[((bh * nchunks + k) * M + m) * d + c];
+        uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
+        *o = f32_to_bf16(bf16_to_f32(*o) + scale * s);
+    }
+}
+
+extern "C" long adap_attention_capture_bwd_workspace_floats(int B, int H, int N, int M, int d) {
+    return (long)B * H * ((N + CAPB_ROWS - 1) / CAPB_ROWS) * M * d;
+}
+
 extern "C" int adap_attention_capture_bwd(const float* d_attnscore, const float* d_q_scaled, const void* q, long ldq,
-                                          const void* k, long ldk, void* dq16, long lddq, void* dk16, long lddk, int B, int H,
-                                          int N, int M, int d, float scale, void* stream) {
+                                          const void* k, long ldk, void* dq16, long lddq, void* dk16, long lddk,
+                                          float* workspace, int B, int H, int N, int M, int d, float scale, void* stream) {
     ADAP_REQUIRE((d_attnscore || d_q_scaled) && q && k && dq16, ADAP_ERR_SHAPE, "attention_capture_bwd: null pointer");
-    ADAP_REQUIRE(!d_attnscore || dk16, ADAP_ERR_SHAPE, "attention_capture_bwd: d_attnscore needs dk");
+    ADAP_REQUIRE(!d_attnscore || (dk16 && workspace), ADAP_ERR_SHAPE, "attention_capture_bwd: d_attnscore needs dk and workspace");
     ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture_bwd: M=%d (cross-attention only, <= 192)", M);
     ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture_bwd: d=%d", d);
+    ADAP_REQUIRE((long)B * H <= 65535, ADAP_ERR_SHAPE, "attention_capture_bwd: B*H");
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = d_attnscore ? (size_t)M * d * 4 : 0;
     static bool attr = false;
@@ -1060,8 +1092,15 @@ extern "C" int adap_attention_capture_bwd(const float* d_attnscore, const float*
     }
     hipLaunchKernelGGL(attn_capture_bwd_dq_kernel, dim3((N + CAP_ROWS - 1) / CAP_ROWS, B * H), dim3(256), lds, s, d_attnscore,
                        d_q_scaled, (const uint16_t*)k, ldk, (uint16_t*)dq16, lddq, B, H, N, M, d, scale);
-    if (d_attnscore)
-        hipLaunchKernelGGL(attn_capture_bwd_dk_kernel, dim3((M + CAPB_KEYS - 1) / CAPB_KEYS, B * H), dim3(256), 0, s, d_attnscore,
-                           (const uint16_t*)q, ldq, (uint16_t*)dk16, lddk, B, H, N, M, d, scale);
+    if (d_attnscore) {
+        const int nchunks = (N + CAPB_ROWS - 1) / CAPB_ROWS;
+        hipLaunchKernelGGL(attn_capture_bwd_dk_kernel, dim3((M + CAPB_KEYS - 1) / CAPB_KEYS, nchunks, B * H), dim3(256), 0, s,
+                           d_attnscore, (const uint16_t*)q, ldq, workspace, B, H, N, M, d);
+        const long total = (long)B * H * M * d;
+        long g = (total + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(attn_capture_bwd_dk_finish_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, (uint16_t*)dk16, lddk,
+                           B, H, M, d, nchunks, scale);
+    }
     return adap_check_launch("attention_capture_bwd");
 }

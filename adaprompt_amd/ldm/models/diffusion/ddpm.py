@@ -53,7 +53,9 @@ class DDPM(nn.Module):
 
     def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
                  cosine_s=8e-3, given_betas=None, v_posterior=0.0, parameterization="eps", conditioning_key="crossattn",
-                 manual_accumulate_grad_batches=2, grad_clip=0.5, **unused):
+                 manual_accumulate_grad_batches=2, grad_clip=0.5, optimizer_type="Prodigy", do_zero_shot=True,
+                 fg_bg_xlayer_consist_loss_weight=5e-5, prompt_emb_delta_reg_weight=2e-4, **unused):
+        """the last four: v1-finetune-ada.yaml:40,50 and ddpm.py:3207-3219, 3246-3270 (regulariser weights / scales)."""
         super().__init__()
         assert parameterization == "eps"
         self.parameterization = parameterization
@@ -61,6 +63,10 @@ class DDPM(nn.Module):
         self.model = DiffusionWrapper(unet_config, conditioning_key)
         self.manual_accumulate_grad_batches = manual_accumulate_grad_batches
         self.grad_clip = grad_clip
+        self.optimizer_type = optimizer_type
+        self.do_zero_shot = do_zero_shot
+        self.fg_bg_xlayer_consist_loss_weight = fg_bg_xlayer_consist_loss_weight
+        self.prompt_emb_delta_reg_weight = prompt_emb_delta_reg_weight
         self.register_schedule(given_betas, beta_schedule, timesteps, linear_start, linear_end, cosine_s)
 
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
@@ -89,6 +95,41 @@ class DDPM(nn.Module):
     def predict_start_from_noise(self, x_t, t, noise):
         return (extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
                 - extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+
+_K_PER_INSTANCE = {}
+
+
+def _embeddings_per_instance(instance_idx):
+    """len(idx) // number of distinct instances (ddpm.py:4286).  ``torch.unique`` on a device tensor costs a device ->
+    host sync; the conditioning side hands over the same index tensor every iteration, so the count is remembered per
+    tensor (address, length, version)."""
+    key = (instance_idx.data_ptr(), instance_idx.numel(), instance_idx._version, str(instance_idx.device))
+    k = _K_PER_INSTANCE.get(key)
+    if k is None:
+        if len(_K_PER_INSTANCE) > 64:
+            _K_PER_INSTANCE.clear()
+        k = _K_PER_INSTANCE[key] = len(instance_idx) // len(torch.unique(instance_idx))
+    return k
+
+
+_TOKEN_WEIGHTS = {}
+
+
+def _token_weights(indices, ssb, ntok):
+    """[ssb, ntok] f32: w[b, m] = number of entries (b, m) among the first ssb instances' share of ``indices`` --
+    cached per index tensors, which the conditioning side reuses from iteration to iteration."""
+    bi, ti = indices
+    key = (bi.data_ptr(), ti.data_ptr(), bi.numel(), bi._version, ti._version, ssb, ntok, str(bi.device))
+    w = _TOKEN_WEIGHTS.get(key)
+    if w is None:
+        if len(_TOKEN_WEIGHTS) > 64:
+            _TOKEN_WEIGHTS.clear()
+        k = _embeddings_per_instance(bi)
+        w = torch.zeros(ssb, ntok, device=bi.device, dtype=torch.float32)
+        w.index_put_((bi[:ssb * k], ti[:ssb * k]), torch.ones(ssb * k, device=bi.device), accumulate=True)
+        _TOKEN_WEIGHTS[key] = w
+    return w
 
 
 class LatentDiffusion(DDPM):
@@ -230,34 +271,46 @@ class LatentDiffusion(DDPM):
         Per aligned layer: the score map of the subject tokens (mean over heads, sum over the K embeddings) against the
         map of the layer below it (``XLAYER_BELOW``), the finer one bilinearly resized to the coarser, demeaned cosine
         with a sign-preserving squared reference, weighted by the normalised ``XLAYER_WEIGHTS``.  -> (fg, bg) losses."""
-        from ...util import calc_ref_cosine_loss, normalize_dict_values, normalized_sum
+        from ...util import cosine_loss_rows, normalize_dict_values, normalized_sum
         layer_w = normalize_dict_values(dict(LatentDiffusion.XLAYER_WEIGHTS))
         below = LatentDiffusion.XLAYER_BELOW
 
-        def first_instances(idx):
-            k = len(idx[0]) // len(torch.unique(idx[0]))            # embeddings per instance
-            return (idx[0][:SSB_SIZE * k], idx[1][:SSB_SIZE * k]), k
-
-        groups = [first_instances(subj_indices)]
+        ntok = next(iter(ca_attnscores.values())).shape[-1]
+        groups = [_token_weights(subj_indices, SSB_SIZE, ntok)]
         if bg_indices is not None:
-            groups.append(first_instances(bg_indices))
+            groups.append(_token_weights(bg_indices, SSB_SIZE, ntok))
+        w_all = torch.stack(groups, dim=-1)[:, None]              # [SSB, 1, 77, groups]
         sums = [[] for _ in groups]
-        for layer, score in ca_attnscores.items():
+        maps = {}
+
+        def token_map(layer, gi):
+            """[SSB, N]: sum over the group's tokens of the head-mean score = score . w, w[b, m] = how often token m
+            of instance b is listed.  The reference gathers the (instance, token) rows and reduces them; as ONE
+            contraction per layer (both groups, and a layer serves two pairs) the forward reads the score tensor once,
+            coalesced, and autograd's backward is an outer product that yields the dense d attnscore the HIP backward
+            consumes -- the gather's backward is an index_put with accumulation over 77-strided slices of up to 40 MB."""
+            if layer not in maps:
+                m = torch.matmul(ca_attnscores[layer][:SSB_SIZE], w_all).mean(dim=1)                # [SSB, N, groups]
+                maps[layer] = m.permute(2, 0, 1)                                                    # [groups, SSB, N]
+            return maps[layer] if gi is None else maps[layer][gi]
+
+        for layer in ca_attnscores:
             if layer not in layer_w:
                 continue
-            fine, coarse = score, ca_attnscores[below[layer]]
-            if coarse.shape[2] > fine.shape[2]:
+            fine, coarse = layer, below[layer]
+            if ca_attnscores[coarse].shape[2] > ca_attnscores[fine].shape[2]:
                 fine, coarse = coarse, fine
-            hf, hc = int(np.sqrt(fine.shape[2])), int(np.sqrt(coarse.shape[2]))
-            for gi, ((bi, ti), k) in enumerate(groups):
-                # [B, heads, N, 77] -> rows (instance, token) -> [SSB, k, heads, N] -> head mean, token sum -> [SSB, N]
-                m_fine = fine[bi, :, :, ti].reshape(SSB_SIZE, k, *fine.shape[1:3]).mean(dim=2).sum(dim=1)
-                m_coarse = coarse[bi, :, :, ti].reshape(SSB_SIZE, k, *coarse.shape[1:3]).mean(dim=2).sum(dim=1)
-                m_fine = F.interpolate(m_fine.reshape(SSB_SIZE, 1, hf, hf), size=(hc, hc), mode="bilinear",
-                                       align_corners=False).reshape(SSB_SIZE, hc * hc)
-                sums[gi].append(layer_w[layer] * calc_ref_cosine_loss(
-                    m_fine, m_coarse, exponent=2, do_demean_first=True, first_n_dims_to_flatten=1, ref_grad_scale=1,
-                    aim_to_align=True))
+            hf, hc = int(np.sqrt(ca_attnscores[fine].shape[2])), int(np.sqrt(ca_attnscores[coarse].shape[2]))
+            G = len(groups)
+            # both groups' maps of all instances as one batch of G*SSB rows: one resize and one cosine per layer pair
+            m_fine, m_coarse = token_map(fine, None), token_map(coarse, None)                       # [G, SSB, N]
+            m_fine = F.interpolate(m_fine.reshape(G * SSB_SIZE, 1, hf, hf), size=(hc, hc), mode="bilinear",
+                                   align_corners=False).reshape(G, SSB_SIZE, hc * hc)
+            per_instance = cosine_loss_rows(m_fine, m_coarse, exponent=2, do_demean_first=True, ref_grad_scale=1,
+                                            aim_to_align=True)                                       # [G, SSB]
+            per_group = per_instance.mean(dim=1) * layer_w[layer]          # = calc_ref_cosine_loss per group
+            for gi in range(G):
+                sums[gi].append(per_group[gi])
         loss_fg = normalized_sum(sums[0])
         loss_bg = normalized_sum(sums[1]) if len(groups) > 1 else normalized_sum([])
         return loss_fg, loss_bg
@@ -396,7 +449,68 @@ class LatentDiffusion(DDPM):
         extra_info["img_mask"] = img_mask                                  # ddpm.py:2876
         model_output, x_noisy = self.guided_denoise(x_start, noise, t, (c_emb, c_in, extra_info))
         loss, grad = self.calc_recon_loss(model_output, noise, img_mask, fg_mask, 1.0, self.bg_pixel_weight)
-        return loss, grad, model_output, {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
+        aux = {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
+        reg, parts = self.recon_regularizers(extra_info, B, do_static_prompt_delta_reg=True)
+        if reg is not None:
+            aux["reg_loss"], aux["reg_parts"] = reg, parts
+            loss = loss + reg.detach()
+        return loss, grad, model_output, aux
+
+    def recon_regularizers(self, extra_info, block_size, do_static_prompt_delta_reg=True):
+        """The two terms a ``do_normal_recon`` iteration adds to the masked MSE (ddpm.py:3207-3270), when the
+        conditioning side supplies what they read:
+          * ``extra_info['c_static_emb_4b']`` (+ ``'prompt_emb_mask'``): calc_prompt_emb_delta_loss, weight
+            prompt_emb_delta_reg_weight x 0.5 (Prodigy) / 5 (zero-shot); off in Arc2Face-distillation iterations (:572);
+          * ``extra_info['subj_indices']`` (+ ``'bg_indices'``): the (instance, token) positions of the subject /
+            background embeddings -- the reference joins them from ``placeholder2indices`` with the embedding
+            manager's string sets (ddpm.py:2566-2569), which live behind the boundary -- and the captured
+            ``attnscore`` of this forward: calc_fg_bg_xlayer_consist_loss x (0.2 fg / 0.06 bg when zero-shot, else
+            1 / 0.3) x fg_bg_xlayer_consist_loss_weight.
+        -> (differentiable scalar or None, {name: float tensor}).  Backward: ``manual_backward``."""
+        from ...util import calc_prompt_emb_delta_loss
+        total, parts = None, {}
+        emb4 = extra_info.get("c_static_emb_4b")
+        if do_static_prompt_delta_reg and emb4 is not None and self.prompt_emb_delta_reg_weight > 0:
+            scale = 0.5 if self.optimizer_type == "Prodigy" else 1.0
+            if self.do_zero_shot:
+                scale /= 5
+            l_delta = calc_prompt_emb_delta_loss(emb4, extra_info.get("prompt_emb_mask"))
+            parts["static_prompt_delta"] = l_delta.detach()
+            total = l_delta * (self.prompt_emb_delta_reg_weight * scale)
+        subj = extra_info.get("subj_indices")
+        acts = extra_info.get("ca_layers_activations")
+        if subj is not None and acts is not None and acts.get("attnscore") and self.fg_bg_xlayer_consist_loss_weight > 0:
+            l_fg, l_bg = self.calc_fg_bg_xlayer_consist_loss(acts["attnscore"], subj, extra_info.get("bg_indices"),
+                                                              block_size)
+            fg_scale, bg_scale = (0.2, 0.06) if self.do_zero_shot else (1.0, 0.3)
+            term = (l_fg * fg_scale + l_bg * bg_scale) * self.fg_bg_xlayer_consist_loss_weight
+            parts["fg_xlayer_consist"] = l_fg.detach() if torch.is_tensor(l_fg) else l_fg
+            parts["bg_xlayer_consist"] = l_bg.detach() if torch.is_tensor(l_bg) else l_bg
+            total = term if total is None else total + term
+        if not torch.is_tensor(total):          # nothing supplied, or only empty sums (no aligned layer captured)
+            total = None
+        return total, parts
+
+    @staticmethod
+    def manual_backward(model_output, grad, aux=None):
+        """``manual_backward(loss)`` (ddpm.py:595) for the pair shared_step returns: the masked-MSE gradient enters at
+        ``model_output`` (computed by the loss kernel, not by autograd) and the regularisers' scalar at its own root, in
+        ONE pass over the tape, so the UNet's backward runs once and receives the attnscore gradients on the way."""
+        roots, grads = [], []
+        if isinstance(model_output, (list, tuple)):
+            for o, g in zip(model_output, grad):
+                if o.requires_grad:
+                    roots.append(o)
+                    grads.append(g)
+        elif model_output.requires_grad:
+            roots.append(model_output)
+            grads.append(grad)
+        reg = None if aux is None else aux.get("reg_loss")
+        if reg is not None and reg.requires_grad:
+            roots.append(reg)
+            grads.append(torch.ones_like(reg))
+        if roots:
+            torch.autograd.backward(roots, grads)
 
     def make_prefetcher(self):
         return LatentPrefetcher(self)
@@ -408,12 +522,7 @@ class LatentDiffusion(DDPM):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
         the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync)."""
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
-        if isinstance(model_output, (list, tuple)):                        # multi-step distillation: one backward
-            live = [(o, g) for o, g in zip(model_output, grad) if o.requires_grad]
-            if live:
-                torch.autograd.backward([o for o, _ in live], [g for _, g in live])
-        elif model_output.requires_grad:
-            model_output.backward(grad)                                    # == manual_backward(loss)
+        self.manual_backward(model_output, grad, aux)                      # == manual_backward(loss), ddpm.py:595
         if reducer is not None:
             reducer.reduce()
         self.batch_idx += 1

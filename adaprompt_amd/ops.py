@@ -371,9 +371,13 @@ def attention_capture_bwd(d_score, d_qs, q, k, dq, dk, heads):
     assert dq.dtype == BF16 and dq.shape == q.shape and (d_score is None or (dk is not None and dk.dtype == BF16))
     for t, shp in ((d_score, (B, heads, N, M)), (d_qs, (B, heads, N, d))):
         assert t is None or (t.dtype == F32 and tuple(t.shape) == shp and t.is_contiguous()), (None if t is None else t.shape, shp)
+    ws = None
+    if d_score is not None:
+        ws = torch.empty(_lib.size_query("adap_attention_capture_bwd_workspace_floats", B, heads, N, M, d), device=q.device,
+                         dtype=F32)
     _lib.call("adap_attention_capture_bwd", _ptr(d_score), _ptr(d_qs), q.data_ptr(), _rows_ld(q)[1], k.data_ptr(),
-              _rows_ld(k)[1], dq.data_ptr(), _rows_ld(dq)[1], _ptr(dk), 0 if dk is None else _rows_ld(dk)[1], B, heads, N, M, d,
-              float(d) ** -0.5, _stream())
+              _rows_ld(k)[1], dq.data_ptr(), _rows_ld(dq)[1], _ptr(dk), 0 if dk is None else _rows_ld(dk)[1], _ptr(ws), B, heads,
+              N, M, d, float(d) ** -0.5, _stream())
 
 
 # --------------------------------------------------------------------------------------------

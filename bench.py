@@ -89,7 +89,8 @@ def build_model(device, seed=0):
     ld.freeze_unet()
     with torch.device(device):
         hook = SyntheticSubjBasisGenerator()
-    ld.cond_fn = make_cond_fn(hook, capture=True)
+    # regs=True: the conditioning side also hands over what the recon iteration's two regularisers read (ddpm.py:3207-3270)
+    ld.cond_fn = make_cond_fn(hook, capture=True, regs=True)
     return ld, hook
 
 
@@ -213,7 +214,7 @@ def main():
             for i in range(2):                    # warm-up on the capture stream (weight packs, workspaces, BLAS handles)
                 draw(i)
                 loss, grad, out, aux = fwd()
-                out.backward(grad)
+                ld.manual_backward(out, grad, aux)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         reducer.zero()
@@ -221,7 +222,7 @@ def main():
         with torch.cuda.graph(g_f):
             loss, grad, out, aux = fwd()
         with torch.cuda.graph(g_b, pool=g_f.pool()):
-            out.backward(grad)
+            ld.manual_backward(out, grad, aux)
         torch.cuda.synchronize()
         reducer.zero()
         return g_f, g_b, loss
@@ -244,7 +245,7 @@ def main():
         pf_submit()                                    # encode of the next micro-batch goes to the side stream now
         loss, grad, out, aux = ld.shared_step(batch, t=t, noise=noise, x_start=x_start)
         reducer.wait()
-        out.backward(grad)
+        ld.manual_backward(out, grad, aux)
         reducer.reduce()
         ld.batch_idx += 1
         if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
@@ -266,7 +267,7 @@ def main():
         else:
             loss, grad, out, aux = fwd()
             reducer.wait()
-            out.backward(grad)
+            ld.manual_backward(out, grad, aux)
         reducer.reduce()
         ld.batch_idx += 1
         if ld.batch_idx % ld.manual_accumulate_grad_batches == 0:
@@ -530,7 +531,7 @@ def main():
             usubmit(i + 1)
             loss, grad, out, aux = ld.shared_step(batches[i % 2], t=t, noise=noise, x_start=x_start)
             red_u.wait()
-            out.backward(grad)
+            ld.manual_backward(out, grad, aux)
             red_u.reduce()
             if (i + 1) % ld.manual_accumulate_grad_batches == 0:
                 red_u.wait()
@@ -580,7 +581,8 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None, "vae_prefetch_stream": prefetch is not None,
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
-                                   "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, "
+                                   "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, masked MSE + "
+                                   "cross-layer attention consistency (gradient through the captured attnscore) + prompt-delta loss, "
                                    "hook stand-in with 149M trainable fp32 params, clip 0.5 + Prodigy step + LR schedule every 2nd micro-batch",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": reducer_bytes(world)},

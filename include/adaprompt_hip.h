@@ -134,10 +134,13 @@ int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, flo
 /* Gradient of those side outputs (ddpm.py:3246-3270: the recon iteration's cross-layer consistency loss reads
  * `attnscore` with gradient; stage 2 also `q`): dq16 / dk16 are the bf16 gradients adap_attention_bwd has written for
  * the same layer, and receive  += scale * dS k  (+ dim_head^-1/4 * dQs)  and  += scale * dS^T q  (f32 sum, rounded
- * once).  d_attnscore f32 [B][H][N][M] and d_q_scaled f32 [B][H][N][d], either may be NULL. */
+ * once).  d_attnscore f32 [B][H][N][M] and d_q_scaled f32 [B][H][N][d], either may be NULL; workspace (needed with
+ * d_attnscore): adap_attention_capture_bwd_workspace_floats(...) floats -- dk is reduced over 128-row chunks of the
+ * queries in two stages, fixed order. */
+long adap_attention_capture_bwd_workspace_floats(int B, int H, int N, int M, int d);
 int adap_attention_capture_bwd(const float* d_attnscore, const float* d_q_scaled, const void* q, long ldq,
-                               const void* k, long ldk, void* dq16, long lddq, void* dk16, long lddk, int B, int H,
-                               int N, int M, int d, float scale, void* stream);
+                               const void* k, long ldk, void* dq16, long lddq, void* dk16, long lddk,
+                               float* workspace, int B, int H, int N, int M, int d, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEGLU, attention.py:32-40: h = [a | gate] bf16 [rows][2*inner] -> a * gelu(gate) bf16 [rows][inner].

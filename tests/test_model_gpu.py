@@ -283,6 +283,80 @@ def test_training_step_matches_oracle():
     assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
 
 
+def test_recon_step_with_regularizers_matches_oracle():
+    """a9: the do_normal_recon iteration = masked MSE + cross-layer consistency of the subject / background attention
+    maps (gradient THROUGH the captured attnscore, adap_attention_capture_bwd) + prompt-delta loss on the four-way static
+    embeddings (ddpm.py:3207-3270).  The regulariser weights are raised from 5e-5 / 2e-4 to O(1) so that their gradients
+    are not lost beside the MSE gradient; loss parts and d loss / d context against the oracle."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import ldm_oracle as O
+    from oracle import regs_oracle as R
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                         {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
+                         fg_bg_xlayer_consist_loss_weight=2.0, prompt_emb_delta_reg_weight=3.0)
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    missing, unexpected = ld.load_state_dict({**usd, **synth.synthetic_vae_state_dict(vdd)}, strict=False)
+    assert not unexpected
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    B, D = 2, ucfg["context_dim"]
+    x0 = synth.synthetic_input("reg.x0", (B, 4, 64, 64))
+    noise = synth.synthetic_input("reg.noise", (B, 4, 64, 64))
+    t = torch.tensor([300, 750])
+    emb4 = synth.synthetic_input("reg.emb4", (4 * B, 16, 77, D))            # subj single | subj comp | cls single | cls comp
+    pmask = torch.full((4 * B, 77, 1), 0.5)
+    for blk, n_tok in enumerate((21, 31, 21, 31)):
+        pmask[blk * B:(blk + 1) * B, :n_tok] = 1.0
+    inst = torch.arange(B)
+    subj = (inst.repeat_interleave(16), torch.arange(4, 20).repeat(B))
+    bgi = (inst.repeat_interleave(4), torch.arange(24, 28).repeat(B))
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+    base = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+            "is_training": True, "capture_distill_attn": True}
+
+    # ---- oracle: the same three terms with the reference's scales (zero-shot + Prodigy: 0.1 | 0.2 / 0.06)
+    e_ref = emb4.clone().requires_grad_(True)
+    ctx_ref = e_ref[:B].reshape(16 * B, 77, D)                              # the UNet sees the subject-single block
+    sched = O.make_schedule()
+    ex_ref = dict(base, img_mask=im64)
+    eps_ref = O.unet_forward(usd, ucfg, O.q_sample(sched, x0, t, noise), t, ctx_ref, ex_ref)
+    mse_ref, _ = O.calc_recon_loss(eps_ref, noise, im64, fg64, 1.0, 0.1)
+    fg_ref, bg_ref = R.calc_fg_bg_xlayer_consist_loss(ex_ref["ca_layers_activations"]["attnscore"], subj, bgi, B)
+    pd_ref = R.calc_prompt_emb_delta_loss(e_ref, pmask.clone())
+    total_ref = mse_ref + (fg_ref * 0.2 + bg_ref * 0.06) * 2.0 + pd_ref * 3.0 * 0.1
+    total_ref.backward()
+
+    # ---- HIP
+    e_hip = emb4.to(dev()).clone().requires_grad_(True)
+    ctx_hip = e_hip[:B].reshape(16 * B, 77, D)
+    ex_hip = dict(base, subj_indices=tuple(i.to(dev()) for i in subj), bg_indices=tuple(i.to(dev()) for i in bgi),
+                  c_static_emb_4b=e_hip, prompt_emb_mask=pmask.to(dev()).clone())
+    batch = {"fg_mask": fg64[:, 0].to(dev()), "aug_mask": im64[:, 0].to(dev())}
+    loss, grad, out, aux = ld.shared_step(batch, t=t.to(dev()), noise=noise.to(dev()), cond=(ctx_hip, None, ex_hip),
+                                          x_start=x0.to(dev()))
+    ld.manual_backward(out, grad, aux)
+    parts = aux["reg_parts"]
+    print(f"[recon+regs] total hip {float(loss):.6f} ref {float(total_ref.detach()):.6f} | fg {float(parts['fg_xlayer_consist']):.5f} "
+          f"/ {float(fg_ref):.5f}  bg {float(parts['bg_xlayer_consist']):.5f} / {float(bg_ref):.5f}  "
+          f"delta {float(parts['static_prompt_delta']):.5f} / {float(pd_ref):.5f}")
+    assert abs(float(parts["fg_xlayer_consist"]) - float(fg_ref)) < 2e-2 * abs(float(fg_ref))
+    assert abs(float(parts["bg_xlayer_consist"]) - float(bg_ref)) < 2e-2 * abs(float(bg_ref))
+    assert abs(float(parts["static_prompt_delta"]) - float(pd_ref)) < 1e-4 * abs(float(pd_ref))
+    assert abs(float(loss) - float(total_ref.detach())) < 5e-3 * float(total_ref.detach())
+    ge = rel_err(e_hip.grad.cpu(), e_ref.grad)
+    # the regularisers' own share of the gradient: remove the MSE part (computed without them on both sides)
+    e_ref2 = emb4.clone().requires_grad_(True)
+    ex2 = dict(base, img_mask=im64)
+    eps2 = O.unet_forward(usd, ucfg, O.q_sample(sched, x0, t, noise), t, e_ref2[:B].reshape(16 * B, 77, D), ex2)
+    O.calc_recon_loss(eps2, noise, im64, fg64, 1.0, 0.1)[0].backward()
+    reg_share = float((e_ref.grad - e_ref2.grad).norm() / e_ref.grad.norm())
+    print(f"[recon+regs] d loss / d embeddings rel {ge:.3e}; the regularisers carry {reg_share:.2f} of its norm")
+    assert reg_share > 0.3          # otherwise this test would not see them
+    assert ge < 5e-2
+
+
 def test_training_loop_prodigy_two_optimizer_steps_vs_oracle():
     """a1 end to end: four micro-batches through LatentDiffusion.training_step with the flat-buffer Prodigy, the
     fused 0.5 clip, the GradReducer on the optimiser's buffer and the LR schedule -- gradients accumulate over two
