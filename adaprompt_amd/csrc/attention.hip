@@ -854,14 +854,18 @@ extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long l
 __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __restrict__ q, long ldq,
                                                            const uint16_t* __restrict__ k, long ldk,
                                                            float* __restrict__ score, float* __restrict__ prob,
-                                                           float* __restrict__ qout, int B, int H, int N, int M, int d,
-                                                           float scale) {
+                                                           float* __restrict__ qout, const float* __restrict__ tok_w,
+                                                           float* __restrict__ tokmap, int G, int B, int H, int N, int M,
+                                                           int d, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dp = d + 4;                  // padded row: float4 reads of consecutive keys land on different banks
     float* sK = (float*)smem;              // [M][dp]
     float* sQ = sK + M * dp;               // [4 waves][d]
+    float* sW = sQ + 4 * d;                // [M][G] token weights (tokmap only)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    if (tokmap)
+        for (int idx = tid; idx < M * G; idx += 256) sW[idx] = tok_w[(size_t)b * M * G + idx];
     for (int idx = tid; idx < M * (d / 4); idx += 256) {
         int key = idx / (d / 4), c4 = idx - key * (d / 4);
         uint2 raw = *(const uint2*)(k + ((size_t)b * M + key) * ldk + head * d + 4 * c4);
@@ -918,17 +922,31 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
                 if (prob) prob[base + key] = __expf(sv[kk] - mx) / sum;
             }
         }
+        if (tokmap) {       // sum over the listed tokens of this head's scores: sum_m score[n][m] * w[m][g]
+            for (int g = 0; g < G; ++g) {
+                float tsum = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    int key = lane + 64 * kk;
+                    if (key < M) tsum += sv[kk] * sW[key * G + g];
+                }
+                tsum = wave_sum(tsum);
+                if (lane == 0) tokmap[((((size_t)b * H + head) * N + n) * G) + g] = tsum;
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
-                                      float* q_scaled, int B, int H, int N, int M, int d, float scale, void* stream) {
-    ADAP_REQUIRE(q && k && (attnscore || attn || q_scaled), ADAP_ERR_SHAPE, "attention_capture: null pointer");
+                                      float* q_scaled, const float* tok_w, float* tokmap, int G, int B, int H, int N, int M,
+                                      int d, float scale, void* stream) {
+    ADAP_REQUIRE(q && k && (attnscore || attn || q_scaled || tokmap), ADAP_ERR_SHAPE, "attention_capture: null pointer");
+    ADAP_REQUIRE(!tokmap || (tok_w && G >= 1 && G <= 4), ADAP_ERR_SHAPE, "attention_capture: token maps need weights, 1 <= G <= 4");
     ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture: M=%d (cross-attention only, <= 192)", M);
     ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture: d=%d", d);
     ADAP_REQUIRE(d % 4 == 0, ADAP_ERR_UNSUPPORTED, "attention_capture: d must be a multiple of 4");
-    size_t lds = ((size_t)M * (d + 4) + 4 * d) * 4;
+    size_t lds = ((size_t)M * (d + 4) + 4 * d + (tokmap ? (size_t)M * G : 0)) * 4;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void*)attn_capture_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -936,7 +954,7 @@ extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, lo
     }
     dim3 grid((N + CAP_ROWS - 1) / CAP_ROWS, B * H);
     hipLaunchKernelGGL(attn_capture_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)q, ldq,
-                       (const uint16_t*)k, ldk, attnscore, attn, q_scaled, B, H, N, M, d, scale);
+                       (const uint16_t*)k, ldk, attnscore, attn, q_scaled, tok_w, tokmap, G, B, H, N, M, d, scale);
     return adap_check_launch("attention_capture");
 }
 
@@ -1069,6 +1087,140 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dk_finish_kernel(const f
         uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
         *o = f32_to_bf16(bf16_to_f32(*o) + scale * s);
     }
+}
+
+// =============================================================================================
+// Token maps: what the cross-layer consistency loss actually reads of attnscore is, per head, the sum over the
+// subject (background) tokens, T[b][h][n][g] = sum_m attnscore[b][h][n][m] * w[b][m][g].  Its gradient never needs
+// the dense [B][H][N][M] tensor:
+//   dq[n] += scale * sum_g dT[n][g] * kw[g],   kw[g] = sum_m w[m][g] k[m]            (G vectors per (b, h))
+//   dk[m] += scale * sum_g w[m][g]  * gq[g],   gq[g] = sum_n dT[n][g] q[n]           (G vectors per (b, h))
+// gq is a reduction over the queries: 128-row chunks, two stages, fixed order.
+// =============================================================================================
+#define TOK_MAXG 4
+__global__ __launch_bounds__(256) void attn_tokmap_bwd_dq_kernel(const float* __restrict__ dt, const float* __restrict__ tok_w,
+                                                                 const uint16_t* __restrict__ k, long ldk,
+                                                                 uint16_t* __restrict__ dq, long lddq, int B, int H, int N,
+                                                                 int M, int d, int G, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* kw = (float*)smem;               // [G][d]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    for (int idx = tid; idx < G * d; idx += 256) {
+        const int g = idx / d, c = idx - g * d;
+        float a = 0.f;
+        for (int m = 0; m < M; ++m)
+            a += tok_w[((size_t)b * M + m) * G + g] * bf16_to_f32(k[((size_t)b * M + m) * ldk + head * d + c]);
+        kw[idx] = a;
+    }
+    __syncthreads();
+    for (int rr = w; rr < CAP_ROWS; rr += 4) {
+        const int n = blockIdx.x * CAP_ROWS + rr;
+        if (n >= N) break;
+        const float* row = dt + (((size_t)b * H + head) * N + n) * G;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) {
+                float v = 0.f;
+                for (int g = 0; g < G; ++g) v += row[g] * kw[g * d + c];
+                uint16_t* o = dq + ((size_t)b * N + n) * lddq + head * d + c;
+                *o = f32_to_bf16(bf16_to_f32(*o) + scale * v);
+            }
+        }
+    }
+}
+
+// stage 1 of gq: part[bh][chunk][g][c] = sum over the chunk's rows of dT[n][g] * q[n][c]
+__global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __restrict__ dt, const uint16_t* __restrict__ q,
+                                                                 long ldq, float* __restrict__ part, int B, int H, int N, int d,
+                                                                 int G) {
+    __shared__ float red[4][TOK_MAXG * 3][64];
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    const int n0 = blockIdx.x * CAPB_ROWS;
+    const int rows = min(CAPB_ROWS, N - n0);
+    float acc[TOK_MAXG][3];
+#pragma unroll
+    for (int g = 0; g < TOK_MAXG; ++g)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[g][j] = 0.f;
+    const float* dtb = dt + (((size_t)b * H + head) * N + n0) * G;
+    const uint16_t* qb = q + ((size_t)b * N + n0) * ldq + head * d;
+#pragma unroll 4
+    for (int r = rl; r < rows; r += 4) {
+        float qv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qv[j] = (cl + 64 * j < d) ? bf16_to_f32(qb[(size_t)r * ldq + cl + 64 * j]) : 0.f;
+#pragma unroll
+        for (int g = 0; g < TOK_MAXG; ++g) {
+            const float t = g < G ? dtb[(size_t)r * G + g] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[g][j] += t * qv[j];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < TOK_MAXG; ++g)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[rl][g * 3 + j][cl] = acc[g][j];
+    __syncthreads();
+    for (int idx = tid; idx < TOK_MAXG * 3 * 64; idx += 256) {
+        const int gj = idx >> 6, c0 = idx & 63;
+        const int g = gj / 3, j = gj - 3 * g, c = c0 + 64 * j;
+        if (g < G && c < d) {
+            const float v = ((red[0][gj][c0] + red[1][gj][c0]) + red[2][gj][c0]) + red[3][gj][c0];
+            part[(((size_t)bh * gridDim.x + blockIdx.x) * G + g) * d + c] = v;
+        }
+    }
+}
+
+// stage 2: one thread per (bh, c): gq[g] = sum_chunk part (fixed order), then dk[m][c] += scale * sum_g w[m][g] gq[g]
+__global__ __launch_bounds__(256) void attn_tokmap_bwd_dk_kernel(const float* __restrict__ part, const float* __restrict__ tok_w,
+                                                                 uint16_t* __restrict__ dk, long lddk, int B, int H, int M,
+                                                                 int d, int G, int nchunks, float scale) {
+    const long total = (long)B * H * d;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % d);
+        const long bh = i / d;
+        const int b = (int)(bh / H), head = (int)(bh - (long)b * H);
+        float gq[TOK_MAXG];
+        for (int g = 0; g < TOK_MAXG; ++g) {
+            gq[g] = 0.f;
+            if (g < G)
+                for (int k = 0; k < nchunks; ++k) gq[g] += part[((bh * nchunks + k) * G + g) * d + c];
+        }
+        for (int m = 0; m < M; ++m) {
+            float v = 0.f;
+            for (int g = 0; g < G; ++g) v += tok_w[((size_t)b * M + m) * G + g] * gq[g];
+            if (v != 0.f) {
+                uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
+                *o = f32_to_bf16(bf16_to_f32(*o) + scale * v);
+            }
+        }
+    }
+}
+
+extern "C" long adap_attention_tokmap_bwd_workspace_floats(int B, int H, int N, int d, int G) {
+    return (long)B * H * ((N + CAPB_ROWS - 1) / CAPB_ROWS) * G * d;
+}
+
+extern "C" int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k,
+                                         long ldk, void* dq16, long lddq, void* dk16, long lddk, float* workspace, int B, int H,
+                                         int N, int M, int d, int G, float scale, void* stream) {
+    ADAP_REQUIRE(d_tokmap && tok_w && q && k && dq16 && dk16 && workspace, ADAP_ERR_SHAPE, "attention_tokmap_bwd: null pointer");
+    ADAP_REQUIRE(G >= 1 && G <= TOK_MAXG, ADAP_ERR_UNSUPPORTED, "attention_tokmap_bwd: G=%d", G);
+    ADAP_REQUIRE(d >= 1 && d <= 160 && M >= 1, ADAP_ERR_UNSUPPORTED, "attention_tokmap_bwd: d=%d M=%d", d, M);
+    ADAP_REQUIRE((long)B * H <= 65535, ADAP_ERR_SHAPE, "attention_tokmap_bwd: B*H");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunks = (N + CAPB_ROWS - 1) / CAPB_ROWS;
+    hipLaunchKernelGGL(attn_tokmap_bwd_dq_kernel, dim3((N + CAP_ROWS - 1) / CAP_ROWS, B * H), dim3(256), (size_t)G * d * 4, s,
+                       d_tokmap, tok_w, (const uint16_t*)k, ldk, (uint16_t*)dq16, lddq, B, H, N, M, d, G, scale);
+    hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), 0, s, d_tokmap, (const uint16_t*)q, ldq,
+                       workspace, B, H, N, d, G);
+    const long total = (long)B * H * d;
+    hipLaunchKernelGGL(attn_tokmap_bwd_dk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, tok_w,
+                       (uint16_t*)dk16, lddk, B, H, M, d, G, nchunks, scale);
+    return adap_check_launch("attention_tokmap_bwd");
 }
 
 extern "C" long adap_attention_capture_bwd_workspace_floats(int B, int H, int N, int M, int d) {

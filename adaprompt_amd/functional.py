@@ -210,7 +210,7 @@ class ResBlockFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture):
+    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None):
         B, H, W, C = x.shape
         N = H * W
         same_ctx = ctx_k is ctx_v or (ctx_k.data_ptr() == ctx_v.data_ptr() and ctx_k.shape == ctx_v.shape)
@@ -242,7 +242,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         o2, lse2 = ops.attention_fwd(q2, k2, v2, heads, None)
         cap = (None, None, None)
         if capture:
-            cap = ops.attention_capture(q2, k2, heads)
+            cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w)        # (+ token maps when tok_w is given)
         to2 = P["to_out2"]
         t2, _ = ops.linear(o2, to2.fwd, C, bias=to2.bias, residual=t1)
         # --- GEGLU feed-forward -----------------------------------------------------------------
@@ -256,6 +256,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         out, _ = ops.linear(t3, pout.fwd, C, bias=pout.bias, residual=x.view(B, N, C))
         ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
         ctx.key_mask = key_mask
+        ctx.tok_w = tok_w if capture else None
         tr = P.get("train") is not None      # weight gradients also need each contraction's input operand
         ctx.save_for_backward(x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh,
                               ctx_k, ctx_v, *((xn, n1, n2, n3, gg, t3) if tr else (None,) * 6))
@@ -270,7 +271,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g, g_score=None, _g_prob=None, g_qs=None):
+    def backward(ctx, g, g_score=None, _g_prob=None, g_qs=None, g_tokmap=None):
         (x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh, ctx_k,
          ctx_v, xn, n1, n2, n3, gg, t3) = ctx.saved_tensors
         P, heads = ctx.P, ctx.heads
@@ -310,6 +311,8 @@ class SpatialTransformerFn(torch.autograd.Function):
             ops.attention_capture_bwd(None if g_score is None else g_score.contiguous(),
                                       None if g_qs is None else g_qs.contiguous(), q2, kv2[..., :C], dq2,
                                       dkv2[..., :C], heads)
+        if g_tokmap is not None:                         # ... and of the token maps (compact: no dense d attnscore)
+            ops.attention_tokmap_bwd(g_tokmap.contiguous(), ctx.tok_w, q2, kv2[..., :C], dq2, dkv2[..., :C], heads)
         gn2, _ = _lin_bwd(dq2, P["q2"])
         if T is not None:
             _dw_lin(T, "to_out2", o2, gt2h)
@@ -348,7 +351,7 @@ class SpatialTransformerFn(torch.autograd.Function):
             _dw_norm(T, "norm", gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, 0)
         gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
-        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None
+        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

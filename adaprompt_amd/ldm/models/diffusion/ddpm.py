@@ -97,41 +97,6 @@ class DDPM(nn.Module):
                 - extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
 
 
-_K_PER_INSTANCE = {}
-
-
-def _embeddings_per_instance(instance_idx):
-    """len(idx) // number of distinct instances (ddpm.py:4286).  ``torch.unique`` on a device tensor costs a device ->
-    host sync; the conditioning side hands over the same index tensor every iteration, so the count is remembered per
-    tensor (address, length, version)."""
-    key = (instance_idx.data_ptr(), instance_idx.numel(), instance_idx._version, str(instance_idx.device))
-    k = _K_PER_INSTANCE.get(key)
-    if k is None:
-        if len(_K_PER_INSTANCE) > 64:
-            _K_PER_INSTANCE.clear()
-        k = _K_PER_INSTANCE[key] = len(instance_idx) // len(torch.unique(instance_idx))
-    return k
-
-
-_TOKEN_WEIGHTS = {}
-
-
-def _token_weights(indices, ssb, ntok):
-    """[ssb, ntok] f32: w[b, m] = number of entries (b, m) among the first ssb instances' share of ``indices`` --
-    cached per index tensors, which the conditioning side reuses from iteration to iteration."""
-    bi, ti = indices
-    key = (bi.data_ptr(), ti.data_ptr(), bi.numel(), bi._version, ti._version, ssb, ntok, str(bi.device))
-    w = _TOKEN_WEIGHTS.get(key)
-    if w is None:
-        if len(_TOKEN_WEIGHTS) > 64:
-            _TOKEN_WEIGHTS.clear()
-        k = _embeddings_per_instance(bi)
-        w = torch.zeros(ssb, ntok, device=bi.device, dtype=torch.float32)
-        w.index_put_((bi[:ssb * k], ti[:ssb * k]), torch.ones(ssb * k, device=bi.device), accumulate=True)
-        _TOKEN_WEIGHTS[key] = w
-    return w
-
-
 class LatentDiffusion(DDPM):
     """The recon-distillation iteration core of the reference ``LatentDiffusion`` (ddpm.py:710-3457)."""
 
@@ -265,23 +230,27 @@ class LatentDiffusion(DDPM):
     XLAYER_WEIGHTS = {8: 0.5, 12: 1., 16: 1., 17: 1., 18: 1., 19: 0.5, 20: 0.5, 21: 0.5, 22: 0.25, 23: 0.25, 24: 0.25}
     XLAYER_BELOW = {8: 7, 12: 8, 16: 12, 17: 16, 18: 17, 19: 18, 20: 19, 21: 20, 22: 21, 23: 22, 24: 23}
 
-    def calc_fg_bg_xlayer_consist_loss(self, ca_attnscores, subj_indices, bg_indices, SSB_SIZE):
+    def calc_fg_bg_xlayer_consist_loss(self, ca_attnscores, subj_indices, bg_indices, SSB_SIZE, token_maps=None):
         """ca_attnscores {layer_idx: attnscore [B, heads, N, 77]} as captured by the UNet (WITH gradient);
         subj_indices / bg_indices: (instance idx, token idx) of the subject / background embeddings in the prompts.
         Per aligned layer: the score map of the subject tokens (mean over heads, sum over the K embeddings) against the
         map of the layer below it (``XLAYER_BELOW``), the finer one bilinearly resized to the coarser, demeaned cosine
         with a sign-preserving squared reference, weighted by the normalised ``XLAYER_WEIGHTS``.  -> (fg, bg) losses."""
-        from ...util import cosine_loss_rows, normalize_dict_values, normalized_sum
+        from ...util import cosine_loss_rows, normalize_dict_values, normalized_sum, token_weight_matrix
         layer_w = normalize_dict_values(dict(LatentDiffusion.XLAYER_WEIGHTS))
         below = LatentDiffusion.XLAYER_BELOW
 
-        ntok = next(iter(ca_attnscores.values())).shape[-1]
-        groups = [_token_weights(subj_indices, SSB_SIZE, ntok)]
-        if bg_indices is not None:
-            groups.append(_token_weights(bg_indices, SSB_SIZE, ntok))
-        w_all = torch.stack(groups, dim=-1)[:, None]              # [SSB, 1, 77, groups]
+        first = next(iter(ca_attnscores.values()))
+        idx_groups = [subj_indices] + ([bg_indices] if bg_indices is not None else [])
+        # only the first SSB instances count (ddpm.py:4292-4301): every instance lists the same number of tokens
+        w_full = token_weight_matrix(idx_groups, first.shape[0], first.shape[-1])       # [B, 77, groups]
+        groups = idx_groups
+        w_all = w_full[:SSB_SIZE, None]                                                 # [SSB, 1, 77, groups]
         sums = [[] for _ in groups]
         maps = {}
+        # ``token_maps`` = ({layer: [B, heads, N, groups]}, weights): the per-head token maps the capture kernel emitted
+        # for exactly these weights (UNetModel.forward) -- then the dense attnscore is not touched at all
+        tm = token_maps[0] if (token_maps is not None and token_maps[1] is w_full) else None
 
         def token_map(layer, gi):
             """[SSB, N]: sum over the group's tokens of the head-mean score = score . w, w[b, m] = how often token m
@@ -290,7 +259,10 @@ class LatentDiffusion(DDPM):
             coalesced, and autograd's backward is an outer product that yields the dense d attnscore the HIP backward
             consumes -- the gather's backward is an index_put with accumulation over 77-strided slices of up to 40 MB."""
             if layer not in maps:
-                m = torch.matmul(ca_attnscores[layer][:SSB_SIZE], w_all).mean(dim=1)                # [SSB, N, groups]
+                if tm is not None:
+                    m = tm[layer][:SSB_SIZE].mean(dim=1)                                            # [SSB, N, groups]
+                else:
+                    m = torch.matmul(ca_attnscores[layer][:SSB_SIZE], w_all).mean(dim=1)
                 maps[layer] = m.permute(2, 0, 1)                                                    # [groups, SSB, N]
             return maps[layer] if gi is None else maps[layer][gi]
 
@@ -480,8 +452,11 @@ class LatentDiffusion(DDPM):
         subj = extra_info.get("subj_indices")
         acts = extra_info.get("ca_layers_activations")
         if subj is not None and acts is not None and acts.get("attnscore") and self.fg_bg_xlayer_consist_loss_weight > 0:
+            tm = None
+            if acts.get("attnscore_tokmap") and extra_info.get("ca_tokmap_weights") is not None:
+                tm = (acts["attnscore_tokmap"], extra_info["ca_tokmap_weights"])
             l_fg, l_bg = self.calc_fg_bg_xlayer_consist_loss(acts["attnscore"], subj, extra_info.get("bg_indices"),
-                                                              block_size)
+                                                              block_size, token_maps=tm)
             fg_scale, bg_scale = (0.2, 0.06) if self.do_zero_shot else (1.0, 0.3)
             term = (l_fg * fg_scale + l_bg * bg_scale) * self.fg_bg_xlayer_consist_loss_weight
             parts["fg_xlayer_consist"] = l_fg.detach() if torch.is_tensor(l_fg) else l_fg

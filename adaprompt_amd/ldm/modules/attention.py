@@ -139,10 +139,18 @@ class SpatialTransformer(nn.Module):
             m2 = F.interpolate(mask.float(), size=(H, W), mode="nearest")
             key_mask = (m2.reshape(B, H * W) != 0).to(torch.uint8).contiguous()
         capture = bool(blk.attn2.save_attn_vars)
-        res = HF.SpatialTransformerFn.apply(x.contiguous(), k_ctx, v_ctx, self._packs(same), self.n_heads, key_mask, capture)
+        # token weights [B, 77, G] set by UNetModel.forward when the conditioning side names the subject / background
+        # token positions: the capture then also returns the per-head token maps (functional / ops.attention_capture)
+        tok_w = getattr(blk.attn2, "token_weights", None) if capture else None
+        if tok_w is not None and (tok_w.shape[0] != B or tok_w.shape[1] != k_ctx.shape[1]):
+            tok_w = None
+        res = HF.SpatialTransformerFn.apply(x.contiguous(), k_ctx, v_ctx, self._packs(same), self.n_heads, key_mask, capture,
+                                            tok_w)
         if capture:
-            out, score, prob, qs = res
+            out, score, prob, qs = res[:4]
             blk.attn2.cached_activations = {"q": qs, "attn": prob, "attnscore": score}
+            if tok_w is not None:
+                blk.attn2.cached_activations["attnscore_tokmap"] = res[4]
         else:
             out = res
         if self.save_feat:

@@ -349,6 +349,20 @@ class UNetModel(nn.Module):
             old, _ = self.set_cross_attn_flags(ca_flag_dict={"save_attn_vars": True}, ca_layer_indices=distill)
             stack.append((old, distill))
 
+        # The cross-layer consistency loss (ddpm.py:4259-4387) reads, of every captured attnscore, only the sum over
+        # the subject / background tokens.  When the conditioning side names those positions, the capture kernel also
+        # emits these token maps per head (tiny, [B,h,N,G]) and their gradient re-enters the attention backward
+        # without a dense [B,h,N,77] gradient ever being formed.
+        tok_w = None
+        if distill and ei.get("subj_indices") is not None and context is not None and torch.is_tensor(context):
+            from ...util import token_weight_matrix
+            idx_groups = [ei["subj_indices"]] + ([ei["bg_indices"]] if ei.get("bg_indices") is not None else [])
+            ntok = context.shape[1] // (2 if iter_type == "mix_hijk" else 1)
+            tok_w = token_weight_matrix(idx_groups, x.shape[0], ntok)
+        for m_ in self.modules():
+            if isinstance(m_, SpatialTransformer):
+                m_.transformer_blocks[0].attn2.token_weights = tok_w
+
         t_emb = timestep_embedding(timesteps, self.model_channels)
         te = self.time_embed
         if torch.is_grad_enabled() and any(p.requires_grad for p in te.parameters()):
@@ -398,6 +412,9 @@ class UNetModel(nn.Module):
         if extra_info is not None:
             extra_info["ca_layers_activations"] = {
                 key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q")}
+            if tok_w is not None and acts and all("attnscore_tokmap" in a for a in acts.values()):
+                extra_info["ca_layers_activations"]["attnscore_tokmap"] = {li: acts[li]["attnscore_tokmap"] for li in acts}
+                extra_info["ca_tokmap_weights"] = tok_w
         for old, idxs in reversed(stack):
             self.set_cross_attn_flags(ca_flag_dict=old, ca_layer_indices=idxs)
 

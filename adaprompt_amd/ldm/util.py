@@ -219,3 +219,25 @@ def calc_prompt_emb_delta_loss(static_embeddings, prompt_emb_mask, cls_delta_gra
     return calc_ref_cosine_loss(ortho_subtract(subj_comp, subj_single), ortho_subtract(cls_comp, cls_single),
                                 emb_mask=token_weights, do_demean_first=True, first_n_dims_to_flatten=3,
                                 ref_grad_scale=cls_delta_grad_scale, aim_to_align=True)
+
+
+_TOKEN_WEIGHTS = {}
+
+
+def token_weight_matrix(index_groups, batch, ntok):
+    """[batch, ntok, G] f32, one column per group of (instance idx, token idx) pairs (subject tokens, background
+    tokens): w[b, m, g] = how often (b, m) is listed in group g.  A sum over a group's tokens of a [.., ntok] tensor is
+    then a contraction with column g.  Cached per index tensors -- the conditioning side reuses them every iteration,
+    and building the matrix costs an index_put."""
+    key = tuple((bi.data_ptr(), ti.data_ptr(), bi.numel(), bi._version, ti._version) for bi, ti in index_groups) + \
+        (batch, ntok, str(index_groups[0][0].device))
+    w = _TOKEN_WEIGHTS.get(key)
+    if w is None:
+        if len(_TOKEN_WEIGHTS) > 64:
+            _TOKEN_WEIGHTS.clear()
+        dev = index_groups[0][0].device
+        w = torch.zeros(batch, ntok, len(index_groups), device=dev, dtype=torch.float32)
+        for g, (bi, ti) in enumerate(index_groups):
+            w[:, :, g].index_put_((bi, ti), torch.ones(bi.numel(), device=dev), accumulate=True)
+        _TOKEN_WEIGHTS[key] = w
+    return w

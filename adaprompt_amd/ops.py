@@ -348,8 +348,9 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=Non
     return dq, dk, dv
 
 
-def attention_capture(q, k, heads, want_q=True):
-    """side outputs of attention.py:245-255 -> (attnscore, attn, q_scaled)."""
+def attention_capture(q, k, heads, want_q=True, tok_w=None):
+    """side outputs of attention.py:245-255 -> (attnscore, attn, q_scaled[, tokmap]).  ``tok_w`` f32 [B, M, G]: also
+    the per-head token maps [B, heads, N, G] = attnscore . tok_w (what the cross-layer consistency loss reads)."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
@@ -357,9 +358,28 @@ def attention_capture(q, k, heads, want_q=True):
     score = torch.empty(B, heads, N, M, device=dev, dtype=F32)
     prob = torch.empty(B, heads, N, M, device=dev, dtype=F32)
     qs = torch.empty(B, heads, N, d, device=dev, dtype=F32) if want_q else None
+    tokmap, G = None, 0
+    if tok_w is not None:
+        assert tok_w.dtype == F32 and tok_w.is_contiguous() and tok_w.shape[:2] == (B, M) and tok_w.shape[2] <= 4, tok_w.shape
+        G = tok_w.shape[2]
+        tokmap = torch.empty(B, heads, N, G, device=dev, dtype=F32)
     _lib.call("adap_attention_capture", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], score.data_ptr(),
-              prob.data_ptr(), _ptr(qs), B, heads, N, M, d, float(d) ** -0.5, _stream())
-    return score, prob, qs
+              prob.data_ptr(), _ptr(qs), _ptr(tok_w), _ptr(tokmap), G, B, heads, N, M, d, float(d) ** -0.5, _stream())
+    return (score, prob, qs) if tok_w is None else (score, prob, qs, tokmap)
+
+
+def attention_tokmap_bwd(d_tokmap, tok_w, q, k, dq, dk, heads):
+    """add the gradient of the token maps (``attention_capture(..., tok_w)``) into the layer's bf16 dq / dk."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    d = C // heads
+    G = tok_w.shape[2]
+    assert d_tokmap.dtype == F32 and d_tokmap.is_contiguous() and tuple(d_tokmap.shape) == (B, heads, N, G)
+    assert dq.dtype == BF16 and dk.dtype == BF16 and dq.shape == q.shape and dk.shape == k.shape
+    ws = torch.empty(_lib.size_query("adap_attention_tokmap_bwd_workspace_floats", B, heads, N, d, G), device=q.device, dtype=F32)
+    _lib.call("adap_attention_tokmap_bwd", d_tokmap.data_ptr(), tok_w.data_ptr(), q.data_ptr(), _rows_ld(q)[1], k.data_ptr(),
+              _rows_ld(k)[1], dq.data_ptr(), _rows_ld(dq)[1], dk.data_ptr(), _rows_ld(dk)[1], ws.data_ptr(), B, heads, N, M, d,
+              G, float(d) ** -0.5, _stream())
 
 
 def attention_capture_bwd(d_score, d_qs, q, k, dq, dk, heads):

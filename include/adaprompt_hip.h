@@ -130,7 +130,17 @@ int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const v
 /* side outputs of the distillation layers, attention.py:245-255: attnscore / attn [B][H][N][M] f32,
  * q_scaled = q * scale^0.5 [B][H][N][d] f32 (any of them may be NULL).  M <= 192. */
 int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
-                           float* q_scaled, int B, int H, int N, int M, int d, float scale, void* stream);
+                           float* q_scaled, const float* tok_w, float* tokmap, int G, int B, int H, int N, int M, int d,
+                           float scale, void* stream);
+/* Token maps (optional outputs of the call above: tok_w f32 [B][M][G] -> tokmap f32 [B][H][N][G] =
+ * sum_m attnscore[b][h][n][m] * tok_w[b][m][g], G <= 4): all the cross-layer consistency loss reads of attnscore
+ * (ddpm.py:4323-4339: mean over heads, sum over the subject / background tokens).  Their gradient is applied to the
+ * layer's bf16 dq / dk without ever forming the dense [B][H][N][M] gradient.  workspace:
+ * adap_attention_tokmap_bwd_workspace_floats(...) floats. */
+long adap_attention_tokmap_bwd_workspace_floats(int B, int H, int N, int d, int G);
+int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k,
+                              long ldk, void* dq16, long lddq, void* dk16, long lddk, float* workspace, int B, int H,
+                              int N, int M, int d, int G, float scale, void* stream);
 /* Gradient of those side outputs (ddpm.py:3246-3270: the recon iteration's cross-layer consistency loss reads
  * `attnscore` with gradient; stage 2 also `q`): dq16 / dk16 are the bf16 gradients adap_attention_bwd has written for
  * the same layer, and receive  += scale * dS k  (+ dim_head^-1/4 * dQs)  and  += scale * dS^T q  (f32 sum, rounded

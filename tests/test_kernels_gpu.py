@@ -452,3 +452,36 @@ def test_attention_capture_bwd(B, N, M, d):
     ops.attention_capture_bwd(None, dqs.to(dev), q.to(dev), k.to(dev), dq2, None, H)
     ref2 = dq0.double() + (d ** -0.25 * dqs.double()).permute(0, 2, 1, 3).reshape(B, N, H * d)
     assert rel(dq2.float().cpu(), ref2.float()) < 3e-3
+
+
+@pytest.mark.parametrize("B,N,M,d,G", [(2, 256, 77, 160, 2), (1, 1024, 77, 80, 1), (2, 4096, 77, 40, 2), (1, 100, 154, 40, 3)])
+def test_attention_token_maps_fwd_bwd(B, N, M, d, G):
+    """token maps T = attnscore . w (per head) from the capture kernel, and their gradient applied to dq / dk without the
+    dense d attnscore: both against the dense formulation in fp64."""
+    H = 8
+    g = torch.Generator().manual_seed(33)
+    q = torch.randn(B, N, H * d, generator=g).bfloat16()
+    k = torch.randn(B, M, H * d, generator=g).bfloat16()
+    w = (torch.rand(B, M, G, generator=g) < 0.2).float() * torch.randint(1, 3, (B, M, G), generator=g).float()
+    dt = torch.randn(B, H, N, G, generator=g)
+    dq0 = torch.randn(B, N, H * d, generator=g).bfloat16()
+    dk0 = torch.randn(B, M, H * d, generator=g).bfloat16()
+    scale = d ** -0.5
+    qh = q.double().view(B, N, H, d).permute(0, 2, 1, 3)
+    kh = k.double().view(B, M, H, d).permute(0, 2, 1, 3)
+    score = scale * qh @ kh.transpose(2, 3)                                  # [B,H,N,M]
+    t_ref = score @ w.double()[:, None]                                      # [B,H,N,G]
+    ds = dt.double() @ w.double()[:, None].transpose(2, 3)                   # dense d attnscore [B,H,N,M]
+    dq_ref = dq0.double() + (scale * ds @ kh).permute(0, 2, 1, 3).reshape(B, N, H * d)
+    dk_ref = dk0.double() + (scale * ds.transpose(2, 3) @ qh).permute(0, 2, 1, 3).reshape(B, M, H * d)
+    dev = torch.device("cuda:0")
+    sc, pr, qs, tm = ops.attention_capture(q.to(dev), k.to(dev), H, tok_w=w.to(dev))
+    assert rel(tm.cpu(), t_ref.float()) < 1e-5
+    assert rel(sc.cpu(), score.float()) < 1e-5
+    dq, dk = dq0.to(dev).clone(), dk0.to(dev).clone()
+    ops.attention_tokmap_bwd(dt.to(dev), w.to(dev), q.to(dev), k.to(dev), dq, dk, H)
+    assert rel(dq.float().cpu(), dq_ref.float()) < 3e-3
+    assert rel(dk.float().cpu(), dk_ref.float()) < 3e-3
+    # keys that no group lists keep their gradient bit for bit
+    untouched = (w.sum(-1) == 0)
+    assert torch.equal(dk.cpu()[untouched], dk0[untouched])
