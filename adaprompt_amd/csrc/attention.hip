@@ -1098,36 +1098,50 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dk_finish_kernel(const f
 // gq is a reduction over the queries: 128-row chunks, two stages, fixed order.
 // =============================================================================================
 #define TOK_MAXG 4
-__global__ __launch_bounds__(256) void attn_tokmap_bwd_dq_kernel(const float* __restrict__ dt, const float* __restrict__ tok_w,
-                                                                 const uint16_t* __restrict__ k, long ldk,
-                                                                 uint16_t* __restrict__ dq, long lddq, int B, int H, int N,
-                                                                 int M, int d, int G, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* kw = (float*)smem;               // [G][d]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
-    for (int idx = tid; idx < G * d; idx += 256) {
+// kw[bh][g][c] = sum_m w[b][m][g] * k[b][m][head*d + c]  -- G*d numbers per (batch, head), one small workgroup each
+__global__ __launch_bounds__(256) void attn_tokmap_kw_kernel(const float* __restrict__ tok_w, const uint16_t* __restrict__ k,
+                                                             long ldk, float* __restrict__ kw, int H, int M, int d, int G) {
+    const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
+    for (int idx = threadIdx.x; idx < G * d; idx += 256) {
         const int g = idx / d, c = idx - g * d;
         float a = 0.f;
-        for (int m = 0; m < M; ++m)
-            a += tok_w[((size_t)b * M + m) * G + g] * bf16_to_f32(k[((size_t)b * M + m) * ldk + head * d + c]);
-        kw[idx] = a;
-    }
-    __syncthreads();
-    for (int rr = w; rr < CAP_ROWS; rr += 4) {
-        const int n = blockIdx.x * CAP_ROWS + rr;
-        if (n >= N) break;
-        const float* row = dt + (((size_t)b * H + head) * N + n) * G;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c = lane + 64 * j;
-            if (c < d) {
-                float v = 0.f;
-                for (int g = 0; g < G; ++g) v += row[g] * kw[g * d + c];
-                uint16_t* o = dq + ((size_t)b * N + n) * lddq + head * d + c;
-                *o = f32_to_bf16(bf16_to_f32(*o) + scale * v);
-            }
+        for (int m = 0; m < M; ++m) {
+            const float wv = tok_w[((size_t)b * M + m) * G + g];
+            if (wv != 0.f) a += wv * bf16_to_f32(k[((size_t)b * M + m) * ldk + head * d + c]);
         }
+        kw[(size_t)bh * G * d + idx] = a;
+    }
+}
+
+// dq[b][n][head*d + c] += scale * sum_g dT[b][head][n][g] * kw[bh][g][c]: element-wise, 8 channels per thread
+__global__ __launch_bounds__(256) void attn_tokmap_bwd_dq_kernel(const float* __restrict__ dt, const float* __restrict__ kw,
+                                                                 uint16_t* __restrict__ dq, long lddq, int B, int H, int N,
+                                                                 int d, int G, float scale) {
+    const int octs = d / 8;                                   // d % 8 == 0 (checked by the caller)
+    const long total = (long)B * N * H * octs;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int o = (int)(i % octs);
+        long r = i / octs;
+        const int head = (int)(r % H);
+        r /= H;
+        const int n = (int)(r % N);
+        const int b = (int)(r / N);
+        const float* row = dt + ((((size_t)b * H + head) * N + n) * G);
+        const float* kwp = kw + ((size_t)(b * H + head) * G) * d + 8 * o;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const float t = row[g];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t * kwp[g * d + e];
+        }
+        uint16_t* op = dq + ((size_t)b * N + n) * lddq + head * d + 8 * o;
+        float cur[8];
+        unpack_bf16x8(*(const uint4*)op, cur);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cur[e] += scale * v[e];
+        *(uint4*)op = pack_bf16x8(cur);
     }
 }
 
@@ -1201,7 +1215,7 @@ __global__ __launch_bounds__(256) void attn_tokmap_bwd_dk_kernel(const float* __
 }
 
 extern "C" long adap_attention_tokmap_bwd_workspace_floats(int B, int H, int N, int d, int G) {
-    return (long)B * H * ((N + CAPB_ROWS - 1) / CAPB_ROWS) * G * d;
+    return (long)B * H * (((N + CAPB_ROWS - 1) / CAPB_ROWS) + 1) * G * d;          // gq partials + kw
 }
 
 extern "C" int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k,
@@ -1213,8 +1227,16 @@ extern "C" int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok
     ADAP_REQUIRE((long)B * H <= 65535, ADAP_ERR_SHAPE, "attention_tokmap_bwd: B*H");
     hipStream_t s = (hipStream_t)stream;
     const int nchunks = (N + CAPB_ROWS - 1) / CAPB_ROWS;
-    hipLaunchKernelGGL(attn_tokmap_bwd_dq_kernel, dim3((N + CAP_ROWS - 1) / CAP_ROWS, B * H), dim3(256), (size_t)G * d * 4, s,
-                       d_tokmap, tok_w, (const uint16_t*)k, ldk, (uint16_t*)dq16, lddq, B, H, N, M, d, G, scale);
+    ADAP_REQUIRE(d % 8 == 0 && lddq % 8 == 0 && ((uintptr_t)dq16 % 16) == 0, ADAP_ERR_ALIGN, "attention_tokmap_bwd: dq alignment");
+    float* kw = workspace + (size_t)B * H * nchunks * G * d;
+    hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), 0, s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
+    {
+        const long tot = (long)B * N * H * (d / 8);
+        long g = (tot + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(attn_tokmap_bwd_dq_kernel, dim3((unsigned)g), dim3(256), 0, s, d_tokmap, kw, (uint16_t*)dq16, lddq, B,
+                           H, N, d, G, scale);
+    }
     hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), 0, s, d_tokmap, (const uint16_t*)q, ldq,
                        workspace, B, H, N, d, G);
     const long total = (long)B * H * d;

@@ -276,8 +276,9 @@ class LatentDiffusion(DDPM):
             G = len(groups)
             # both groups' maps of all instances as one batch of G*SSB rows: one resize and one cosine per layer pair
             m_fine, m_coarse = token_map(fine, None), token_map(coarse, None)                       # [G, SSB, N]
-            m_fine = F.interpolate(m_fine.reshape(G * SSB_SIZE, 1, hf, hf), size=(hc, hc), mode="bilinear",
-                                   align_corners=False).reshape(G, SSB_SIZE, hc * hc)
+            if hf != hc:            # (a same-size bilinear resize is the identity)
+                m_fine = F.interpolate(m_fine.reshape(G * SSB_SIZE, 1, hf, hf), size=(hc, hc), mode="bilinear",
+                                       align_corners=False).reshape(G, SSB_SIZE, hc * hc)
             per_instance = cosine_loss_rows(m_fine, m_coarse, exponent=2, do_demean_first=True, ref_grad_scale=1,
                                             aim_to_align=True)                                       # [G, SSB]
             per_group = per_instance.mean(dim=1) * layer_w[layer]          # = calc_ref_cosine_loss per group
