@@ -480,3 +480,78 @@ extern "C" int adap_add2(const float* a, long lda, const float* b, long ldb, flo
                        y32, (uint16_t*)y16, rows, C / 4);
     return adap_check_launch("add2");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise demeaned cosine loss with a sign-preserving squared reference, forward and analytic backward
+// (ldm/util.py:437-535 calc_ref_cosine_loss with exponent 2: the cross-layer attention consistency loss and the
+// prompt-delta loss of the recon iteration).  Per row of x, r [R][D]:
+//   xt = x - mean(x), rt = r - mean(r) (if demean);  t = rt * |rt|;  cos = <xt,t> / sqrt((|xt|^2 + 1e-12)(|t|^2 + 1e-12))
+//   loss = 1 - cos (align) or max(0, cos) (repel)      -- F.cosine_embedding_loss with margin 0
+// One workgroup per row; torch spends ~25 element-wise launches per call on this chain (and again in backward).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ r,
+                                                          long ldr, const float* __restrict__ gl, float* __restrict__ loss,
+                                                          float* __restrict__ dx, long lddx, float* __restrict__ dr, long lddr,
+                                                          int D, int demean, int align, float ref_grad_scale) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    const float* rr = r + row * ldr;
+    const int t = threadIdx.x;
+    float sx = 0.f, sr = 0.f;
+    if (demean) {
+        for (int i = t; i < D; i += 256) { sx += xr[i]; sr += rr[i]; }
+        sx = block_sum_256(sx, red) / D;
+        sr = block_sum_256(sr, red) / D;
+    }
+    float P = 0.f, A = 0.f, Bq = 0.f;
+    for (int i = t; i < D; i += 256) {
+        const float xt = xr[i] - sx, rt = rr[i] - sr, tt = rt * fabsf(rt);
+        P += xt * tt; A += xt * xt; Bq += tt * tt;
+    }
+    P = block_sum_256(P, red);
+    A = block_sum_256(A, red) + 1e-12f;
+    Bq = block_sum_256(Bq, red) + 1e-12f;
+    const float inv = 1.0f / sqrtf(A * Bq);
+    const float c = P * inv;
+    if (loss && t == 0) loss[row] = align ? 1.0f - c : fmaxf(c, 0.f);
+    if (!dx && !dr) return;
+    // d loss / d cos, times the incoming gradient of this row's loss
+    float gc = gl[row] * (align ? -1.0f : (c > 0.f ? 1.0f : 0.f));
+    // dcos/dxt = (t - (P/A) xt) * inv ;  dcos/dt = (xt - (P/B) t) * inv ;  dt/drt = 2 |rt|
+    float mx = 0.f, mr = 0.f;
+    if (demean) {
+        for (int i = t; i < D; i += 256) {
+            const float xt = xr[i] - sx, rt = rr[i] - sr, tt = rt * fabsf(rt);
+            mx += (tt - (P / A) * xt) * inv;
+            mr += (xt - (P / Bq) * tt) * inv * 2.0f * fabsf(rt);
+        }
+        mx = block_sum_256(mx, red) / D;
+        mr = block_sum_256(mr, red) / D;
+    }
+    for (int i = t; i < D; i += 256) {
+        const float xt = xr[i] - sx, rt = rr[i] - sr, tt = rt * fabsf(rt);
+        if (dx) dx[row * lddx + i] = gc * ((tt - (P / A) * xt) * inv - mx);
+        if (dr) dr[row * lddr + i] = gc * ref_grad_scale * ((xt - (P / Bq) * tt) * inv * 2.0f * fabsf(rt) - mr);
+    }
+}
+
+// loss != NULL: forward (gl, dx, dr NULL).  dx / dr != NULL: backward for the rows' loss gradients gl [R].
+extern "C" int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const float* gl, float* loss, float* dx,
+                                long lddx, float* dr, long lddr, long R, int D, int demean, int align, float ref_grad_scale,
+                                void* stream) {
+    ADAP_REQUIRE(x && r && (loss || ((dx || dr) && gl)), ADAP_ERR_SHAPE, "cosine_rows: null pointer");
+    ADAP_REQUIRE(R >= 0 && D >= 1 && ldx >= D && ldr >= D, ADAP_ERR_SHAPE, "cosine_rows: shape");
+    if (R == 0) return ADAP_OK;
+    hipLaunchKernelGGL(cosine_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ldx, r, ldr, gl, loss, dx,
+                       lddx, dr, lddr, D, demean, align, ref_grad_scale);
+    return adap_check_launch("cosine_rows");
+}
