@@ -1,10 +1,12 @@
 """Block-level autograd Functions of the UNet: each one sequences HIP kernels for the forward
-and, explicitly, for the data-gradient backward (the UNet is frozen in the shipped config,
-``unfreeze_model: False`` v1-finetune-ada.yaml:26 / ddpm.py:775-786, so gradients flow only to
-the inputs -- ultimately to the layerwise text context that the subject-basis generators
-produced).  torch.autograd is used as the tape between blocks; inside a block nothing is
-left to it: residual adds, time-embedding adds, bias adds and gradient accumulation are fused
-into kernel epilogues.
+and, explicitly, for the backward.  In the shipped config the UNet is frozen (``unfreeze_model:
+False`` v1-finetune-ada.yaml:26 / ddpm.py:775-786): gradients flow only to the inputs --
+ultimately to the layerwise text context that the subject-basis generators produced -- and, through
+the captured cross-attention scores, from the recon iteration's consistency loss (ddpm.py:3246-3270).
+With ``unfreeze_model: True`` the same backward functions also add the weight gradients into
+``param.grad`` (``train_of`` / ``_dw_*``).  torch.autograd is used as the tape between blocks;
+inside a block nothing is left to it: residual adds, time-embedding adds, bias adds and gradient
+accumulation are fused into kernel epilogues.
 
 All activations are pixel-major f32 (the residual stream) or bf16 (matrix-core operands)."""
 import torch
