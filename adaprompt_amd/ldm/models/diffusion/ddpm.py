@@ -2,14 +2,15 @@
 ldm/models/diffusion/ddpm.py): schedule buffers (``register_schedule`` :240-292), ``q_sample``
 (:416-419), ``predict_start_from_noise`` (:358-362), first-stage encode + posterior sample
 (:955-962, :1381-1419, :1178-1256), ``apply_model`` / ``DiffusionWrapper`` (:2192-2297,
-:5505-5544), ``guided_denoise`` (:2483-2532), ``calc_recon_loss`` (:3571-3595) and the
+:5505-5544), ``guided_denoise`` (:2483-2532), ``calc_recon_loss`` (:3571-3595), the recon
+iteration's regularisers (:3207-3270, ``calc_fg_bg_xlayer_consist_loss`` :4259-4387) and the
 manual-optimisation ``training_step`` (:515-638: backward every micro-batch, clip 0.5 + step +
 zero_grad every ``manual_accumulate_grad_batches``-th batch, loss not divided).
 
 What is deliberately NOT here (SURVEY.md section 2 "out of scope" / section 8f "next"): Lightning, the
 data pipeline, the CLIP text encoder + EmbeddingManager + SubjBasisGenerator internals (they stay
 the reference's own classes behind ``cond_fn``), the Arc2Face text encoder (the teacher's context is an input),
-compositional distillation and its auxiliary losses, DDIM sampling.  The Arc2Face teacher ROLLOUT and the
+compositional distillation and its auxiliary losses.  The Arc2Face teacher ROLLOUT and the
 multi-step distillation loss (ddpm.py:5432-5478, 2950-3039) are here: the teacher is an SD-1.5-topology UNet and
 runs on the same kernels (``Arc2FaceWrapper``).  ``cond_fn(batch) -> (c_static_emb
 [16*B, 77, 768], prompts, extra_info)`` is the embedding hook: whatever produced the context (the
