@@ -233,15 +233,17 @@ def token_weight_matrix(index_groups, batch, ntok):
     tokens): w[b, m, g] = how often (b, m) is listed in group g.  A sum over a group's tokens of a [.., ntok] tensor is
     then a contraction with column g.  Cached per index tensors -- the conditioning side reuses them every iteration,
     and building the matrix costs an index_put."""
-    key = tuple((bi.data_ptr(), ti.data_ptr(), bi.numel(), bi._version, ti._version) for bi, ti in index_groups) + \
-        (batch, ntok, str(index_groups[0][0].device))
-    w = _TOKEN_WEIGHTS.get(key)
-    if w is None:
-        if len(_TOKEN_WEIGHTS) > 64:
-            _TOKEN_WEIGHTS.clear()
-        dev = index_groups[0][0].device
-        w = torch.zeros(batch, ntok, len(index_groups), device=dev, dtype=torch.float32)
-        for g, (bi, ti) in enumerate(index_groups):
-            w[:, :, g].index_put_((bi, ti), torch.ones(bi.numel(), device=dev), accumulate=True)
-        _TOKEN_WEIGHTS[key] = w
+    # keyed by the tensor OBJECTS (and their versions); the entry keeps them alive, so neither an id nor a device
+    # address can come back with other contents while the entry exists
+    key = tuple((id(bi), id(ti), bi._version, ti._version) for bi, ti in index_groups) + (batch, ntok)
+    hit = _TOKEN_WEIGHTS.get(key)
+    if hit is not None:
+        return hit[0]
+    if len(_TOKEN_WEIGHTS) >= 16:
+        _TOKEN_WEIGHTS.clear()
+    dev = index_groups[0][0].device
+    w = torch.zeros(batch, ntok, len(index_groups), device=dev, dtype=torch.float32)
+    for g, (bi, ti) in enumerate(index_groups):
+        w[:, :, g].index_put_((bi, ti), torch.ones(bi.numel(), device=dev), accumulate=True)
+    _TOKEN_WEIGHTS[key] = (w, [t for pair in index_groups for t in pair])
     return w
