@@ -6,6 +6,10 @@ either through the top-level ``ldm`` alias package of this repo or by the rewrit
 import importlib
 from bisect import bisect_right
 
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
 from torch.optim.lr_scheduler import ConstantLR, PolynomialLR, SequentialLR
 
 _PREFIX = "adaprompt_amd."
@@ -79,10 +83,6 @@ def prodigy_linear_schedule(opt, max_steps, warm_up_steps, scheduler_cycles=1):
 # normalized_sum :2110, calc_prompt_emb_delta_loss :2037).  Host-side torch on small tensors (token embeddings,
 # [instances, pixels] score maps): same names, arguments and return values as the reference.
 # ----------------------------------------------------------------------------------------------------------------
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.nn as nn  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
 
 def ortho_subtract(a, b, on_last_n_dims=1, return_align_coeffs=False):
