@@ -57,6 +57,8 @@ struct ConvParams {
     long batch_stride_y16;
     int dbg;                // what-if switches for tuning (env ADAP_CONV_DEBUG; 0 in production): 1 no DMA in the loop,
                             // 2 no MFMA, 4 no epilogue stores -- results are garbage with any of them set
+    unsigned long long* clk;  // diagnostic (adap_conv2d_set_clock_probe; NULL in production): per workgroup of the
+                              // stencil-window kernel, shader-clock and 100 MHz real-time ticks spent in its K loop
 };
 
 #define BM 128
@@ -1005,6 +1007,11 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
     // each gets its own straight-line schedule and register allocation; all roles execute the same barriers
     Tile cur;
     decode(blockIdx.x, cur);
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (p.clk && tid == 0) {                // in-kernel clock probe (MI355X_MICROARCH.md "DVFS give-back", item 6)
+        clk0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     stage_a(cur, 0, ch_begin);
     stage_b(cur, 0, ch_begin, 0);
     stage_b(cur, 1, ch_begin, 1);
@@ -1064,6 +1071,10 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
         }
     }
     if (ROLE == 2) mfmas();             // the late half's last step: no barrier any more (the early half is done)
+    if (p.clk && tid == 0) {
+        p.clk[2 * (blockIdx.x + (size_t)gridDim.x * blockIdx.z)] = __builtin_amdgcn_s_memtime() - clk0;
+        p.clk[2 * (blockIdx.x + (size_t)gridDim.x * blockIdx.z) + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
     if (ROLE != 0 || !(p.dbg & 4)) epilogue(cur.bimg, cur.y0, cur.x0, cur.n0);
 }
 
@@ -1433,6 +1444,13 @@ static bool narrow_tiles_enabled() {
 // which kernel the last adap_conv2d_nhwc call of this thread dispatched to (bench.py's per-kernel roofline):
 // 1000*variant + BN, variant 0 = conv_gemm_kernel f32 activations, 1 = conv_gemm_kernel bf16, 2 = conv_gemm_ring_kernel<256,.,3>,
 // 3 = conv_gemm_ring_kernel<128,.,4>, 4 = conv3x3_halo_kernel, 5 = conv3x3_win32_kernel
+// diagnostic: a device buffer of 2 * (workgroups of the next stencil-window launches) uint64, or NULL (production)
+static unsigned long long* g_clock_probe = nullptr;
+extern "C" int adap_conv2d_set_clock_probe(void* buf) {
+    g_clock_probe = (unsigned long long*)buf;
+    return ADAP_OK;
+}
+
 static thread_local int g_last_variant = -1;
 extern "C" int adap_conv2d_last_variant(void) { return g_last_variant; }
 
@@ -1514,6 +1532,7 @@ extern "C" int adap_conv2d_nhwc(
             dbg = e ? atoi(e) : 0;
         }
         p.dbg = dbg;
+        p.clk = g_clock_probe;
     }
     hipStream_t s = (hipStream_t)stream;
 

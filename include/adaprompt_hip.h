@@ -74,6 +74,10 @@ int adap_conv2d_nhwc(const void* x, int x_dtype, long ldx, const void* w_packed,
 long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW);
 /* which kernel variant the calling thread's last adap_conv2d_nhwc dispatched to (1000*variant + channel tile; profiling aid) */
 int adap_conv2d_last_variant(void);
+/* Diagnostic (tools/clock_probe.py): with a non-NULL device buffer of 2 * workgroups uint64, every workgroup of the
+ * stencil-window kernel stores the shader-clock ticks (s_memtime) and the 100 MHz real-time ticks (s_memrealtime) its
+ * K loop took -- the in-kernel clock the chip holds under this kernel's load.  NULL (the default) switches it off. */
+int adap_conv2d_set_clock_probe(void* buf);
 
 /* OIHW f32 (checkpoint layout, ddpm.py:321-344) -> bf16 [KH*KW][rows][cols].
  * mode 0 (forward): rows >= O, cols >= I, out[t][o][i] = w[o][i][ky][kx] (zero padded).
