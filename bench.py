@@ -323,11 +323,12 @@ def main():
                     "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 1),
                     "achieved": round(v["work"] / (v["ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9), 1), "unit": unit}
         traffic, traffic_src = pmc_traffic(dom)
+        clock = in_kernel_clock(device) if rank == 0 else None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src,
                     "launches_per_step": c["launches"] // 2, "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 1),
-                    "ms_per_step_in_kernel": round(c["ms"] / 2, 3),
+                    "ms_per_step_in_kernel": round(c["ms"] / 2, 3), "in_kernel_clock": clock,
                     "note": "algorithmic 2*MAC FLOPs of the launches dispatched to this kernel / their HIP-event time on the "
                             "launch stream; per-launch events add ~10 us to short launches, rocprofv3 durations in profiles/",
                     "all_contraction_kernels": {"launches_per_step": call["launches_per_step"],
@@ -605,6 +606,38 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def in_kernel_clock(device):
+    """clock the chip holds under the dominant kernel's load (MI355X_MICROARCH.md 'DVFS give-back', item 6): ~2 s of
+    back-to-back launches of its best-fed shape (512 -> 512 @128^2, bs 4) on random data, then one launch stamped with
+    s_memtime / s_memrealtime around every workgroup's K loop (adap_conv2d_set_clock_probe)."""
+    from adaprompt_amd import _lib, ops
+    B, C, H = 4, 512, 128
+    x = torch.randn(B, H, H, C, device=device).to(torch.bfloat16)
+    pk = ops.PackedConv(torch.randn(C, C, 3, 3, device=device) * 0.02, torch.zeros(C, device=device))
+    flops = 2.0 * B * H * H * C * C * 9
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(8000):                               # ~2 s at ~0.25 ms per launch
+        ops.conv2d(x, pk.fwd, C, 3, 1, 1, bias=pk.bias)
+    nwg = B * (H * H // 256) * (C // 128)
+    buf = torch.zeros(2 * nwg, device=device, dtype=torch.int64)
+    _lib.call("adap_conv2d_set_clock_probe", buf.data_ptr())
+    e0.record()
+    ops.conv2d(x, pk.fwd, C, 3, 1, 1, bias=pk.bias)
+    e1.record()
+    _lib.call("adap_conv2d_set_clock_probe", 0)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    v = buf.view(-1, 2).cpu().double()
+    v = v[v[:, 1] > 0]
+    ghz = float((v[:, 0] / v[:, 1] * 0.1).median())
+    peak = BF16_MFMA_PEAK_TFLOPS * ghz / 2.4
+    tf = flops / us / 1e6
+    return {"shape": "conv3x3 512->512 @128x128 bs4, conv3x3_halo_kernel<128, true, true>", "ghz": round(ghz, 3),
+            "nominal_ghz": 2.4, "launch_us": round(us, 1), "achieved": round(tf, 1), "peak_at_clock": round(peak, 1),
+            "unit": "TFLOP/s", "frac_at_clock": round(tf / peak, 4),
+            "note": "d(s_memtime)/d(s_memrealtime) x 100 MHz, median over the launch's workgroups after ~2 s of sustained load"}
 
 
 def pmc_traffic(kernel):
