@@ -485,6 +485,10 @@ def test_attention_token_maps_fwd_bwd(B, N, M, d, G):
     # keys that no group lists keep their gradient bit for bit
     untouched = (w.sum(-1) == 0)
     assert torch.equal(dk.cpu()[untouched], dk0[untouched])
+    # fixed-order two-stage reduction over the queries: a repeat is bit-identical
+    dq_b, dk_b = dq0.to(dev).clone(), dk0.to(dev).clone()
+    ops.attention_tokmap_bwd(dt.to(dev), w.to(dev), q.to(dev), k.to(dev), dq_b, dk_b, H)
+    assert torch.equal(dq_b, dq) and torch.equal(dk_b, dk)
 
 
 @pytest.mark.parametrize("R,D,demean,align,rgs", [(8, 4096, True, True, 1.0), (5, 64, True, True, 0.05), (3, 1024, False, False, 1.0),
