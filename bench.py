@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-ddim", action="store_true",
                     help="skip the extra leg that times config 5 (50-step DDIM at bs=8 with guidance + VAE decode)")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the ~2 s in-kernel clock measurement of the roofline leg (its 8000 launches of one shape "
+                         "would dominate a rocprofv3 --stats average of the dominant kernel)")
     ap.add_argument("--no-unfrozen", action="store_true",
                     help="skip the `unfreeze_model: True` leg (weight gradients + 4.5 GB optimiser / all-reduce payload)")
     ap.add_argument("--no-distill-mix", action="store_true",
@@ -323,7 +326,7 @@ def main():
                     "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 1),
                     "achieved": round(v["work"] / (v["ms"] * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9), 1), "unit": unit}
         traffic, traffic_src = pmc_traffic(dom)
-        clock = in_kernel_clock(device) if rank == 0 else None
+        clock = in_kernel_clock(device) if (rank == 0 and not args.no_clock_probe) else None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src,
