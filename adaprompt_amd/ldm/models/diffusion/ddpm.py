@@ -55,8 +55,10 @@ class DDPM(nn.Module):
     def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
                  cosine_s=8e-3, given_betas=None, v_posterior=0.0, parameterization="eps", conditioning_key="crossattn",
                  manual_accumulate_grad_batches=2, grad_clip=0.5, optimizer_type="Prodigy", do_zero_shot=True,
-                 fg_bg_xlayer_consist_loss_weight=5e-5, prompt_emb_delta_reg_weight=2e-4, **unused):
-        """the last four: v1-finetune-ada.yaml:40,50 and ddpm.py:3207-3219, 3246-3270 (regulariser weights / scales)."""
+                 fg_bg_xlayer_consist_loss_weight=5e-5, prompt_emb_delta_reg_weight=2e-4,
+                 fg_bg_complementary_loss_weight=2e-4, **unused):
+        """the last five: v1-finetune-ada.yaml:40,48,50 and ddpm.py:3207-3219, 3246-3270, 3467-3500 (regulariser weights
+        / scales)."""
         super().__init__()
         assert parameterization == "eps"
         self.parameterization = parameterization
@@ -68,6 +70,7 @@ class DDPM(nn.Module):
         self.do_zero_shot = do_zero_shot
         self.fg_bg_xlayer_consist_loss_weight = fg_bg_xlayer_consist_loss_weight
         self.prompt_emb_delta_reg_weight = prompt_emb_delta_reg_weight
+        self.fg_bg_complementary_loss_weight = fg_bg_complementary_loss_weight
         self.register_schedule(given_betas, beta_schedule, timesteps, linear_start, linear_end, cosine_s)
 
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
@@ -96,6 +99,19 @@ class DDPM(nn.Module):
     def predict_start_from_noise(self, x_t, t, noise):
         return (extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
                 - extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+
+_CONSTS = {}
+
+
+def _const_tensor(values, device):
+    """a small constant f32 tensor on ``device``, created once (``torch.tensor(list, device=...)`` is a pageable
+    host -> device copy, i.e. a stream synchronisation, every time it is called)."""
+    key = (values, str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, device=device, dtype=torch.float32)
+    return t
 
 
 class LatentDiffusion(DDPM):
@@ -289,6 +305,104 @@ class LatentDiffusion(DDPM):
         loss_bg = normalized_sum(sums[1]) if len(groups) > 1 else normalized_sum([])
         return loss_fg, loss_bg
 
+    # ---- subject / background attention maps should be complementary and respect the fg mask (ddpm.py:3932-4258) --
+    COMPLEM_WEIGHTS = {7: 0.5, 8: 0.5, 12: 1., 16: 1., 17: 1., 18: 1., 19: 1., 20: 1., 21: 1., 22: 1., 23: 1., 24: 1.}
+
+    def calc_fg_mb_suppress_loss(self, ca_attnscores, subj_indices, BLOCK_SIZE, fg_mask, instance_mask=None,
+                                 token_maps=None):
+        """ddpm.py:3932-4040: the subject-only case of ``calc_fg_bg_complementary_loss`` (its second return value)."""
+        if subj_indices is None or len(subj_indices) == 0 or fg_mask is None:
+            return 0
+        return self.calc_fg_bg_complementary_loss(ca_attnscores, subj_indices, None, BLOCK_SIZE, fg_mask=fg_mask,
+                                                  instance_mask=instance_mask, token_maps=token_maps)[1]
+
+    def calc_fg_bg_complementary_loss(self, ca_attnscores, subj_indices, bg_indices, BLOCK_SIZE, fg_grad_scale=0.1,
+                                      fg_mask=None, instance_mask=None, do_sqrt_norm=False, token_maps=None):
+        """-> (fg_bg_complementary, subj_mb_suppress, bg_mf_suppress, fg_bg_mask_contrast), ddpm.py:4043-4258.
+        Everything is a function of the per-head score maps of the subject tokens (sum over K_fg) and of the
+        background tokens (sum over K_bg) -- the token maps the capture kernel emits (``token_maps``, see
+        ``calc_fg_bg_xlayer_consist_loss``); without them they are contracted from the dense attnscore.
+
+        The reference walks the 12 layers one by one, with two ``.any()`` host checks per layer (skip a layer whose
+        resized mask has no foreground or no background pixel).  Here the layers of one resolution form one batch
+        [layers, BLOCK, heads, N] and the skip is a 0/1 factor computed on the device: same sums, no sync, a third of
+        the launches."""
+        from ...util import (cosine_loss_rows, gen_gradient_scaler, normalize_dict_values, resize_mask_for_feat_or_attn,
+                             token_weight_matrix)
+        if subj_indices is None:
+            return 0, 0, 0, 0
+        have_bg = bg_indices is not None
+        use_mask = fg_mask is not None and (instance_mask is None or bool(instance_mask.sum() > 0))
+        if not have_bg and not use_mask:
+            return 0, 0, 0, 0
+        layer_w = normalize_dict_values(dict(LatentDiffusion.COMPLEM_WEIGHTS))
+        layers = [li for li in ca_attnscores if li in layer_w]
+        if not layers:
+            return 0, 0, 0, 0
+        first = ca_attnscores[layers[0]]
+        idx_groups = [subj_indices] + ([bg_indices] if have_bg else [])
+        w_full = token_weight_matrix(idx_groups, first.shape[0], first.shape[-1])           # [B, 77, groups]
+        tm = token_maps[0] if (token_maps is not None and token_maps[1] is w_full) else None
+        # tokens listed per instance (every instance lists the same number: ddpm.py:4081-4084)
+        k_fg = float(subj_indices[0].numel()) / first.shape[0]
+        k_bg = float(bg_indices[0].numel()) / first.shape[0] if have_bg else 1.0
+        by_res = {}
+        for li in layers:
+            by_res.setdefault(ca_attnscores[li].shape[2], []).append(li)
+        scaler = gen_gradient_scaler(0.5)           # protect the subject's activations on the foreground
+        margin, margin_bg_at_mf = 0.4, 0.4 * k_fg / k_bg
+        iw = None if instance_mask is None else instance_mask[:BLOCK_SIZE].view(1, BLOCK_SIZE, 1, 1).float()
+        tot = [0, 0, 0, 0]
+        for n_px, lis in by_res.items():
+            if tm is not None:
+                maps = torch.stack([tm[li][:BLOCK_SIZE] for li in lis])                     # [L, BLOCK, heads, N, groups]
+            else:
+                maps = torch.stack([torch.matmul(ca_attnscores[li][:BLOCK_SIZE], w_full[:BLOCK_SIZE, None]) for li in lis])
+            if do_sqrt_norm:
+                maps = maps / _const_tensor(tuple(float(np.sqrt(k)) for k in (k_fg, k_bg)[:maps.shape[-1]]), maps.device)
+            lw = _const_tensor(tuple(layer_w[li] for li in lis), maps.device)
+            subj = maps[..., 0]
+            bg = maps[..., 1] if have_bg else None
+            L, Bk, Hh, N = subj.shape
+            if have_bg:
+                # cosine_embedding(bg, subj*|subj|, -1): rows are (layer, instance, head); mean over instance and head
+                per_row = cosine_loss_rows(bg, subj, exponent=2, do_demean_first=False, ref_grad_scale=fg_grad_scale,
+                                           aim_to_align=False)                               # [L, BLOCK, heads]
+                tot[0] = tot[0] + (per_row.mean(dim=(1, 2)) * lw).sum()
+            if not use_mask:
+                continue
+            m = resize_mask_for_feat_or_attn(subj[0], fg_mask[:BLOCK_SIZE], "fg_mask", num_spatial_dims=1,
+                                             mode="nearest|bilinear")
+            fgm = (m.reshape(1, Bk, 1, N) > 1e-6).to(subj.dtype).expand(1, Bk, Hh, N)
+            bgm = 1 - fgm
+            # a layer whose mask has an empty foreground or background in ANY instance is skipped (ddpm.py:4150-4157)
+            valid = ((fgm.sum(dim=(2, 3)) > 0).all() & (bgm.sum(dim=(2, 3)) > 0).all()).to(subj.dtype)
+
+            def hinge(x):           # masked_mean(x, x > 0, instance_weights) per leading index: [..., BLOCK, heads, N]
+                pos = (x > 0).to(x.dtype)
+                xw = x if iw is None else x * iw
+                return (xw * pos).sum(dim=(-3, -2, -1)) / pos.sum(dim=(-3, -2, -1)).clamp(min=1e-6)
+
+            def mean_over(x, msk):  # masked_mean(x, msk, dim=(heads, N), keepdim) per (layer, instance)
+                return (x * msk).sum(dim=(2, 3), keepdim=True) / msk.sum(dim=(2, 3), keepdim=True).clamp(min=1e-6)
+
+            subj_at_mf = scaler(subj * fgm)
+            subj_at_mb = subj * bgm
+            avg_subj_mf = mean_over(subj_at_mf, fgm)
+            if not have_bg:
+                tot[1] = tot[1] + (hinge(subj_at_mb + margin - avg_subj_mf) * lw).sum() * valid * 0.05
+                continue
+            bg_at_mf, bg_at_mb = bg * fgm, bg * bgm
+            avg_bg_mb = mean_over(bg_at_mb, bgm)
+            # the four hinge terms as one [4, L, BLOCK, heads, N] batch
+            h4 = hinge(torch.stack([subj_at_mb + margin - avg_subj_mf, bg_at_mf + margin - avg_bg_mb,
+                                    bg_at_mf + margin_bg_at_mf - avg_subj_mf, subj_at_mb + margin - avg_bg_mb]))
+            h4 = (h4 * lw).sum(dim=1) * valid                                               # [4]
+            tot[1] = tot[1] + h4[0] * 0.05
+            tot[2] = tot[2] + h4[1] * 0.1
+            tot[3] = tot[3] + (h4[2] + h4[3]) * 0.05
+        return tuple(tot)
+
     # ---- Arc2Face distillation: teacher rollout + multi-step student loss (ddpm.py:2950-3039) ------------------
     MAX_ACCUMU_BATCH_SIZE = 7
 
@@ -424,15 +538,20 @@ class LatentDiffusion(DDPM):
         model_output, x_noisy = self.guided_denoise(x_start, noise, t, (c_emb, c_in, extra_info))
         loss, grad = self.calc_recon_loss(model_output, noise, img_mask, fg_mask, 1.0, self.bg_pixel_weight)
         aux = {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
-        reg, parts = self.recon_regularizers(extra_info, B, do_static_prompt_delta_reg=True)
+        reg, parts = self.recon_regularizers(extra_info, B, do_static_prompt_delta_reg=True, fg_mask=fg_mask,
+                                             instance_mask=batch.get("batch_have_fg_mask"), do_complementary=True)
         if reg is not None:
             aux["reg_loss"], aux["reg_parts"] = reg, parts
             loss = loss + reg.detach()
         return loss, grad, model_output, aux
 
-    def recon_regularizers(self, extra_info, block_size, do_static_prompt_delta_reg=True):
-        """The two terms a ``do_normal_recon`` iteration adds to the masked MSE (ddpm.py:3207-3270), when the
-        conditioning side supplies what they read:
+    def recon_regularizers(self, extra_info, block_size, do_static_prompt_delta_reg=True, fg_mask=None,
+                           instance_mask=None, do_complementary=False):
+        """The terms a ``do_normal_recon`` iteration adds to the masked MSE (ddpm.py:2921-2950 -> 3461-3500, and
+        3207-3270), when the conditioning side supplies what they read:
+          * (``do_complementary``: not in Arc2Face-distillation iterations, ddpm.py:2922) calc_fg_bg_complementary_loss
+            on the captured attnscore with the latent-resolution ``fg_mask``: (0.2 (zero-shot) x complementary +
+            subj_mb_suppress + bg_mf_suppress + fg_bg_mask_contrast) x fg_bg_complementary_loss_weight;
           * ``extra_info['c_static_emb_4b']`` (+ ``'prompt_emb_mask'``): calc_prompt_emb_delta_loss, weight
             prompt_emb_delta_reg_weight x 0.5 (Prodigy) / 5 (zero-shot); off in Arc2Face-distillation iterations (:572);
           * ``extra_info['subj_indices']`` (+ ``'bg_indices'``): the (instance, token) positions of the subject /
@@ -453,10 +572,21 @@ class LatentDiffusion(DDPM):
             total = l_delta * (self.prompt_emb_delta_reg_weight * scale)
         subj = extra_info.get("subj_indices")
         acts = extra_info.get("ca_layers_activations")
+        tm = None
+        if acts is not None and acts.get("attnscore_tokmap") and extra_info.get("ca_tokmap_weights") is not None:
+            tm = (acts["attnscore_tokmap"], extra_info["ca_tokmap_weights"])
+        if do_complementary and subj is not None and acts is not None and acts.get("attnscore") \
+                and self.fg_bg_complementary_loss_weight > 0:
+            l_c, l_smb, l_bmf, l_con = self.calc_fg_bg_complementary_loss(
+                acts["attnscore"], subj, extra_info.get("bg_indices"), block_size, fg_grad_scale=0.1, fg_mask=fg_mask,
+                instance_mask=instance_mask, do_sqrt_norm=False, token_maps=tm)
+            term = (l_c * (0.2 if self.do_zero_shot else 1.0) + l_smb + l_bmf + l_con) * self.fg_bg_complementary_loss_weight
+            for name, val in (("fg_bg_complem", l_c), ("subj_mb_suppress", l_smb), ("bg_mf_suppress", l_bmf),
+                              ("fg_bg_mask_contrast", l_con)):
+                parts[name] = val.detach() if torch.is_tensor(val) else val
+            if torch.is_tensor(term):
+                total = term if total is None else total + term
         if subj is not None and acts is not None and acts.get("attnscore") and self.fg_bg_xlayer_consist_loss_weight > 0:
-            tm = None
-            if acts.get("attnscore_tokmap") and extra_info.get("ca_tokmap_weights") is not None:
-                tm = (acts["attnscore_tokmap"], extra_info["ca_tokmap_weights"])
             l_fg, l_bg = self.calc_fg_bg_xlayer_consist_loss(acts["attnscore"], subj, extra_info.get("bg_indices"),
                                                               block_size, token_maps=tm)
             fg_scale, bg_scale = (0.2, 0.06) if self.do_zero_shot else (1.0, 0.3)

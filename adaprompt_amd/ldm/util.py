@@ -247,3 +247,55 @@ def token_weight_matrix(index_groups, batch, ntok):
         w[:, :, g].index_put_((bi, ti), torch.ones(bi.numel(), device=dev), accumulate=True)
     _TOKEN_WEIGHTS[key] = (w, [t for pair in index_groups for t in pair])
     return w
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# helpers of the fg / bg complementary loss (reference ldm/util.py: masked_mean :1450, resize_mask_for_feat_or_attn
+# :1570, sel_emb_attns_by_indices :1945)
+# ----------------------------------------------------------------------------------------------------------------
+def masked_mean(ts, mask, instance_weights=None, dim=None, keepdim=False):
+    """sum(ts * instance_weights * mask) / max(sum(mask), 1e-6) over ``dim`` (all dims when None); mask is broadcast to
+    ts first so that the count is right; mask None: plain mean of ts * instance_weights."""
+    if instance_weights is None:
+        instance_weights = 1
+    elif isinstance(instance_weights, torch.Tensor):
+        instance_weights = instance_weights.view(*instance_weights.shape, *([1] * (ts.ndim - instance_weights.ndim)))
+    if mask is None:
+        return (ts * instance_weights).mean()
+    mask = mask.expand(ts.shape)
+    count = mask.sum(dim=dim, keepdim=keepdim).clamp(min=1e-6)
+    return (ts * instance_weights * mask).sum(dim=dim, keepdim=keepdim) / count
+
+
+def resize_mask_for_feat_or_attn(feat_or_attn, mask, mask_name="mask", num_spatial_dims=1, mode="nearest|bilinear",
+                                 warn_on_all_zero=False):
+    """mask [B,1,H,W] at the (square) resolution of ``feat_or_attn``'s trailing spatial dims: the element-wise maximum of
+    the nearest and the bilinear resize.  (The reference's all-zero warning costs a device -> host sync per call; it is
+    off by default here.)"""
+    side = int(np.sqrt(feat_or_attn.shape[-num_spatial_dims:].numel()))
+    out = F.interpolate(mask.float(), size=(side, side), mode="nearest")
+    if mode == "nearest|bilinear":
+        out = torch.maximum(out, F.interpolate(mask.float(), size=(side, side), mode="bilinear", align_corners=False))
+    if warn_on_all_zero and (out.sum(dim=(1, 2, 3)) == 0).any():
+        print(f"WARNING: {mask_name} has all-zero masks.")
+    return out
+
+
+def sel_emb_attns_by_indices(attn_mat, indices, all_token_weights=None, do_sum=True, do_mean=False, do_sqrt_norm=False):
+    """attn_mat [B, tokens, heads, N]; indices (instance idx, token idx), the instances in ascending blocks -> for every
+    listed instance the (weighted) sum / mean over its listed tokens: [n_instances, heads, N].  One contraction with a
+    [n_instances, tokens] weight matrix instead of a Python loop over instances."""
+    inst, tok = indices
+    uniq, inverse, counts = torch.unique(inst, return_inverse=True, return_counts=True)
+    w = torch.zeros(len(uniq), attn_mat.shape[1], device=attn_mat.device, dtype=attn_mat.dtype)
+    vals = torch.ones(len(tok), device=attn_mat.device, dtype=attn_mat.dtype) if all_token_weights is None \
+        else all_token_weights[inst, tok].to(attn_mat.dtype)
+    w.index_put_((inverse, tok), vals, accumulate=True)
+    if not (do_sum or do_mean):
+        raise NotImplementedError("sel_emb_attns_by_indices without a reduction over the tokens is not on the path")
+    out = torch.einsum("bthn,bt->bhn", attn_mat[uniq], w)
+    if do_mean and not do_sum:
+        out = out / counts.view(-1, 1, 1).to(out.dtype)
+    if do_sqrt_norm:
+        out = out / counts.view(-1, 1, 1).to(out.dtype).sqrt()
+    return out

@@ -244,6 +244,33 @@ def _run_regs(calc_prompt_emb_delta_loss, calc_ref_cosine_loss, normalize_dict_v
     save("regs_util", **out)
 
 
+def run_regs_masks():
+    """ldm/util.py: masked_mean :1450, resize_mask_for_feat_or_attn :1570, sel_emb_attns_by_indices :1945 -- the helpers
+    of the fg/bg complementary loss (ddpm.py:3932-4258)."""
+    from ldm.util import masked_mean, resize_mask_for_feat_or_attn, sel_emb_attns_by_indices
+    out = {}
+    ts = synth.synthetic_input("regm.ts", (3, 8, 64))
+    mask = (synth.synthetic_input("regm.mask", (3, 1, 64)) > 0.2).float()
+    iw = torch.tensor([1.0, 0.0, 1.0])
+    out["mm_all"] = masked_mean(ts, mask)
+    out["mm_dim"] = masked_mean(ts, mask, dim=(1, 2), keepdim=True)
+    out["mm_iw"] = masked_mean(ts, ts > 0.1, instance_weights=iw)
+    out["mm_none"] = masked_mean(ts, None, instance_weights=iw)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 64), indexing="ij")
+    m64 = torch.stack([((xx / 0.5) ** 2 + (yy / 0.7) ** 2 <= 1).float(), ((xx - 0.3).abs() + (yy + 0.2).abs() <= 0.12).float()])[:, None]
+    for h in (8, 16, 32):
+        out[f"rm_{h}"] = resize_mask_for_feat_or_attn(torch.zeros(2, 8, h * h), m64, "fg_mask", num_spatial_dims=1,
+                                                       mode="nearest|bilinear")
+    out["rm_near_16"] = resize_mask_for_feat_or_attn(torch.zeros(2, 8, 256), m64, "fg_mask", num_spatial_dims=1, mode="nearest")
+    attn = synth.synthetic_input("regm.attn", (3, 77, 8, 64))
+    subj = (torch.arange(3).repeat_interleave(4), torch.tensor([5, 6, 7, 8, 6, 7, 8, 9, 5, 6, 7, 8]))
+    bg = (torch.arange(3), torch.tensor([11, 12, 34]))
+    out["sel_sum"] = sel_emb_attns_by_indices(attn, subj, do_sum=True, do_mean=False, do_sqrt_norm=False)
+    out["sel_sqrt"] = sel_emb_attns_by_indices(attn, subj, do_sum=True, do_mean=False, do_sqrt_norm=True)
+    out["sel_bg"] = sel_emb_attns_by_indices(attn, bg, do_sum=True, do_mean=False, do_sqrt_norm=False)
+    save("regs_masks", **out)
+
+
 def run_decoder_and_ddim(model, util, full):
     """VAE Decoder + post_quant_conv (model.py:502-608, autoencoder.py:330-333) and the DDIM schedule helpers
     (util.py:46-77)."""
@@ -451,6 +478,7 @@ def main():
     run_prodigy()
     run_anneal()
     run_regs()
+    run_regs_masks()
     run_decoder_and_ddim(model, util, args.full)
 
     if args.full:

@@ -284,9 +284,10 @@ def test_training_step_matches_oracle():
 
 
 def test_recon_step_with_regularizers_matches_oracle():
-    """a9: the do_normal_recon iteration = masked MSE + cross-layer consistency of the subject / background attention
-    maps (gradient THROUGH the captured attnscore, adap_attention_capture_bwd) + prompt-delta loss on the four-way static
-    embeddings (ddpm.py:3207-3270).  The regulariser weights are raised from 5e-5 / 2e-4 to O(1) so that their gradients
+    """a9: the do_normal_recon iteration = masked MSE + fg/bg complementary loss with its three mask hinges
+    (ddpm.py:3461-3500) + cross-layer consistency of the subject / background attention maps (both with the gradient
+    THROUGH the captured attnscore, via the token maps) + prompt-delta loss on the four-way static embeddings
+    (ddpm.py:3207-3270).  The regulariser weights are raised from 5e-5 / 2e-4 to O(1) so that their gradients
     are not lost beside the MSE gradient; loss parts and d loss / d context against the oracle."""
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from oracle import ldm_oracle as O
@@ -295,7 +296,8 @@ def test_recon_step_with_regularizers_matches_oracle():
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
     ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
-                         fg_bg_xlayer_consist_loss_weight=2.0, prompt_emb_delta_reg_weight=3.0)
+                         fg_bg_xlayer_consist_loss_weight=2.0, prompt_emb_delta_reg_weight=3.0,
+                         fg_bg_complementary_loss_weight=1.5)
     usd = synth.synthetic_unet_state_dict(ucfg)
     missing, unexpected = ld.load_state_dict({**usd, **synth.synthetic_vae_state_dict(vdd)}, strict=False)
     assert not unexpected
@@ -325,7 +327,10 @@ def test_recon_step_with_regularizers_matches_oracle():
     mse_ref, _ = O.calc_recon_loss(eps_ref, noise, im64, fg64, 1.0, 0.1)
     fg_ref, bg_ref = R.calc_fg_bg_xlayer_consist_loss(ex_ref["ca_layers_activations"]["attnscore"], subj, bgi, B)
     pd_ref = R.calc_prompt_emb_delta_loss(e_ref, pmask.clone())
-    total_ref = mse_ref + (fg_ref * 0.2 + bg_ref * 0.06) * 2.0 + pd_ref * 3.0 * 0.1
+    cm_ref = R.calc_fg_bg_complementary_loss(ex_ref["ca_layers_activations"]["attnscore"], subj, bgi, B, fg_grad_scale=0.1,
+                                             fg_mask=fg64)
+    total_ref = mse_ref + (fg_ref * 0.2 + bg_ref * 0.06) * 2.0 + pd_ref * 3.0 * 0.1 \
+        + (cm_ref[0] * 0.2 + cm_ref[1] + cm_ref[2] + cm_ref[3]) * 1.5
     total_ref.backward()
 
     # ---- HIP
@@ -344,6 +349,9 @@ def test_recon_step_with_regularizers_matches_oracle():
     assert abs(float(parts["fg_xlayer_consist"]) - float(fg_ref)) < 2e-2 * abs(float(fg_ref))
     assert abs(float(parts["bg_xlayer_consist"]) - float(bg_ref)) < 2e-2 * abs(float(bg_ref))
     assert abs(float(parts["static_prompt_delta"]) - float(pd_ref)) < 1e-4 * abs(float(pd_ref))
+    for name, ref in zip(("fg_bg_complem", "subj_mb_suppress", "bg_mf_suppress", "fg_bg_mask_contrast"), cm_ref):
+        print(f"[recon+regs] {name} {float(parts[name]):.6f} / {float(ref):.6f}")
+        assert abs(float(parts[name]) - float(ref)) < 3e-2 * abs(float(ref)) + 1e-5, name
     assert abs(float(loss) - float(total_ref.detach())) < 5e-3 * float(total_ref.detach())
     ge = rel_err(e_hip.grad.cpu(), e_ref.grad)
     # the regularisers' own share of the gradient: remove the MSE part (computed without them on both sides)
