@@ -555,3 +555,145 @@ extern "C" int adap_cosine_rows(const float* x, long ldx, const float* r, long l
                        lddx, dr, lddr, D, demean, align, ref_grad_scale);
     return adap_check_launch("cosine_rows");
 }
+
+// ---------------------------------------------------------------------------------------------
+// The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for a stack of same-resolution
+// layers, forward and analytic backward.  S = subject score map, G = background-token score map, [L][B][H][N]
+// (read with an element stride: the two are columns of the token-map tensor), f = foreground mask [B][N] in {0,1}.
+//   aS[l,b] = sum_{h,n} S f / max(H sum_n f, 1e-6)             (the forward value is unaffected by the 0.5 ScaleGrad)
+//   aG[l,b] = sum_{h,n} G (1-f) / max(H sum_n (1-f), 1e-6)
+//   x1 = S(1-f) + m - aS   x2 = G f + m - aG   x3 = G f + m3 - aS   x4 = S(1-f) + m - aG
+//   out[j][l] = sum_{b,h,n} x_j [x_j > 0] iw_b / max(#{x_j > 0}, 1e-6)
+// Kernel 1 (grid L*B): aS, aG.  Kernel 2 (grid L*B): per (l,b) the four weighted sums and positive counts.
+// Finish (tiny): out[j][l] and the total counts.  Backward (grid L*B): recomputes x_j and applies
+//   dS = (1-f) (c1 p1 + c4 p4) iw - 0.5 f / dS_den * iw (c1 P1 + c3 P3),   c_j = gout[j][l] / cnt_j[l],  P_j = #{x_j > 0} in (l,b)
+//   dG = f (c2 p2 + c3 p3) iw - (1-f) / dG_den * iw (c2 P2 + c4 P4)
+// ---------------------------------------------------------------------------------------------
+struct HingeParams {
+    const float* S; const float* G; long estride;      // element (l,b,h,n) at S[((l*B+b)*H+h)*N*estride + n*estride]
+    const float* f;                                     // [B][N]
+    const float* iw;                                    // [B] or NULL
+    int L, B, H, N;
+    float m, m3;
+    float* avg;                                         // [L*B][2]   aS, aG
+    float* part;                                        // [L*B][8]   sum_j (4), cnt_j (4)
+};
+
+__global__ __launch_bounds__(256) void hinge_avg_kernel(HingeParams p) {
+    __shared__ float red[4];
+    const int lb = blockIdx.x, b = lb % p.B, t = threadIdx.x;
+    const long base = (long)lb * p.H * p.N * p.estride;
+    float sS = 0.f, sG = 0.f, nf = 0.f;
+    for (int i = t; i < p.H * p.N; i += 256) {
+        const int n = i % p.N;
+        const float f = p.f[(long)b * p.N + n];
+        sS += p.S[base + (long)i * p.estride] * f;
+        if (p.G) sG += p.G[base + (long)i * p.estride] * (1.f - f);
+        nf += f;
+    }
+    sS = block_sum_256(sS, red);
+    sG = block_sum_256(sG, red);
+    nf = block_sum_256(nf, red);
+    if (t == 0) {
+        p.avg[2 * lb] = sS / fmaxf(nf, 1e-6f);
+        p.avg[2 * lb + 1] = sG / fmaxf((float)p.H * p.N - nf, 1e-6f);
+    }
+}
+
+__global__ __launch_bounds__(256) void hinge_sum_kernel(HingeParams p) {
+    __shared__ float red[4];
+    const int lb = blockIdx.x, b = lb % p.B, t = threadIdx.x;
+    const long base = (long)lb * p.H * p.N * p.estride;
+    const float aS = p.avg[2 * lb], aG = p.avg[2 * lb + 1];
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < p.H * p.N; i += 256) {
+        const int n = i % p.N;
+        const float f = p.f[(long)b * p.N + n];
+        const float S = p.S[base + (long)i * p.estride], G = p.G ? p.G[base + (long)i * p.estride] : 0.f;
+        float x[4] = {S * (1.f - f) + p.m - aS, G * f + p.m - aG, G * f + p.m3 - aS, S * (1.f - f) + p.m - aG};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x[j] > 0.f) { s[j] += x[j]; c[j] += 1.f; }
+    }
+    const float w = p.iw ? p.iw[b] : 1.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sj = block_sum_256(s[j], red), cj = block_sum_256(c[j], red);
+        if (t == 0) { p.part[8 * lb + j] = sj * w; p.part[8 * lb + 4 + j] = cj; }
+    }
+}
+
+// out[j][l] = sum_b part_sum / max(sum_b part_cnt, 1e-6); cnt[j][l] = that denominator
+__global__ void hinge_finish_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ cnt, int L, int B,
+                                    int has_bg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * L) return;
+    const int j = i / L, l = i - j * L;
+    float s = 0.f, c = 0.f;
+    for (int b = 0; b < B; ++b) { s += part[8 * (l * B + b) + j]; c += part[8 * (l * B + b) + 4 + j]; }
+    c = fmaxf(c, 1e-6f);
+    const bool live = has_bg || j == 0;
+    out[i] = live ? s / c : 0.f;
+    cnt[i] = c;
+}
+
+__global__ __launch_bounds__(256) void hinge_bwd_kernel(HingeParams p, const float* __restrict__ gout, const float* __restrict__ cnt,
+                                                        float* __restrict__ dS, float* __restrict__ dG, long dstride) {
+    const int lb = blockIdx.x, l = lb / p.B, b = lb % p.B, t = threadIdx.x;
+    const long base = (long)lb * p.H * p.N * p.estride, dbase = (long)lb * p.H * p.N * dstride;
+    const float aS = p.avg[2 * lb], aG = p.avg[2 * lb + 1];
+    const float w = p.iw ? p.iw[b] : 1.f;
+    float c[4], P[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = (p.G || j == 0) ? gout[j * p.L + l] / cnt[j * p.L + l] * w : 0.f;
+        P[j] = p.part[8 * lb + 4 + j];
+    }
+    // denominators of the two masked means of this instance
+    __shared__ float red[4];
+    float nf = 0.f;
+    for (int n = t; n < p.N; n += 256) nf += p.f[(long)b * p.N + n];
+    nf = block_sum_256(nf, red) * p.H;
+    const float denS = fmaxf(nf, 1e-6f), denG = fmaxf((float)p.H * p.N - nf, 1e-6f);
+    const float viaS = 0.5f * (c[0] * P[0] + c[2] * P[2]) / denS;       // ScaleGrad(0.5) on the foreground part of S
+    const float viaG = (c[1] * P[1] + c[3] * P[3]) / denG;
+    for (int i = t; i < p.H * p.N; i += 256) {
+        const int n = i % p.N;
+        const float f = p.f[(long)b * p.N + n];
+        const float S = p.S[base + (long)i * p.estride], G = p.G ? p.G[base + (long)i * p.estride] : 0.f;
+        const float x0 = S * (1.f - f) + p.m - aS, x1 = G * f + p.m - aG, x2 = G * f + p.m3 - aS, x3 = S * (1.f - f) + p.m - aG;
+        const float p0 = x0 > 0.f, p1 = x1 > 0.f, p2 = x2 > 0.f, p3 = x3 > 0.f;
+        dS[dbase + (long)i * dstride] = (1.f - f) * (c[0] * p0 + c[3] * p3) - f * viaS;
+        if (dG) dG[dbase + (long)i * dstride] = f * (c[1] * p1 + c[2] * p2) - (1.f - f) * viaG;
+    }
+}
+
+// workspace floats: 2*L*B (avg) + 8*L*B (partials) + 4*L (counts)
+extern "C" long adap_mask_hinges_workspace_floats(int L, int B) { return 10L * L * B + 4L * L; }
+
+// forward: out f32 [4][L].  S / G: element stride `estride` floats (G may be NULL: only term 0).  workspace is read again
+// by the backward (keep it): adap_mask_hinges_bwd(gout [4][L]) -> dS, dG with element stride `dstride`.
+extern "C" int adap_mask_hinges_fwd(const float* S, const float* G, long estride, const float* fmask, const float* iw, float* out,
+                                    float* workspace, int L, int B, int H, int N, float margin, float margin_bg_at_mf,
+                                    void* stream) {
+    ADAP_REQUIRE(S && fmask && out && workspace && L > 0 && B > 0 && H > 0 && N > 0 && estride >= 1, ADAP_ERR_SHAPE,
+                 "mask_hinges_fwd: arguments");
+    HingeParams p = {S, G, estride, fmask, iw, L, B, H, N, margin, margin_bg_at_mf, workspace, workspace + 2L * L * B};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(hinge_avg_kernel, dim3(L * B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(hinge_sum_kernel, dim3(L * B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(hinge_finish_kernel, dim3((4 * L + 63) / 64), dim3(64), 0, s, p.part, out, workspace + 10L * L * B, L, B,
+                       G != nullptr);
+    return adap_check_launch("mask_hinges_fwd");
+}
+
+extern "C" int adap_mask_hinges_bwd(const float* S, const float* G, long estride, const float* fmask, const float* iw,
+                                    const float* gout, const float* workspace, float* dS, float* dG, long dstride, int L, int B,
+                                    int H, int N, float margin, float margin_bg_at_mf, void* stream) {
+    ADAP_REQUIRE(S && fmask && gout && workspace && dS && (!G || dG) && dstride >= 1, ADAP_ERR_SHAPE, "mask_hinges_bwd: arguments");
+    HingeParams p = {S, G, estride, fmask, iw, L, B, H, N, margin, margin_bg_at_mf, (float*)workspace,
+                     (float*)workspace + 2L * L * B};
+    hipLaunchKernelGGL(hinge_bwd_kernel, dim3(L * B), dim3(256), 0, (hipStream_t)stream, p, gout, workspace + 10L * L * B, dS, dG,
+                       dstride);
+    return adap_check_launch("mask_hinges_bwd");
+}

@@ -493,3 +493,23 @@ class CosineRowsFn(torch.autograd.Function):
         dx, dr = ops.cosine_rows(x2, r2, demean, align, rgs, gl=g.reshape(-1).float().contiguous(),
                                  want_dx=ctx.needs_input_grad[0], want_dr=want_dr)
         return (None if dx is None else dx.reshape(xs)), (None if dr is None else dr.reshape(rs)), None, None, None
+
+
+class MaskHingesFn(torch.autograd.Function):
+    """the four mask hinge terms of the fg/bg complementary loss (ddpm.py:4143-4238) for a stack of same-resolution
+    token maps [L, B, heads, N, groups]: three launches forward, one backward (ops.mask_hinges)."""
+
+    @staticmethod
+    def forward(ctx, maps, fmask, iw, margin, margin_bg_at_mf, have_bg):
+        maps = maps.contiguous()
+        out, ws = ops.mask_hinges(maps, fmask, iw, margin, margin_bg_at_mf, have_bg)
+        ctx.save_for_backward(maps, fmask, ws)
+        ctx.cfg = (iw, float(margin), float(margin_bg_at_mf), bool(have_bg))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        maps, fmask, ws = ctx.saved_tensors
+        iw, margin, m3, have_bg = ctx.cfg
+        d = ops.mask_hinges(maps, fmask, iw, margin, m3, have_bg, gout=gout.contiguous().float(), ws=ws)
+        return d, None, None, None, None, None

@@ -386,6 +386,17 @@ class LatentDiffusion(DDPM):
             def mean_over(x, msk):  # masked_mean(x, msk, dim=(heads, N), keepdim) per (layer, instance)
                 return (x * msk).sum(dim=(2, 3), keepdim=True) / msk.sum(dim=(2, 3), keepdim=True).clamp(min=1e-6)
 
+            if maps.is_cuda and maps.dtype == torch.float32:
+                # one fused HIP pass per direction instead of ~60 element-wise launches (functional.MaskHingesFn)
+                from .... import functional as HF
+                iw_v = None if instance_mask is None else instance_mask[:BLOCK_SIZE].float().contiguous()
+                h4 = HF.MaskHingesFn.apply(maps, fgm[0, :, 0, :].contiguous(), iw_v, margin, margin_bg_at_mf, have_bg)
+                h4 = (h4 * lw).sum(dim=1) * valid                                            # [4]
+                tot[1] = tot[1] + h4[0] * 0.05
+                if have_bg:
+                    tot[2] = tot[2] + h4[1] * 0.1
+                    tot[3] = tot[3] + (h4[2] + h4[3]) * 0.05
+                continue
             subj_at_mf = scaler(subj * fgm)
             subj_at_mb = subj * bgm
             avg_subj_mf = mean_over(subj_at_mf, fgm)

@@ -629,3 +629,26 @@ def cosine_rows(x, r, demean, align, ref_grad_scale=1.0, gl=None, want_dx=True, 
     _lib.call("adap_cosine_rows", x.data_ptr(), x.stride(0), r.data_ptr(), r.stride(0), gl.data_ptr(), 0, _ptr(dx), D, _ptr(dr), D,
               R, D, int(bool(demean)), int(bool(align)), float(ref_grad_scale), _stream())
     return dx, dr
+
+
+def mask_hinges(maps, fmask, iw, margin, margin_bg_at_mf, have_bg, gout=None, ws=None):
+    """maps f32 [L, B, H, N, G] contiguous (column 0 subject, column 1 background); fmask f32 [B, N] in {0,1}.
+    gout None -> (out [4, L], workspace);  gout [4, L] + the forward's workspace -> d maps [L, B, H, N, G]."""
+    assert maps.dtype == F32 and maps.is_contiguous() and maps.dim() == 5
+    L, B, H, N, G = maps.shape
+    assert fmask.dtype == F32 and fmask.is_contiguous() and tuple(fmask.shape) == (B, N) and (not have_bg or G >= 2)
+    S = maps.data_ptr()
+    Gp = S + 4 if have_bg else 0
+    if gout is None:
+        out = torch.empty(4, L, device=maps.device, dtype=F32)
+        ws = torch.empty(_lib.size_query("adap_mask_hinges_workspace_floats", L, B), device=maps.device, dtype=F32)
+        _lib.call("adap_mask_hinges_fwd", S, Gp, G, fmask.data_ptr(), _ptr(iw), out.data_ptr(), ws.data_ptr(), L, B, H, N,
+                  float(margin), float(margin_bg_at_mf), _stream())
+        return out, ws
+    assert gout.dtype == F32 and gout.is_contiguous() and tuple(gout.shape) == (4, L)
+    d = torch.zeros_like(maps) if G > (2 if have_bg else 1) else torch.empty_like(maps)
+    _lib.call("adap_mask_hinges_bwd", S, Gp, G, fmask.data_ptr(), _ptr(iw), gout.data_ptr(), ws.data_ptr(), d.data_ptr(),
+              d.data_ptr() + 4 if have_bg else 0, G, L, B, H, N, float(margin), float(margin_bg_at_mf), _stream())
+    if not have_bg and G > 1:
+        d[..., 1:].zero_()
+    return d

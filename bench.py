@@ -91,6 +91,9 @@ def build_model(device, seed=0):
         hook = SyntheticSubjBasisGenerator()
     # regs=True: the conditioning side also hands over what the recon iteration's two regularisers read (ddpm.py:3207-3270)
     ld.cond_fn = make_cond_fn(hook, capture=True, regs=True)
+    for _k in ("fg_bg_complementary_loss_weight", "fg_bg_xlayer_consist_loss_weight", "prompt_emb_delta_reg_weight"):
+        if os.environ.get("ADAP_OFF_" + _k):
+            setattr(ld, _k, 0.0)
     return ld, hook
 
 

@@ -279,6 +279,20 @@ int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const f
                      long lddx, float* dr, long lddr, long R, int D, int demean, int align, float ref_grad_scale,
                      void* stream);
 
+/* The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for L same-resolution layers:
+ * S / G f32 [L][B][H][N] = per-head score maps of the subject / background tokens (element stride `estride`: they
+ * are columns of a token-map tensor; G NULL = subject-only, calc_fg_mb_suppress_loss), fmask f32 [B][N] in {0,1},
+ * iw f32 [B] instance weights or NULL.  out f32 [4][L] = (subj_mb_suppress, bg_mf_suppress, subj_bg_contrast_at_mf,
+ * bg_subj_contrast_at_mb) BEFORE the layer weights and the 0.05 / 0.1 scales.  The backward reads the forward's
+ * workspace (adap_mask_hinges_workspace_floats(L, B) floats) and gout f32 [4][L]; it includes the 0.5 ScaleGrad on the
+ * subject's foreground mean (ddpm.py:4093, 4163). */
+long adap_mask_hinges_workspace_floats(int L, int B);
+int adap_mask_hinges_fwd(const float* S, const float* G, long estride, const float* fmask, const float* iw, float* out,
+                         float* workspace, int L, int B, int H, int N, float margin, float margin_bg_at_mf, void* stream);
+int adap_mask_hinges_bwd(const float* S, const float* G, long estride, const float* fmask, const float* iw,
+                         const float* gout, const float* workspace, float* dS, float* dG, long dstride, int L, int B,
+                         int H, int N, float margin, float margin_bg_at_mf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -516,3 +516,53 @@ def test_cosine_rows_fwd_bwd(R, D, demean, align, rgs):
         assert rh.grad is None
     else:
         assert rel(rh.grad.cpu(), (rd.grad * rgs).float()) < 2e-5
+
+
+@pytest.mark.parametrize("L,B,H,N,G,have_bg,use_iw", [(3, 2, 8, 256, 2, True, False), (1, 4, 8, 64, 2, True, True),
+                                                       (2, 2, 8, 1024, 1, False, False), (3, 4, 8, 4096, 2, True, False)])
+def test_mask_hinges_fwd_bwd(L, B, H, N, G, have_bg, use_iw):
+    """adap_mask_hinges_* against the torch chain of ddpm.py:4143-4238 (masked means with the 0.5 ScaleGrad, four hinge
+    terms, masked_mean over the positives) and its autograd, in fp64."""
+    from adaprompt_amd import functional as HF
+    g = torch.Generator().manual_seed(23)
+    maps = torch.randn(L, B, H, N, G, generator=g)
+    f = (torch.rand(B, N, generator=g) < 0.35).float()
+    iw = torch.tensor([1.0, 0.5, 0.0, 2.0][:B]) if use_iw else None
+    gout = torch.randn(4, L, generator=g)
+    m, m3 = 0.4, 0.4 * 16 / 4
+    md = maps.double().requires_grad_(True)
+    S = md[..., 0]
+    Gm = md[..., 1] if have_bg else None
+    fm = f.double().view(1, B, 1, N).expand(L, B, H, N)
+    bm = 1 - fm
+
+    class Half(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, gg):
+            return gg * 0.5
+
+    def mean_over(x, msk):
+        return (x * msk).sum(dim=(2, 3), keepdim=True) / msk.sum(dim=(2, 3), keepdim=True).clamp(min=1e-6)
+
+    def hinge(x):
+        pos = (x > 0).double()
+        xw = x if iw is None else x * iw.double().view(1, B, 1, 1)
+        return (xw * pos).sum(dim=(1, 2, 3)) / pos.sum(dim=(1, 2, 3)).clamp(min=1e-6)
+
+    aS = mean_over(Half.apply(S * fm), fm)
+    terms = [hinge(S * bm + m - aS)]
+    if have_bg:
+        aG = mean_over(Gm * bm, bm)
+        terms += [hinge(Gm * fm + m - aG), hinge(Gm * fm + m3 - aS), hinge(S * bm + m - aG)]
+    ref = torch.stack(terms + [torch.zeros(L, dtype=torch.float64)] * (4 - len(terms)))
+    (ref * gout.double()).sum().backward()
+    dev = torch.device("cuda:0")
+    mh = maps.to(dev).requires_grad_(True)
+    out = HF.MaskHingesFn.apply(mh, f.to(dev), None if iw is None else iw.to(dev), m, m3, have_bg)
+    (out * gout.to(dev)).sum().backward()
+    assert rel(out.cpu(), ref.detach().float()) < 2e-5
+    assert rel(mh.grad.cpu(), md.grad.float()) < 2e-5
