@@ -91,6 +91,7 @@ def build_model(device, seed=0):
         hook = SyntheticSubjBasisGenerator()
     # regs=True: the conditioning side also hands over what the recon iteration's two regularisers read (ddpm.py:3207-3270)
     ld.cond_fn = make_cond_fn(hook, capture=True, regs=True)
+    # attribution aid: ADAP_OFF_<weight name>=1 switches one auxiliary loss off
     for _k in ("fg_bg_complementary_loss_weight", "fg_bg_xlayer_consist_loss_weight", "prompt_emb_delta_reg_weight"):
         if os.environ.get("ADAP_OFF_" + _k):
             setattr(ld, _k, 0.0)
@@ -591,7 +592,8 @@ def main():
             "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None, "vae_prefetch_stream": prefetch is not None,
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
                                    "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, masked MSE + "
-                                   "cross-layer attention consistency (gradient through the captured attnscore) + prompt-delta loss, "
+                                   "fg/bg complementary loss with its mask hinges + cross-layer attention consistency (both with the "
+                                   "gradient through the captured attnscore) + prompt-delta loss, "
                                    "hook stand-in with 149M trainable fp32 params, clip 0.5 + Prodigy step + LR schedule every 2nd micro-batch",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": reducer_bytes(world)},
