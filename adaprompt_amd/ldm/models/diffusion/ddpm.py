@@ -505,9 +505,12 @@ class LatentDiffusion(DDPM):
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
     def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
                     num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
-                    trim_to_half_batch=True, batched_student=True, teacher_out=None):
+                    trim_to_half_batch=True, batched_student=True, teacher_out=None, anneal_t=False):
         """``x_start``: a latent already encoded for this batch (e.g. by ``LatentPrefetcher`` on a side stream while
         the previous micro-batch's UNet pass was running); otherwise the batch is encoded here.
+
+        ``anneal_t``: apply the recon iteration's timestep annealing to ``t`` (off by default so that callers who pass
+        an explicit ``t`` -- the parity tests -- get exactly that ``t``).
 
         ``use_arc2face_as_target``: the distillation iteration (ddpm.py:1837-1876, 2950-3039): only the first
         HALF_BS instances are kept when ``num_denoising_steps`` > 1, ``batch["arc2face_prompt_emb"]`` [B,21,768] is
@@ -543,6 +546,12 @@ class LatentDiffusion(DDPM):
                 batched_student=batched_student, teacher_out=teacher_out)
             aux.update(x_start=x_start, t=t)
             return loss, grads, outs, aux
+        if anneal_t:
+            # recon iterations shift t up by a random factor in [1, 1.3] with an annealed probability
+            # (ddpm.py:2851-2866: the zero-shot and the default branch use the same ranges)
+            from ...util import probably_anneal_t
+            t = probably_anneal_t(t, getattr(self, "training_percent", 0.0), self.num_timesteps, ratio_range=(1, 1.3),
+                                  keep_prob_range=(0.4, 0.2))
         c_emb, c_in, extra_info = cond
         extra_info = dict(extra_info)
         extra_info["img_mask"] = img_mask                                  # ddpm.py:2876

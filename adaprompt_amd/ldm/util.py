@@ -299,3 +299,46 @@ def sel_emb_attns_by_indices(attn_mat, indices, all_token_weights=None, do_sum=T
     if do_sqrt_norm:
         out = out / counts.view(-1, 1, 1).to(out.dtype).sqrt()
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# timestep annealing of the recon iteration (reference ldm/util.py:1468-1530, applied at ddpm.py:2851-2866)
+# ----------------------------------------------------------------------------------------------------------------
+def anneal_value(training_percent, final_percent, value_range):
+    assert 0 - 1e-6 <= training_percent <= 1 + 1e-6
+    v_init, v_final = value_range
+    return v_init + (v_final - v_init) * training_percent if training_percent < final_percent else v_final
+
+
+def anneal_array(training_percent, final_percent, begin_array, end_array):
+    assert len(begin_array) == len(end_array)
+    return anneal_value(training_percent, final_percent, (np.array(begin_array), np.array(end_array)))
+
+
+def draw_annealed_bool(training_percent, final_percent, true_prob_range):
+    import random
+    return random.random() < anneal_value(training_percent, final_percent, true_prob_range)
+
+
+def probably_anneal_t(t, training_percent, num_timesteps, ratio_range, keep_prob_range=(0, 0.5)):
+    """with an annealed probability keep ``t``; otherwise redraw every t_i uniformly from
+    [clip(int(t_i * lb), 0, T-1), min(int(t_i * ub) + 1, T)).  The keep decision consumes one ``random.random()``.
+    Host tensors: the redraw consumes one ``np.random.randint`` per element, exactly like the reference.  Device
+    tensors: the same distribution from torch's device generator in three element-wise ops -- the reference's
+    ``int(t_i * lb)`` on a device tensor is a device -> host sync per element."""
+    if draw_annealed_bool(training_percent, 1.0, keep_prob_range):
+        return t.clone()
+    lb, ub = ratio_range
+    assert lb < ub
+    if t.is_cuda:
+        lo = (t.double() * lb).floor().clamp(0, num_timesteps - 1)
+        hi = ((t.double() * ub).floor() + 1).clamp(max=num_timesteps)
+        u = torch.rand(t.shape, device=t.device, dtype=torch.float64)
+        return (lo + (u * (hi - lo)).floor()).clamp(max=num_timesteps - 1).to(t.dtype)
+    out = t.clone()
+    flat, src = out.view(-1), t.reshape(-1).tolist()
+    for i, ti in enumerate(src):
+        lo = min(max(int(ti * lb), 0), num_timesteps - 1)
+        hi = min(int(ti * ub) + 1, num_timesteps)
+        flat[i] = int(np.random.randint(lo, hi))
+    return out

@@ -249,7 +249,7 @@ def main():
         t = torch.randint(0, 1000, (B,), device=device, generator=gen)
         noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
         x_start = prefetch.get()                       # encoded while the previous step's UNet pass ran
-        loss, grad, out, aux = ld.shared_step(batch, t=t, noise=noise, x_start=x_start)
+        loss, grad, out, aux = ld.shared_step(batch, t=t, noise=noise, x_start=x_start, anneal_t=True)
         # the next micro-batch's encode goes to the side stream once forward + losses are queued: it then fills the
         # CUs during the regularisers' many small kernels and the backward (measured +1 % over submitting it first)
         pf_submit()

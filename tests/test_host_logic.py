@@ -219,3 +219,27 @@ def test_multistep_host_helpers_match_oracle():
     lw = Arc2FaceWrapper.layerwise(ctx)
     assert lw.shape == (32, 3, 4) and torch.equal(lw[0], ctx[0]) and torch.equal(lw[15], ctx[0]) \
         and torch.equal(lw[16], ctx[1])
+
+
+def test_mirror_probably_anneal_t_matches_reference_draws():
+    """adaprompt_amd.ldm.util.probably_anneal_t on host tensors consumes ``random`` / ``np.random`` exactly as the
+    reference (golden: tests/golden/anneal_t.npz, ldm/util.py:1468-1530); on the device it is the same distribution."""
+    import random
+
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from adaprompt_amd.ldm import util as U
+    g = load_golden("anneal_t")
+    for row, want in zip(g["cases"].tolist(), g["outs"].tolist()):
+        seed, tp, lb, ub, k0, k1 = row[:6]
+        t = torch.tensor([int(v) for v in row[6:]])
+        random.seed(100 + int(seed))
+        np.random.seed(200 + int(seed))
+        lb = int(lb) if lb == int(lb) else lb
+        got = U.probably_anneal_t(t, tp, 1000, ratio_range=(lb, ub), keep_prob_range=(k0, k1))
+        assert got.tolist() == want, (row, got.tolist(), want)
+    av = [U.anneal_value(tp, fp, (0.2, 0.9)) for tp in (0.0, 0.3, 0.5, 1.0) for fp in (0.5, 1.0)]
+    np.testing.assert_allclose(av, g["anneal_values"].numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(U.anneal_array(0.25, 0.5, [0.4, 0.3, 0.2, 0.1], [0.1, 0.2, 0.3, 0.4]),
+                               g["anneal_array"].numpy(), rtol=0, atol=0)

@@ -365,6 +365,32 @@ def test_recon_step_with_regularizers_matches_oracle():
     assert ge < 5e-2
 
 
+def test_probably_anneal_t_device_path_has_the_reference_distribution():
+    """the sync-free device formulation of probably_anneal_t (util.py:1508-1530): every redraw lies in
+    [int(t*lb), int(t*ub)] clipped to the schedule, the redraw is uniform over that range, and t is kept with the
+    annealed probability."""
+    import random
+    from adaprompt_amd.ldm.util import probably_anneal_t
+    random.seed(0)
+    torch.manual_seed(0)
+    t = torch.tensor([0, 3, 250, 640, 769, 999], device=dev())
+    draws, kept = [], 0
+    for _ in range(400):
+        out = probably_anneal_t(t, 0.5, 1000, ratio_range=(1, 1.3), keep_prob_range=(0.4, 0.2))
+        if torch.equal(out, t):
+            kept += 1
+        else:
+            draws.append(out.cpu())
+    assert 0.18 < kept / 400 < 0.42                         # keep probability 0.3 at training_percent 0.5 (+ chance ties)
+    d = torch.stack(draws).double()
+    lo = torch.tensor([0, 3, 250, 640, 769, 999.0])
+    hi = torch.tensor([0, 3, 325, 832, 999, 999.0])         # min(int(t*1.3) + 1, 1000) - 1
+    assert bool((d >= lo).all()) and bool((d <= hi).all())
+    assert bool((d.max(0).values >= hi - 2).all()) and bool((d.min(0).values <= lo + 2).all())
+    mid = (lo + hi) / 2
+    assert bool(((d.mean(0) - mid).abs() <= 0.12 * (hi - lo) + 1e-9).all())
+
+
 def test_training_loop_prodigy_two_optimizer_steps_vs_oracle():
     """a1 end to end: four micro-batches through LatentDiffusion.training_step with the flat-buffer Prodigy, the
     fused 0.5 clip, the GradReducer on the optimiser's buffer and the LR schedule -- gradients accumulate over two
