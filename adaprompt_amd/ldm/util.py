@@ -342,3 +342,65 @@ def probably_anneal_t(t, training_percent, num_timesteps, ratio_range, keep_prob
         hi = min(int(ti * ub) + 1, num_timesteps)
         flat[i] = int(np.random.randint(lo, hi))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# host-side helpers of the conditioning assembly (reference ldm/util.py: repeat_selected_instances :1410,
+# add_noise_to_tensor :2123, anneal_add_noise_to_embedding :2144, distribute_embedding_to_M_tokens(_by_dict) :882-932;
+# used by LatentDiffusion.forward, ddpm.py:1710-2042)
+# ----------------------------------------------------------------------------------------------------------------
+def repeat_selected_instances(sel_indices, REPEAT, *args):
+    """every non-None tensor: pick ``sel_indices`` along dim 0 and tile that REPEAT times along dim 0."""
+    return [None if a is None else a[sel_indices].repeat([REPEAT] + [1] * (a.ndim - 1)) for a in args]
+
+
+def add_noise_to_tensor(ts, noise_std, noise_std_is_relative=True, keep_norm=False, std_dim=-1, norm_dim=-1):
+    """ts + N(0, noise_std) -- relative: noise_std times the mean std of ts over ``std_dim``; keep_norm: rescale to
+    the original norms over ``norm_dim``."""
+    if noise_std_is_relative:
+        noise_std = noise_std * ts.std(dim=std_dim).mean().detach()
+    noisy = ts + torch.randn_like(ts) * noise_std
+    if keep_norm:
+        noisy = noisy * ts.norm(dim=norm_dim, keepdim=True) / (noisy.norm(dim=norm_dim, keepdim=True).detach() + 1e-8)
+    return noisy
+
+
+def anneal_add_noise_to_embedding(embeddings, training_percent, begin_noise_std_range, end_noise_std_range, add_noise_prob,
+                                  noise_std_is_relative=True, keep_norm=False, std_dim=-1, norm_dim=-1):
+    """with probability ``add_noise_prob`` (one ``random.random()``) add noise whose std is drawn (one
+    ``np.random.uniform``) from a range annealed from ``begin_`` to ``end_noise_std_range`` over training."""
+    import random
+    if random.random() > add_noise_prob:
+        return embeddings
+    if end_noise_std_range is not None:
+        lo = anneal_value(training_percent, 1, (begin_noise_std_range[0], end_noise_std_range[0]))
+        hi = anneal_value(training_percent, 1, (begin_noise_std_range[1], end_noise_std_range[1]))
+    else:
+        lo, hi = begin_noise_std_range
+    return add_noise_to_tensor(embeddings, np.random.uniform(lo, hi), noise_std_is_relative, keep_norm, std_dim, norm_dim)
+
+
+def distribute_embedding_to_M_tokens(text_embedding, placeholder_indices_N, divide_scheme="sqrt_M"):
+    """text_embedding [B, N, D]: copy the embedding at the FIRST of the M listed token positions to all M of them,
+    divided by sqrt(M) ('sqrt_M'), M ('M') or 1 ('none')."""
+    if placeholder_indices_N is None:
+        return text_embedding
+    pos = torch.unique(placeholder_indices_N)
+    M = len(pos)
+    if M == 1:
+        return text_embedding
+    div = {"sqrt_M": np.sqrt(M), "M": M, "none": 1, None: 1}[divide_scheme]
+    mask = torch.zeros_like(text_embedding)
+    mask[:, pos] = 1
+    repl = torch.zeros_like(text_embedding)
+    repl[:, pos] = text_embedding[:, pos[:1]].repeat(1, M, 1) / div
+    return text_embedding * (1 - mask) + repl * mask
+
+
+def distribute_embedding_to_M_tokens_by_dict(text_embedding, placeholder_indices_dict, divide_scheme="sqrt_M"):
+    if placeholder_indices_dict is None:
+        return text_embedding
+    for indices in placeholder_indices_dict.values():
+        if indices is not None and len(indices[1]) > 1:
+            text_embedding = distribute_embedding_to_M_tokens(text_embedding, indices[1])
+    return text_embedding

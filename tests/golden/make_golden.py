@@ -271,6 +271,45 @@ def run_regs_masks():
     save("regs_masks", **out)
 
 
+def run_cond_helpers():
+    """the host-side helpers of the conditioning assembly (LatentDiffusion.forward, ddpm.py:1710-2042): ldm/util.py
+    repeat_selected_instances :1410, add_noise_to_tensor :2123, anneal_add_noise_to_embedding :2144,
+    distribute_embedding_to_M_tokens(_by_dict) :882-932 -- with seeded ``random`` / ``np.random`` / torch RNG."""
+    import random
+    from ldm.util import (add_noise_to_tensor, anneal_add_noise_to_embedding, distribute_embedding_to_M_tokens,
+                          distribute_embedding_to_M_tokens_by_dict, repeat_selected_instances)
+    out = {}
+    a = synth.synthetic_input("ch.a", (4, 3, 5))
+    b = synth.synthetic_input("ch.b", (4, 7))
+    r = repeat_selected_instances(slice(0, 2), 3, a, None, b)
+    out["rep_a"], out["rep_b"] = r[0], r[2]
+    emb = synth.synthetic_input("ch.emb", (6, 32))
+    torch.manual_seed(11)
+    out["noise_rel"] = add_noise_to_tensor(emb, 0.1, noise_std_is_relative=True, keep_norm=False)
+    torch.manual_seed(12)
+    out["noise_keepnorm"] = add_noise_to_tensor(emb, 0.05, noise_std_is_relative=False, keep_norm=True)
+    for i, (tp, prob) in enumerate(((0.0, 1.0), (0.6, 0.5), (0.3, 0.0))):
+        random.seed(30 + i)
+        np.random.seed(40 + i)
+        torch.manual_seed(50 + i)
+        out[f"anneal_noise_{i}"] = anneal_add_noise_to_embedding(emb, tp, begin_noise_std_range=[0.02, 0.06],
+                                                                 end_noise_std_range=[0.01, 0.03], add_noise_prob=prob)
+    random.seed(33)
+    np.random.seed(43)
+    torch.manual_seed(53)
+    out["anneal_noise_noend"] = anneal_add_noise_to_embedding(emb, 0.5, begin_noise_std_range=[0.02, 0.06],
+                                                              end_noise_std_range=None, add_noise_prob=1.0)
+    te = synth.synthetic_input("ch.te", (16, 77, 24))
+    idx = torch.tensor([5, 6, 7, 8, 5, 6, 7, 8])
+    out["dist_sqrt"] = distribute_embedding_to_M_tokens(te, idx)
+    out["dist_M"] = distribute_embedding_to_M_tokens(te, idx, divide_scheme="M")
+    out["dist_single"] = distribute_embedding_to_M_tokens(te, torch.tensor([9]))
+    d = {"z": (torch.zeros(4, dtype=torch.long), torch.tensor([5, 6, 7, 8])), "y": None,
+         "w": (torch.zeros(1, dtype=torch.long), torch.tensor([20]))}
+    out["dist_dict"] = distribute_embedding_to_M_tokens_by_dict(te, d)
+    save("cond_helpers", **out)
+
+
 def run_decoder_and_ddim(model, util, full):
     """VAE Decoder + post_quant_conv (model.py:502-608, autoencoder.py:330-333) and the DDIM schedule helpers
     (util.py:46-77)."""
@@ -479,6 +518,7 @@ def main():
     run_anneal()
     run_regs()
     run_regs_masks()
+    run_cond_helpers()
     run_decoder_and_ddim(model, util, args.full)
 
     if args.full:

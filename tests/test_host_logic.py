@@ -243,3 +243,48 @@ def test_mirror_probably_anneal_t_matches_reference_draws():
     np.testing.assert_allclose(av, g["anneal_values"].numpy(), rtol=0, atol=0)
     np.testing.assert_allclose(U.anneal_array(0.25, 0.5, [0.4, 0.3, 0.2, 0.1], [0.1, 0.2, 0.3, 0.4]),
                                g["anneal_array"].numpy(), rtol=0, atol=0)
+
+
+def test_conditioning_helpers_match_reference_golden():
+    """the host-side helpers of LatentDiffusion.forward's conditioning assembly (ddpm.py:1710-2042) against fixtures
+    captured from the reference's own ldm/util.py with the same seeds."""
+    import random
+
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from adaprompt_amd import synth
+    from adaprompt_amd.ldm import util as U
+    g = load_golden("cond_helpers")
+
+    def close(x, y):
+        return float((x.double() - y.double()).abs().max()) <= 1e-6 * float(y.double().abs().max()) + 1e-9
+
+    a, b = synth.synthetic_input("ch.a", (4, 3, 5)), synth.synthetic_input("ch.b", (4, 7))
+    r = U.repeat_selected_instances(slice(0, 2), 3, a, None, b)
+    assert r[1] is None and torch.equal(r[0], g["rep_a"]) and torch.equal(r[2], g["rep_b"])
+    emb = synth.synthetic_input("ch.emb", (6, 32))
+    torch.manual_seed(11)
+    assert close(U.add_noise_to_tensor(emb, 0.1, noise_std_is_relative=True, keep_norm=False), g["noise_rel"])
+    torch.manual_seed(12)
+    assert close(U.add_noise_to_tensor(emb, 0.05, noise_std_is_relative=False, keep_norm=True), g["noise_keepnorm"])
+    for i, (tp, prob) in enumerate(((0.0, 1.0), (0.6, 0.5), (0.3, 0.0))):
+        random.seed(30 + i)
+        np.random.seed(40 + i)
+        torch.manual_seed(50 + i)
+        got = U.anneal_add_noise_to_embedding(emb, tp, begin_noise_std_range=[0.02, 0.06], end_noise_std_range=[0.01, 0.03],
+                                              add_noise_prob=prob)
+        assert close(got, g[f"anneal_noise_{i}"]), i
+    random.seed(33)
+    np.random.seed(43)
+    torch.manual_seed(53)
+    assert close(U.anneal_add_noise_to_embedding(emb, 0.5, begin_noise_std_range=[0.02, 0.06], end_noise_std_range=None,
+                                                 add_noise_prob=1.0), g["anneal_noise_noend"])
+    te = synth.synthetic_input("ch.te", (16, 77, 24))
+    idx = torch.tensor([5, 6, 7, 8, 5, 6, 7, 8])
+    assert close(U.distribute_embedding_to_M_tokens(te, idx), g["dist_sqrt"])
+    assert close(U.distribute_embedding_to_M_tokens(te, idx, divide_scheme="M"), g["dist_M"])
+    assert torch.equal(U.distribute_embedding_to_M_tokens(te, torch.tensor([9])), g["dist_single"])
+    d = {"z": (torch.zeros(4, dtype=torch.long), torch.tensor([5, 6, 7, 8])), "y": None,
+         "w": (torch.zeros(1, dtype=torch.long), torch.tensor([20]))}
+    assert close(U.distribute_embedding_to_M_tokens_by_dict(te, d), g["dist_dict"])
