@@ -645,6 +645,29 @@ class LatentDiffusion(DDPM):
     def make_distill_prefetcher(self):
         return DistillPrefetcher(self)
 
+    def draw_iteration_flags(self, global_step, composition_regs_iter_gap=0, arc2face_distill_iter_prob=0.0,
+                             mix_prompt_distill_weight=0.0, np_random=np.random):
+        """The iteration-type draw at the top of the reference's ``training_step`` (ddpm.py:516-572), consuming
+        ``np.random`` in the same order: every ``composition_regs_iter_gap``-th global step is a compositional
+        regularisation iteration (one ``np.random.choice`` over the candidate types); otherwise, with probability
+        ``arc2face_distill_iter_prob`` (one ``np.random.rand``), a normal-recon iteration distils from the Arc2Face
+        teacher, which also switches the static prompt-delta loss off.  -> the reference's ``iter_flags`` subset."""
+        flags = {"do_normal_recon": True, "do_arc2face_distill": False, "is_compos_iter": False,
+                 "do_mix_prompt_distillation": False, "do_ada_prompt_delta_reg": False, "calc_clip_loss": False,
+                 "do_static_prompt_delta_reg": self.prompt_emb_delta_reg_weight > 0}
+        cand = []
+        if mix_prompt_distill_weight > 0:
+            cand.append("do_mix_prompt_distillation")
+        elif self.prompt_emb_delta_reg_weight > 0:
+            cand.append("do_ada_prompt_delta_reg")
+        if cand and composition_regs_iter_gap > 0 and global_step % composition_regs_iter_gap == 0:
+            kind = cand[np_random.choice(len(cand), p=np.ones(len(cand)) / len(cand))]
+            flags["do_mix_prompt_distillation"] = kind == "do_mix_prompt_distillation"
+            flags.update(do_ada_prompt_delta_reg=True, is_compos_iter=True, calc_clip_loss=True, do_normal_recon=False)
+        if flags["do_normal_recon"] and arc2face_distill_iter_prob > 0 and np_random.rand() < arc2face_distill_iter_prob:
+            flags.update(do_arc2face_distill=True, do_static_prompt_delta_reg=False)
+        return flags
+
     def training_step(self, batch, optimizer=None, reducer=None, scheduler=None, **step_kwargs):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
         the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync)."""

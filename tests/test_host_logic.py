@@ -288,3 +288,47 @@ def test_conditioning_helpers_match_reference_golden():
     d = {"z": (torch.zeros(4, dtype=torch.long), torch.tensor([5, 6, 7, 8])), "y": None,
          "w": (torch.zeros(1, dtype=torch.long), torch.tensor([20]))}
     assert close(U.distribute_embedding_to_M_tokens_by_dict(te, d), g["dist_dict"])
+
+
+def test_iteration_flag_draw_follows_the_reference_order():
+    """ddpm.py:516-572: compositional iterations on every gap-th global step (they consume np.random.choice and skip the
+    arc2face draw), otherwise one np.random.rand against arc2face_distill_iter_prob, which also disables the static
+    prompt-delta loss."""
+    import numpy as np
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+
+    class Stub:
+        prompt_emb_delta_reg_weight = 2e-4
+
+    class Rec:
+        def __init__(self, vals):
+            self.vals, self.calls = list(vals), []
+
+        def rand(self):
+            self.calls.append("rand")
+            return self.vals.pop(0)
+
+        def choice(self, n, p=None):
+            self.calls.append(("choice", n))
+            return 0
+
+    draw = LatentDiffusion.draw_iteration_flags
+    r = Rec([0.05])
+    f = draw(Stub(), 7, composition_regs_iter_gap=3, arc2face_distill_iter_prob=0.1, np_random=r)
+    assert r.calls == ["rand"] and f["do_arc2face_distill"] and not f["do_static_prompt_delta_reg"] and f["do_normal_recon"]
+    r = Rec([0.5])
+    f = draw(Stub(), 7, composition_regs_iter_gap=3, arc2face_distill_iter_prob=0.1, np_random=r)
+    assert r.calls == ["rand"] and not f["do_arc2face_distill"] and f["do_static_prompt_delta_reg"]
+    r = Rec([0.0])
+    f = draw(Stub(), 6, composition_regs_iter_gap=3, arc2face_distill_iter_prob=0.1, np_random=r)
+    assert r.calls == [("choice", 1)] and f["is_compos_iter"] and not f["do_normal_recon"] and f["do_ada_prompt_delta_reg"] \
+        and not f["do_mix_prompt_distillation"] and not f["do_arc2face_distill"]
+    f = draw(Stub(), 6, composition_regs_iter_gap=3, mix_prompt_distill_weight=1e-4, np_random=Rec([]))
+    assert f["do_mix_prompt_distillation"] and f["calc_clip_loss"]
+    r = Rec([])
+    f = draw(Stub(), 6, composition_regs_iter_gap=0, arc2face_distill_iter_prob=0.0, np_random=r)
+    assert r.calls == [] and f["do_normal_recon"] and not f["is_compos_iter"]
+    # with the real generator: the share of distillation iterations is the configured probability
+    np.random.seed(0)
+    n = sum(draw(Stub(), 1, arc2face_distill_iter_prob=0.3)["do_arc2face_distill"] for _ in range(2000))
+    assert 520 < n < 680
