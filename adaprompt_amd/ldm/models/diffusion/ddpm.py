@@ -645,6 +645,38 @@ class LatentDiffusion(DDPM):
     def make_distill_prefetcher(self):
         return DistillPrefetcher(self)
 
+    def configure_optimizers(self, optimized_parameters, max_steps, prodigy_config=None, weight_decay=0.0,
+                             unfreeze_model=False, extra_model_parameters=()):
+        """The Prodigy branch of the reference's ``configure_optimizers`` (ddpm.py:5134-5345) with the 'Linear' schedule
+        (v1-finetune-ada.yaml:59,74-84).  ``optimized_parameters``: what ``EmbeddingManager.optimized_parameters()``
+        returns -- a list of {'params', 'lr_ratio', 'excluded_from_prodigy'} (embedding_manager.py:2078-2095).  As in the
+        reference, Prodigy gets ONE flat list (lr = 1) of the requires-grad parameters of every group that is not
+        ``excluded_from_prodigy`` -- the groups' learning-rate ratios (and ``model_lr``) only matter to the Adam variants,
+        which are not built here; ``unfreeze_model`` appends the UNet's (and ``extra_model_parameters``', e.g. the text
+        encoder's) parameters (ddpm.py:5176-5181).  -> Lightning's [{'optimizer', 'frequency', 'lr_scheduler': {...}}]."""
+        from ...prodigy import Prodigy
+        from ...util import prodigy_linear_schedule
+        if getattr(self, "optimizer_type", "Prodigy") != "Prodigy":
+            raise NotImplementedError("only optimizer_type 'Prodigy' (the shipped config) is built; AdamW / NAdam / "
+                                      "ProdigyAdamW are out of scope (DESIGN.md 7)")
+        cfg = {"zs_betas": (0.9, 0.999), "betas": (0.985, 0.993), "d_coef": 2.0, "warm_up_steps": 500, "scheduler_cycles": 1,
+               "scheduler_type": "Linear"}
+        cfg.update(prodigy_config or {})
+        if cfg["scheduler_type"] != "Linear":
+            raise NotImplementedError(f"Prodigy scheduler_type {cfg['scheduler_type']!r}: only 'Linear' is built")
+        groups = [{"params": [q for q in g["params"] if q.requires_grad],
+                   "excluded_from_prodigy": g.get("excluded_from_prodigy", False)} for g in optimized_parameters]
+        if unfreeze_model:
+            groups.append({"params": [q for q in list(extra_model_parameters) + list(self.model.parameters())],
+                           "excluded_from_prodigy": False})
+        params = [q for g in groups if not g["excluded_from_prodigy"] for q in g["params"]]
+        opt = Prodigy(params, lr=1.0, weight_decay=weight_decay,
+                      betas=tuple(cfg["zs_betas"] if self.do_zero_shot else cfg["betas"]), d_coef=cfg["d_coef"],
+                      safeguard_warmup=cfg["scheduler_cycles"] > 1, use_bias_correction=True)
+        sched = prodigy_linear_schedule(opt, max_steps=max_steps, warm_up_steps=cfg["warm_up_steps"],
+                                        scheduler_cycles=cfg["scheduler_cycles"])
+        return [{"optimizer": opt, "frequency": 1, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}]
+
     def draw_iteration_flags(self, global_step, composition_regs_iter_gap=0, arc2face_distill_iter_prob=0.0,
                              mix_prompt_distill_weight=0.0, np_random=np.random):
         """The iteration-type draw at the top of the reference's ``training_step`` (ddpm.py:516-572), consuming

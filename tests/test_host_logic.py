@@ -332,3 +332,44 @@ def test_iteration_flag_draw_follows_the_reference_order():
     np.random.seed(0)
     n = sum(draw(Stub(), 1, arc2face_distill_iter_prob=0.3)["do_arc2face_distill"] for _ in range(2000))
     assert 520 < n < 680
+
+
+def test_configure_optimizers_prodigy_branch():
+    """ddpm.py:5134-5345, Prodigy branch: one flat lr-1 parameter list of the not-excluded, requires-grad parameters,
+    zero-shot betas, d_coef, bias correction, ConstantLR warm-up + linear cycle(s) under SequentialLR2."""
+    import torch
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    from adaprompt_amd.ldm.util import SequentialLR2
+
+    class Stub:
+        optimizer_type, do_zero_shot = "Prodigy", True
+        model = torch.nn.Linear(3, 2)
+
+    a, b, c, d = (torch.nn.Parameter(torch.zeros(n)) for n in (4, 5, 6, 7))
+    b.requires_grad_(False)
+    groups = [{"params": [a, b], "lr_ratio": 1.0, "excluded_from_prodigy": False},
+              {"params": [c], "lr_ratio": 0.1, "excluded_from_prodigy": True},
+              {"params": [d], "lr_ratio": 2.0, "excluded_from_prodigy": False}]
+    out = LatentDiffusion.configure_optimizers(Stub(), groups, max_steps=2000,
+                                               prodigy_config={"warm_up_steps": 500, "scheduler_cycles": 2, "d_coef": 5})
+    assert len(out) == 1 and out[0]["frequency"] == 1 and out[0]["lr_scheduler"]["interval"] == "step"
+    opt, sched = out[0]["optimizer"], out[0]["lr_scheduler"]["scheduler"]
+    assert isinstance(opt, Prodigy) and isinstance(sched, SequentialLR2)
+    got = [q for g in opt.param_groups for q in g["params"]]
+    assert len(got) == 2 and got[0] is a and got[1] is d
+    g0 = opt.param_groups[0]
+    assert g0["lr"] == 1.0 and tuple(g0["betas"]) == (0.9, 0.999) and g0["d_coef"] == 5 and g0["use_bias_correction"] \
+        and g0["safeguard_warmup"]
+    assert list(sched._milestones) == [500, 1250]            # 2 cycles of 750 steps after the warm-up
+    Stub.do_zero_shot = False
+    out = LatentDiffusion.configure_optimizers(Stub(), groups, max_steps=2000, unfreeze_model=True)
+    opt = out[0]["optimizer"]
+    got = [q for g in opt.param_groups for q in g["params"]]
+    assert len(got) == 4 and got[2] is Stub.model.weight and tuple(opt.param_groups[0]["betas"]) == (0.985, 0.993)
+    Stub.optimizer_type = "AdamW"
+    try:
+        LatentDiffusion.configure_optimizers(Stub(), groups, max_steps=10)
+        raise AssertionError("AdamW must be refused")
+    except NotImplementedError:
+        pass
