@@ -158,6 +158,18 @@ class LatentDiffusion(DDPM):
         """``unfreeze_model: False`` (yaml:26, ddpm.py:775-786)."""
         for p in self.model.parameters():
             p.requires_grad = False
+        self.unfreeze_model = False
+
+    def on_save_checkpoint(self, checkpoint, embedding_manager=None, ckpt_dir=None, global_step=None):
+        """ddpm.py:5393-5400: with a frozen UNet the Lightning checkpoint is emptied (nothing in it changed) and only the
+        embedding manager's state is written -- by the embedding manager itself (``save(path)``, the reference's own class
+        behind the boundary), as ``embeddings.pt`` and ``embeddings_gs-<step>.pt``."""
+        import os
+        if not getattr(self, "unfreeze_model", any(p.requires_grad for p in self.model.parameters())):
+            checkpoint.clear()
+        if embedding_manager is not None and ckpt_dir is not None and os.path.isdir(ckpt_dir):
+            embedding_manager.save(os.path.join(ckpt_dir, "embeddings.pt"))
+            embedding_manager.save(os.path.join(ckpt_dir, f"embeddings_gs-{global_step}.pt"))
 
     # ---- first stage ----------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -373,3 +373,29 @@ def test_configure_optimizers_prodigy_branch():
         raise AssertionError("AdamW must be refused")
     except NotImplementedError:
         pass
+
+
+def test_on_save_checkpoint_contract(tmp_path):
+    """ddpm.py:5393-5400: frozen UNet -> the checkpoint dict is emptied; the embedding manager writes its two files."""
+    import torch
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+
+    class Stub:
+        model = torch.nn.Linear(2, 2)
+
+    class Mgr:
+        def __init__(self):
+            self.saved = []
+
+        def save(self, path):
+            self.saved.append(path)
+
+    st, mgr = Stub(), Mgr()
+    LatentDiffusion.freeze_unet(st)
+    ck = {"state_dict": {"a": 1}, "epoch": 3}
+    LatentDiffusion.on_save_checkpoint(st, ck, mgr, str(tmp_path), 1200)
+    assert ck == {} and [p.split("/")[-1] for p in mgr.saved] == ["embeddings.pt", "embeddings_gs-1200.pt"]
+    st.unfreeze_model = True
+    ck = {"state_dict": {"a": 1}}
+    LatentDiffusion.on_save_checkpoint(st, ck)
+    assert ck == {"state_dict": {"a": 1}}
