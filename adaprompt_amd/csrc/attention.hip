@@ -1188,29 +1188,32 @@ __global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __
     }
 }
 
-// stage 2: one thread per (bh, c): gq[g] = sum_chunk part (fixed order), then dk[m][c] += scale * sum_g w[m][g] gq[g]
-__global__ __launch_bounds__(256) void attn_tokmap_bwd_dk_kernel(const float* __restrict__ part, const float* __restrict__ tok_w,
-                                                                 uint16_t* __restrict__ dk, long lddk, int B, int H, int M,
-                                                                 int d, int G, int nchunks, float scale) {
-    const long total = (long)B * H * d;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % d);
-        const long bh = i / d;
-        const int b = (int)(bh / H), head = (int)(bh - (long)b * H);
-        float gq[TOK_MAXG];
-        for (int g = 0; g < TOK_MAXG; ++g) {
-            gq[g] = 0.f;
-            if (g < G)
-                for (int k = 0; k < nchunks; ++k) gq[g] += part[((bh * nchunks + k) * G + g) * d + c];
+// stage 2: a workgroup per (batch*head, key): keys no group lists exit at once; the others sum the chunk partials of
+// their channels in fixed order (every listed key repeats that small sum -- cheaper than a serial walk over the keys)
+// and add scale * sum_g w[m][g] gq[g] into dk
+__global__ __launch_bounds__(64) void attn_tokmap_bwd_dk_kernel(const float* __restrict__ part, const float* __restrict__ tok_w,
+                                                                uint16_t* __restrict__ dk, long lddk, int B, int H, int M,
+                                                                int d, int G, int nchunks, float scale) {
+    const int m = blockIdx.x;
+    const long bh = blockIdx.y;
+    const int b = (int)(bh / H), head = (int)(bh - (long)b * H);
+    float w[TOK_MAXG];
+    bool any = false;
+    for (int g = 0; g < TOK_MAXG; ++g) {
+        w[g] = g < G ? tok_w[((size_t)b * M + m) * G + g] : 0.f;
+        any = any || w[g] != 0.f;
+    }
+    if (!any) return;
+    for (int c = threadIdx.x; c < d; c += 64) {
+        float v = 0.f;
+        for (int g = 0; g < G; ++g) {
+            if (w[g] == 0.f) continue;
+            float gq = 0.f;
+            for (int k = 0; k < nchunks; ++k) gq += part[((bh * nchunks + k) * G + g) * d + c];
+            v += w[g] * gq;
         }
-        for (int m = 0; m < M; ++m) {
-            float v = 0.f;
-            for (int g = 0; g < G; ++g) v += tok_w[((size_t)b * M + m) * G + g] * gq[g];
-            if (v != 0.f) {
-                uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
-                *o = f32_to_bf16(bf16_to_f32(*o) + scale * v);
-            }
-        }
+        uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
+        *o = f32_to_bf16(bf16_to_f32(*o) + scale * v);
     }
 }
 
@@ -1239,9 +1242,8 @@ extern "C" int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok
     }
     hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), 0, s, d_tokmap, (const uint16_t*)q, ldq,
                        workspace, B, H, N, d, G);
-    const long total = (long)B * H * d;
-    hipLaunchKernelGGL(attn_tokmap_bwd_dk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, tok_w,
-                       (uint16_t*)dk16, lddk, B, H, M, d, G, nchunks, scale);
+    hipLaunchKernelGGL(attn_tokmap_bwd_dk_kernel, dim3(M, B * H), dim3(64), 0, s, workspace, tok_w, (uint16_t*)dk16, lddk, B, H, M,
+                       d, G, nchunks, scale);
     return adap_check_launch("attention_tokmap_bwd");
 }
 
