@@ -538,8 +538,8 @@ def main():
             t = torch.randint(0, 1000, (B,), device=device, generator=gen)
             noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
             x_start = pf_u.get()
+            loss, grad, out, aux = ld.shared_step(batches[i % 2], t=t, noise=noise, x_start=x_start, anneal_t=True)
             usubmit(i + 1)
-            loss, grad, out, aux = ld.shared_step(batches[i % 2], t=t, noise=noise, x_start=x_start)
             red_u.wait()
             ld.manual_backward(out, grad, aux)
             red_u.reduce()
