@@ -386,6 +386,13 @@ def main():
         t_rfb = timed(rb_fb)
         rb_bytes = 4.0 * (2 * B * 64 * 64 * C + 2 * 9 * C * C + B * 4 * C)
         rb_flops = 2.0 * 2 * B * 64 * 64 * C * C * 9
+        # the HBM-bound part of that block, where the north star's HBM target applies: GroupNorm32 + SiLU (f32 in -> bf16 out)
+        gw, gb_ = torch.ones(C, device=device), torch.zeros(C, device=device)
+        t_gn = timed(lambda: ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1))
+        dy16 = go.to(torch.bfloat16)
+        _, _, gm_, gr_ = ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1)
+        t_gnb = timed(lambda: ops.groupnorm_bwd(dy16, xr, gw, gb_, gm_, gr_, 1, out_f32=False, out_bf16=True))
+        gn_bytes_f, gn_bytes_b = xr.numel() * (4 + 2), xr.numel() * (4 + 2 + 2)       # algorithmic: x once + y / x, dy once + dx
         aggregates = {
             "attention_self_64x64": {"shape": f"B{B} h8 N{N} d40", "fwd_us": round(t_f * 1e6, 1), "bwd_us": round(t_b * 1e6, 1),
                                      "fwd_tflops": round(fl / t_f / 1e12, 1), "bwd_tflops": round(2.5 * fl / t_b / 1e12, 1),
@@ -396,8 +403,15 @@ def main():
                                    "fwd_frac_of_hbm_peak": round(rb_bytes / t_rf / 8e12, 4),
                                    "fwd_tflops": round(rb_flops / t_rf / 1e12, 1),
                                    "fwd_frac_of_bf16_mfma_peak": round(rb_flops / t_rf / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "groupnorm_silu_320_64x64": {"fwd_us": round(t_gn * 1e6, 1), "bwd_us": round(t_gnb * 1e6, 1),
+                                         "algorithmic_bytes_fwd": int(gn_bytes_f), "algorithmic_bytes_bwd": int(gn_bytes_b),
+                                         "fwd_GBps": round(gn_bytes_f / t_gn / 1e9, 1), "bwd_GBps": round(gn_bytes_b / t_gnb / 1e9, 1),
+                                         "fwd_frac_of_hbm_peak": round(gn_bytes_f / t_gn / 8e12, 4),
+                                         "bwd_frac_of_hbm_peak": round(gn_bytes_b / t_gnb / 8e12, 4),
+                                         "note": "two launches each (statistics, apply): 21 MB tensors are launch-latency bound; "
+                                                 "the 134 MB+ VAE shapes reach 4.2 TB/s"},
         }
-        del qkv, o_, lse_, do_, xr, er, xg, go
+        del qkv, o_, lse_, do_, xr, er, xg, go, dy16
 
     # ---- extra leg, reported beside `value`: config 2's actual iteration mix -- VAE encode of 4, then the
     # Arc2Face teacher rolls ND in {1,3,5,7} steps out on HALF_BS instances and the student is distilled on them
