@@ -712,9 +712,31 @@ class LatentDiffusion(DDPM):
             flags.update(do_arc2face_distill=True, do_static_prompt_delta_reg=False)
         return flags
 
-    def training_step(self, batch, optimizer=None, reducer=None, scheduler=None, **step_kwargs):
+    def training_step(self, batch, optimizer=None, reducer=None, scheduler=None, auto_iteration=None, **step_kwargs):
         """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
-        the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync)."""
+        the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync).
+
+        ``auto_iteration``: a dict with the trainer-side settings of the reference's ``training_step`` preamble
+        (ddpm.py:516-572, 1839-1859) -- ``max_steps``, ``composition_regs_iter_gap``, ``arc2face_distill_iter_prob``,
+        ``max_num_denoising_steps`` -- then ``training_percent`` is updated and the iteration type is DRAWN as in the
+        reference: an Arc2Face-distillation iteration (with its number of denoising steps), else a plain recon
+        iteration with timestep annealing.  Compositional iterations (stage 2) are not built and raise."""
+        if auto_iteration is not None:
+            cfg = auto_iteration
+            gstep = self.batch_idx // self.manual_accumulate_grad_batches            # Lightning's global_step
+            self.training_percent = min(1.0, gstep * self.manual_accumulate_grad_batches / max(1, cfg.get("max_steps", 1)))
+            flags = self.draw_iteration_flags(gstep, cfg.get("composition_regs_iter_gap", 0),
+                                              cfg.get("arc2face_distill_iter_prob", 0.0),
+                                              cfg.get("mix_prompt_distill_weight", 0.0))
+            if flags["is_compos_iter"]:
+                raise NotImplementedError("compositional regularisation iterations (stage 2, composition_regs_iter_gap > 0) "
+                                          "are not built (DESIGN.md 7b)")
+            if flags["do_arc2face_distill"]:
+                step_kwargs.update(use_arc2face_as_target=True, num_denoising_steps=self.draw_num_denoising_steps(
+                    cfg.get("max_num_denoising_steps", 7)))
+            else:
+                step_kwargs.setdefault("anneal_t", True)
+            self.iter_flags = flags
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
         self.manual_backward(model_output, grad, aux)                      # == manual_backward(loss), ddpm.py:595
         if reducer is not None:
