@@ -566,3 +566,28 @@ def test_mask_hinges_fwd_bwd(L, B, H, N, G, have_bg, use_iw):
     (out * gout.to(dev)).sum().backward()
     assert rel(out.cpu(), ref.detach().float()) < 2e-5
     assert rel(mh.grad.cpu(), md.grad.float()) < 2e-5
+
+
+def test_integration_md_ctypes_stub_runs_verbatim():
+    """the binding INTEGRATION.md shows a reference maintainer (GroupNorm32 + SiLU through the C ABI with plain ctypes)
+    is executed as printed there and compared with torch's group_norm + silu."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch\n.*?)```", src, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                  # the stub opens the library by its path relative to the repo root
+    try:
+        exec(code, ns)
+        gn = torch.nn.GroupNorm(32, 320, eps=1e-5).cuda()
+        with torch.no_grad():
+            gn.weight.normal_(1, 0.2)
+            gn.bias.normal_(0, 0.2)
+        x = torch.randn(2, 16, 16, 320, device="cuda")
+        y, mean, rstd = ns["groupnorm32_silu"](x, gn)
+    finally:
+        os.chdir(cwd)
+    ref = F.silu(gn(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    assert rel(y.float(), ref) < 5e-3
