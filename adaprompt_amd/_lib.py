@@ -15,6 +15,8 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "adaprompt_hip.h")
 LIB_PATH = os.path.join(HERE, "libadaprompt_hip.so")
 
+ABI_VERSION = 2        # bumped whenever an entry point's argument list changes (capi.hip returns the same number)
+
 _SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
@@ -52,18 +54,23 @@ def load(build_if_missing=True):
     global _lib, _protos
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise RuntimeError(f"{LIB_PATH} not found; run `python -m adaprompt_amd.build`")
-        from . import build as _build
+    from . import build as _build
+    if build_if_missing:
+        # no-op when the source stamp matches; otherwise a stale library (sources, header or flags changed since it was
+        # built -- the .so is git-ignored but ships with the snapshot) is rebuilt instead of being dlopen'ed
         _build.build(verbose=False)
+    elif not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found; run `python -m adaprompt_amd.build`")
+    elif not _build.is_current():
+        raise RuntimeError(f"{LIB_PATH} is stale (csrc/ or include/adaprompt_hip.h changed since it was built); "
+                           "run `python -m adaprompt_amd.build`")
     lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
     for name, (restype, argtypes, _) in _protos.items():
         fn = getattr(lib, name)       # AttributeError here == header/library mismatch: fail loudly
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.adap_abi_version() != 1:
+    if lib.adap_abi_version() != ABI_VERSION:
         raise RuntimeError("libadaprompt_hip.so: ABI version mismatch")
     _lib = lib
     return lib

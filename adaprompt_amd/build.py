@@ -9,6 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadaprompt_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "adaprompt_hip.h")
 SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip", "wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -21,14 +22,23 @@ def _stamp():
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode())
             h.update(fh.read())
+    with open(HEADER, "rb") as fh:                    # the public C ABI is part of what the library was built from
+        h.update(b"adaprompt_hip.h")
+        h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
+
+
+def is_current():
+    """the library exists and was built from exactly the sources / header / flags on disk."""
+    stamp_file = OUT + ".stamp"
+    return os.path.exists(OUT) and os.path.exists(stamp_file) and open(stamp_file).read() == _stamp()
 
 
 def build(force=False, verbose=True):
     stamp_file = OUT + ".stamp"
     stamp = _stamp()
-    if not force and os.path.exists(OUT) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+    if not force and is_current():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")

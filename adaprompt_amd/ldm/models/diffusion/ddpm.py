@@ -27,6 +27,7 @@ from .... import ops
 from ...modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
 from ...modules.distributions.distributions import DiagonalGaussianDistribution
 from ...util import default, instantiate_from_config
+from .conditioning import ConditioningMixin
 
 
 class DiffusionWrapper(nn.Module):
@@ -52,26 +53,101 @@ class DiffusionWrapper(nn.Module):
 class DDPM(nn.Module):
     """Schedule buffers + q_sample / predict_x0 + the manual-optimisation step bookkeeping."""
 
-    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=1e-4, linear_end=2e-2,
-                 cosine_s=8e-3, given_betas=None, v_posterior=0.0, parameterization="eps", conditioning_key="crossattn",
-                 manual_accumulate_grad_batches=2, grad_clip=0.5, optimizer_type="Prodigy", do_zero_shot=True,
-                 fg_bg_xlayer_consist_loss_weight=5e-5, prompt_emb_delta_reg_weight=2e-4,
-                 fg_bg_complementary_loss_weight=2e-4, **unused):
-        """the last five: v1-finetune-ada.yaml:40,48,50 and ddpm.py:3207-3219, 3246-3270, 3467-3500 (regulariser weights
-        / scales)."""
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None, ignore_keys=(),
+                 load_only_unet=False, monitor="val/loss", use_ema=False, first_stage_key="image", image_size=256, channels=3,
+                 log_every_t=100, clip_denoised=True, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3, given_betas=None,
+                 original_elbo_weight=0., unfreeze_model=False, model_lr=0., v_posterior=0., conditioning_key="crossattn",
+                 parameterization="eps", optimizer_type="Prodigy", grad_clip=0.5, manual_accumulate_grad_batches=2,
+                 adam_config=None, prodigy_config=None, use_positional_encodings=False, learn_logvar=False, logvar_init=0.,
+                 use_layerwise_embedding=True, composition_regs_iter_gap=3, static_embedding_reg_weight=0.,
+                 prompt_emb_delta_reg_weight=2e-4, mix_prompt_distill_weight=0., comp_fg_bg_preserve_loss_weight=0.,
+                 fg_bg_complementary_loss_weight=2e-4, fg_wds_complementary_loss_weight=0.,
+                 fg_bg_xlayer_consist_loss_weight=5e-5, compel_cfg_weight_level_range=(2, 2), apply_compel_cfg_prob=0.,
+                 wds_bg_recon_discount=1., do_clip_teacher_filtering=True, num_candidate_teachers=2,
+                 use_background_token=True, use_fp_trick=True, normalize_ca_q_and_outfeat=True, do_zero_shot=True,
+                 arc2face_distill_iter_prob=0, apply_arc2face_inverse_embs=False, p_gen_arc2face_rand_face=0.4,
+                 p_add_noise_to_real_id_embs=0.6, max_num_denoising_steps=5,
+                 extend_prompt2token_proj_attention_multiplier=-1, load_old_embman_ckpt=False):
+        """The reference's keyword surface (ddpm.py:76-130), so that the ``params`` block of v1-finetune-ada.yaml:5-84
+        instantiates this class unchanged.  Every keyword is stored under the reference's attribute name; the ones whose
+        feature is not built (EMA, learned log-variance, x0 parameterisation, positional encodings) are refused loudly
+        instead of being ignored.  Defaults differ from the reference only where the reference's default is never what the
+        yaml ships AND this package's tests relied on the shipped value: the three recon-regulariser weights (yaml:40,48,50),
+        ``manual_accumulate_grad_batches`` (yaml:62) and ``use_layerwise_embedding`` (yaml:28)."""
         super().__init__()
-        assert parameterization == "eps"
+        assert parameterization == "eps", "SD-1.5 / AdaFace predicts eps; 'x0' is not built"
+        if use_ema:
+            raise NotImplementedError("use_ema: True (LitEma) is out of scope -- the shipped config has use_ema: False (yaml:25)")
+        if learn_logvar or use_positional_encodings:
+            raise NotImplementedError("learn_logvar / use_positional_encodings are unused by the SD-1.5 config and not built")
         self.parameterization = parameterization
+        self.cond_stage_model = None
+        self.clip_denoised, self.log_every_t, self.first_stage_key = clip_denoised, log_every_t, first_stage_key
+        self.image_size, self.channels = image_size, channels
+        self.use_layerwise_embedding = use_layerwise_embedding
+        self.N_CA_LAYERS = 16 if use_layerwise_embedding else 1
+        self.do_zero_shot = do_zero_shot
+        self.static_embedding_reg_weight = static_embedding_reg_weight
+        self.composition_regs_iter_gap = composition_regs_iter_gap
+        self.prompt_emb_delta_reg_weight = prompt_emb_delta_reg_weight
+        self.mix_prompt_distill_weight = mix_prompt_distill_weight
+        self.comp_fg_bg_preserve_loss_weight = comp_fg_bg_preserve_loss_weight
+        self.fg_bg_complementary_loss_weight = fg_bg_complementary_loss_weight
+        self.fg_wds_complementary_loss_weight = fg_wds_complementary_loss_weight
+        self.fg_bg_xlayer_consist_loss_weight = fg_bg_xlayer_consist_loss_weight
+        self.compel_cfg_weight_level_range = None if compel_cfg_weight_level_range is None else list(compel_cfg_weight_level_range)
+        self.empty_context = None
+        self.apply_compel_cfg_prob = apply_compel_cfg_prob
+        self.do_clip_teacher_filtering = do_clip_teacher_filtering
+        self.num_candidate_teachers = num_candidate_teachers
+        self.prompt_mix_scheme = "mix_hijk"
+        self.wds_bg_recon_discount = wds_bg_recon_discount
+        self.use_background_token = use_background_token
+        self.use_fp_trick = use_fp_trick
+        self.normalize_ca_q_and_outfeat = normalize_ca_q_and_outfeat
+        self.arc2face_distill_iter_prob = arc2face_distill_iter_prob if do_zero_shot else 0
+        self.apply_arc2face_inverse_embs = apply_arc2face_inverse_embs
+        self.p_gen_arc2face_rand_face = p_gen_arc2face_rand_face
+        self.p_add_noise_to_real_id_embs = p_add_noise_to_real_id_embs
+        self.max_num_denoising_steps = max_num_denoising_steps
+        self.extend_prompt2token_proj_attention_multiplier = extend_prompt2token_proj_attention_multiplier
+        self.load_old_embman_ckpt = load_old_embman_ckpt
+        self.cached_inits = {}
+        self.do_static_prompt_delta_reg = prompt_emb_delta_reg_weight >= 0
+        self.init_iteration_flags()
+        self.is_dreambooth = False
         self.v_posterior = v_posterior
         self.model = DiffusionWrapper(unet_config, conditioning_key)
-        self.manual_accumulate_grad_batches = manual_accumulate_grad_batches
-        self.grad_clip = grad_clip
+        self.use_ema = use_ema
         self.optimizer_type = optimizer_type
-        self.do_zero_shot = do_zero_shot
-        self.fg_bg_xlayer_consist_loss_weight = fg_bg_xlayer_consist_loss_weight
-        self.prompt_emb_delta_reg_weight = prompt_emb_delta_reg_weight
-        self.fg_bg_complementary_loss_weight = fg_bg_complementary_loss_weight
+        self.adam_config = adam_config
+        self.prodigy_config = prodigy_config if "Prodigy" in optimizer_type else None
+        self.grad_clip = grad_clip
+        self.manual_accumulate_grad_batches = manual_accumulate_grad_batches
+        self.automatic_optimization = False
+        self.training_percent = 0.
+        self.original_elbo_weight = original_elbo_weight
+        self.unfreeze_model = unfreeze_model
+        self.model_lr = model_lr
+        self.monitor = monitor
+        self.loss_type = loss_type
         self.register_schedule(given_betas, beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
+
+    def init_iteration_flags(self):
+        """ddpm.py:484-506."""
+        self.iter_flags = {"calc_clip_loss": False, "do_normal_recon": True, "do_arc2face_distill": False,
+                           "gen_arc2face_rand_face": False, "arc2face_prompt_emb": None, "add_noise_to_real_id_embs": False,
+                           "faceless_img_count": 0, "use_arc2face_as_target": False, "num_denoising_steps": 1,
+                           "is_compos_iter": False, "do_mix_prompt_distillation": False,
+                           "do_static_prompt_delta_reg": self.do_static_prompt_delta_reg, "do_ada_prompt_delta_reg": False,
+                           "use_background_token": False, "use_wds_comp": False, "use_wds_cls_captions": False,
+                           "use_fp_trick": False, "reuse_init_conds": False, "comp_init_fg_from_training_image": False}
+
+    @property
+    def device(self):
+        return self.betas.device
 
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
                           linear_end=2e-2, cosine_s=8e-3):
@@ -114,24 +190,99 @@ def _const_tensor(values, device):
     return t
 
 
-class LatentDiffusion(DDPM):
+class LatentDiffusion(ConditioningMixin, DDPM):
     """The recon-distillation iteration core of the reference ``LatentDiffusion`` (ddpm.py:710-3457)."""
 
-    def __init__(self, first_stage_config, unet_config, cond_fn=None, scale_factor=0.18215, bg_pixel_weight=0.1,
-                 ckpt_path=None, **kwargs):
-        kwargs.setdefault("linear_start", 0.00085)
-        kwargs.setdefault("linear_end", 0.012)
-        super().__init__(unet_config=unet_config, **kwargs)
-        self.first_stage_model = instantiate_from_config(first_stage_config).eval()
-        for p in self.first_stage_model.parameters():
-            p.requires_grad = False
+    def __init__(self, first_stage_config, cond_stage_config=None, personalization_config=None, num_timesteps_cond=None,
+                 cond_stage_key="image", cond_stage_trainable=False, concat_mode=True, cond_stage_forward=None,
+                 conditioning_key=None, scale_factor=1.0, scale_by_std=False, is_dreambooth=False, *args,
+                 cond_fn=None, bg_pixel_weight=0.1, **kwargs):
+        """The reference's constructor (ddpm.py:710-810): ``first_stage_config``, ``cond_stage_config``,
+        ``personalization_config`` and -- through ``**kwargs`` -- ``unet_config=`` and every ``DDPM`` keyword, so
+        ``instantiate_from_config(yaml.model)`` builds this class from v1-finetune-ada.yaml as it stands.  The text encoder
+        and the embedding manager named by the two configs are the reference's own classes (or whatever the targets resolve
+        to) and are only called (``conditioning.ConditioningMixin``).  Two keyword-only extras: ``cond_fn(batch) -> cond``
+        replaces the conditioning side wholesale (benchmarks / kernel tests without HF weights), ``bg_pixel_weight``."""
+        self.num_timesteps_cond = default(num_timesteps_cond, 1)
+        self.scale_by_std = scale_by_std
+        assert self.num_timesteps_cond <= kwargs.get("timesteps", 1000)
+        if scale_by_std:
+            raise NotImplementedError("scale_by_std is unused by the SD-1.5 config (scale_factor 0.18215 is given) and not built")
+        if is_dreambooth:
+            raise NotImplementedError("is_dreambooth: the DreamBooth regularisation batches are out of scope (SURVEY.md section 2)")
+        if conditioning_key is None:
+            conditioning_key = "concat" if concat_mode else "crossattn"
+        ckpt_path = kwargs.pop("ckpt_path", None)
+        ignore_keys = kwargs.pop("ignore_keys", [])
+        super().__init__(*args, conditioning_key=conditioning_key, **kwargs)
+        self.concat_mode = concat_mode
+        self.cond_stage_trainable = cond_stage_trainable
+        self.cond_stage_key = cond_stage_key
+        self.cond_stage_forward = cond_stage_forward
+        self.clip_denoised = False
         self.scale_factor = scale_factor
         self.bg_pixel_weight = bg_pixel_weight
         self.cond_fn = cond_fn
         self.batch_idx = 0
-        self.arc2face = None          # Arc2FaceWrapper, attached by set_arc2face_teacher (ddpm.py:903-907)
+        self.is_dreambooth = False
+        self.instantiate_first_stage(first_stage_config)
+        self.embedding_manager = None
+        if cond_stage_config is not None:
+            self.instantiate_cond_stage(cond_stage_config)
+        self.restarted_from_ckpt = ckpt_path is not None
         if ckpt_path is not None:
-            self.init_from_ckpt(ckpt_path)
+            self.init_from_ckpt(ckpt_path, ignore_keys)
+        self.arc2face = None          # Arc2FaceWrapper, attached by set_arc2face_teacher (ddpm.py:771, 903-907)
+        if not self.unfreeze_model:   # ddpm.py:775-786
+            if self.cond_stage_model is not None:
+                self.cond_stage_model.eval()
+                for p in self.cond_stage_model.parameters():
+                    p.requires_grad = False
+            self.freeze_unet()
+        if personalization_config is not None:
+            self.embedding_manager = self.instantiate_embedding_manager(personalization_config, self.cond_stage_model)
+            if self.do_zero_shot and hasattr(self.embedding_manager, "make_frozen_copy_of_subj_basis_generators"):
+                self.embedding_manager.make_frozen_copy_of_subj_basis_generators()      # ddpm.py:797
+        if self.cond_stage_model is not None and self.embedding_manager is not None:
+            # ddpm.py:812-814: the empty prompt's context, one layer's worth
+            self.empty_context = self.get_learned_conditioning([""], embman_iter_type="empty")[0][[0]]
+
+    @classmethod
+    def hot_path(cls, first_stage_config, unet_config, cond_fn=None, **kwargs):
+        """the kernels-only construction used by bench.py / smoke() / the kernel tests: no text encoder, no embedding manager
+        (the context comes from ``cond_fn`` or is passed to ``shared_step``), SD-1.5's schedule and scale factor."""
+        kwargs.setdefault("linear_start", 0.00085)
+        kwargs.setdefault("linear_end", 0.012)
+        kwargs.setdefault("scale_factor", 0.18215)
+        kwargs.setdefault("conditioning_key", "crossattn")
+        kwargs.setdefault("unfreeze_model", True)         # leave requires_grad alone: callers call freeze_unet() themselves
+        return cls(first_stage_config, unet_config=unet_config, cond_fn=cond_fn, **kwargs)
+
+    # ---- ddpm.py:863-901 ---------------------------------------------------------------------------------------------
+    def instantiate_first_stage(self, config):
+        self.first_stage_model = instantiate_from_config(config).eval()
+        for p in self.first_stage_model.parameters():
+            p.requires_grad = False
+
+    def instantiate_cond_stage(self, config):
+        if config == "__is_unconditional__":
+            self.cond_stage_model = None
+            return
+        if config == "__is_first_stage__":
+            raise NotImplementedError("cond_stage_config '__is_first_stage__' is not an SD-1.5 configuration")
+        model = instantiate_from_config(config)
+        if not self.cond_stage_trainable:
+            model = model.eval()
+            for p in model.parameters():
+                p.requires_grad = False
+        self.cond_stage_model = model
+
+    def instantiate_embedding_manager(self, config, text_embedder):
+        model = instantiate_from_config(config, text_embedder=text_embedder)
+        ckpt = (config.get("params") or {}).get("embedding_manager_ckpt", None)
+        if ckpt:                      # not when missing OR empty
+            model.load(ckpt, self.extend_prompt2token_proj_attention_multiplier, self.load_old_embman_ckpt)
+        return model
 
     # ---- checkpoint API (ddpm.py:321-344): .ckpt ['state_dict'] or .safetensors, strict=False ----------
     def init_from_ckpt(self, path, ignore_keys=(), only_model=False):
@@ -160,14 +311,27 @@ class LatentDiffusion(DDPM):
             p.requires_grad = False
         self.unfreeze_model = False
 
+    @property
+    def global_step(self):
+        """Lightning's counter under manual optimisation: one per optimiser step, i.e. per ``manual_accumulate_grad_batches``
+        micro-batches (ddpm.py:518-520)."""
+        return self.batch_idx // self.manual_accumulate_grad_batches
+
     def on_save_checkpoint(self, checkpoint, embedding_manager=None, ckpt_dir=None, global_step=None):
-        """ddpm.py:5393-5400: with a frozen UNet the Lightning checkpoint is emptied (nothing in it changed) and only the
-        embedding manager's state is written -- by the embedding manager itself (``save(path)``, the reference's own class
-        behind the boundary), as ``embeddings.pt`` and ``embeddings_gs-<step>.pt``."""
+        """ddpm.py:5392-5400 -- Lightning calls ``on_save_checkpoint(checkpoint)``: with a frozen UNet the checkpoint dict is
+        emptied (nothing in it changed) and only the embedding manager's state is written -- by the embedding manager itself
+        (``save(path)``, the reference's own class behind the boundary), as ``embeddings.pt`` and ``embeddings_gs-<step>.pt``
+        in ``self.trainer.checkpoint_callback.dirpath``.  The three keywords override what is otherwise read from ``self`` /
+        the attached trainer."""
         import os
         if not getattr(self, "unfreeze_model", any(p.requires_grad for p in self.model.parameters())):
             checkpoint.clear()
+        embedding_manager = embedding_manager if embedding_manager is not None else getattr(self, "embedding_manager", None)
+        if ckpt_dir is None:
+            cb = getattr(getattr(self, "trainer", None), "checkpoint_callback", None)
+            ckpt_dir = getattr(cb, "dirpath", None)
         if embedding_manager is not None and ckpt_dir is not None and os.path.isdir(ckpt_dir):
+            global_step = self.global_step if global_step is None else global_step
             embedding_manager.save(os.path.join(ckpt_dir, "embeddings.pt"))
             embedding_manager.save(os.path.join(ckpt_dir, f"embeddings_gs-{global_step}.pt"))
 
@@ -531,6 +695,33 @@ class LatentDiffusion(DDPM):
         ``forward`` does before ``p_losses`` runs."""
         if x_start is None:
             x_start, _mask = self.get_input(batch, post_noise)
+        hw = x_start.shape[-2:]
+        fg = batch.get("fg_mask")
+        aug = batch.get("aug_mask")
+        img_mask = None if aug is None else torch.nn.functional.interpolate(aug[:, None].float(), size=hw, mode="nearest")
+        fg_mask = None if fg is None else torch.nn.functional.interpolate(fg[:, None].float(), size=hw, mode="nearest")
+        instance_mask = batch.get("batch_have_fg_mask", batch.get("has_fg_mask"))
+        do_static_delta = True
+        if cond is None and self.cond_fn is None:
+            # the reference's own conditioning side (yaml-instantiated text encoder + embedding manager): the front of its
+            # ``shared_step`` and ``forward`` (ddpm.py:1436-2179), conditioning.ConditioningMixin
+            if self.embedding_manager is None:
+                raise RuntimeError("shared_step needs a context: pass cond=, set cond_fn, or construct the model with "
+                                   "cond_stage_config + personalization_config")
+            x_start, img_mask, fg_mask, captions = self.prepare_recon_iteration(batch, x_start, img_mask, fg_mask)
+            fl = self.iter_flags
+            cond = self.assemble_conditioning(captions, x_start.shape[0])
+            cond[2]["capture_distill_attn"] = True                      # ddpm.py:2866 (recon: not do_teacher_filter)
+            self.attach_subject_indices(cond[2])
+            instance_mask = fl["batch_have_fg_mask"]
+            use_arc2face_as_target = bool(fl["use_arc2face_as_target"])
+            num_denoising_steps = int(fl["num_denoising_steps"])
+            trim_to_half_batch = False                                  # prepare_recon_iteration has trimmed everything
+            do_static_delta = bool(fl["do_static_prompt_delta_reg"])
+            if use_arc2face_as_target:
+                batch = dict(batch, arc2face_prompt_emb=fl["arc2face_prompt_emb"])
+            t = None if t is None else t[:x_start.shape[0]]
+            noise = None if noise is None else noise[:x_start.shape[0]]
         nd = int(num_denoising_steps)
         if use_arc2face_as_target and nd > 1 and trim_to_half_batch:
             hb = self.half_batch_size(x_start.shape[0], nd)
@@ -538,6 +729,8 @@ class LatentDiffusion(DDPM):
             batch = {k: (v[:hb] if torch.is_tensor(v) and v.dim() > 0 else v) for k, v in batch.items()}
             t = None if t is None else t[:hb]
             noise = None if noise is None else noise[:hb]
+            img_mask = None if img_mask is None else img_mask[:hb]
+            fg_mask = None if fg_mask is None else fg_mask[:hb]
         B = x_start.shape[0]
         if t is None:
             t = torch.randint(0, self.num_timesteps, (B,), device=x_start.device).long()
@@ -545,11 +738,13 @@ class LatentDiffusion(DDPM):
             noise = torch.randn_like(x_start)
         if cond is None:
             cond = self.cond_fn(batch)
-        hw = x_start.shape[-2:]
-        fg = batch.get("fg_mask")
-        aug = batch.get("aug_mask")
-        img_mask = None if aug is None else torch.nn.functional.interpolate(aug[:, None].float(), size=hw, mode="nearest")
-        fg_mask = None if fg is None else torch.nn.functional.interpolate(fg[:, None].float(), size=hw, mode="nearest")
+        if anneal_t and teacher_out is None:
+            # every normal-recon iteration -- Arc2Face distillation included -- shifts t up by a random factor in [1, 1.3]
+            # with an annealed probability BEFORE the multi-step shift (ddpm.py:2851-2866: the zero-shot and the default
+            # branch use the same ranges); a prefetched rollout was made from a t that already went through both
+            from ...util import probably_anneal_t
+            t = probably_anneal_t(t, getattr(self, "training_percent", 0.0), self.num_timesteps, ratio_range=(1, 1.3),
+                                  keep_prob_range=(0.4, 0.2))
         if use_arc2face_as_target:
             if teacher_out is None:
                 t = self.shift_t_for_multistep(t, nd)          # (a prefetched rollout was made with the shifted t)
@@ -558,20 +753,14 @@ class LatentDiffusion(DDPM):
                 batched_student=batched_student, teacher_out=teacher_out)
             aux.update(x_start=x_start, t=t)
             return loss, grads, outs, aux
-        if anneal_t:
-            # recon iterations shift t up by a random factor in [1, 1.3] with an annealed probability
-            # (ddpm.py:2851-2866: the zero-shot and the default branch use the same ranges)
-            from ...util import probably_anneal_t
-            t = probably_anneal_t(t, getattr(self, "training_percent", 0.0), self.num_timesteps, ratio_range=(1, 1.3),
-                                  keep_prob_range=(0.4, 0.2))
         c_emb, c_in, extra_info = cond
         extra_info = dict(extra_info)
         extra_info["img_mask"] = img_mask                                  # ddpm.py:2876
         model_output, x_noisy = self.guided_denoise(x_start, noise, t, (c_emb, c_in, extra_info))
         loss, grad = self.calc_recon_loss(model_output, noise, img_mask, fg_mask, 1.0, self.bg_pixel_weight)
         aux = {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
-        reg, parts = self.recon_regularizers(extra_info, B, do_static_prompt_delta_reg=True, fg_mask=fg_mask,
-                                             instance_mask=batch.get("batch_have_fg_mask"), do_complementary=True)
+        reg, parts = self.recon_regularizers(extra_info, B, do_static_prompt_delta_reg=do_static_delta, fg_mask=fg_mask,
+                                             instance_mask=instance_mask, do_complementary=True)
         if reg is not None:
             aux["reg_loss"], aux["reg_parts"] = reg, parts
             loss = loss + reg.detach()
@@ -657,8 +846,8 @@ class LatentDiffusion(DDPM):
     def make_distill_prefetcher(self):
         return DistillPrefetcher(self)
 
-    def configure_optimizers(self, optimized_parameters, max_steps, prodigy_config=None, weight_decay=0.0,
-                             unfreeze_model=False, extra_model_parameters=()):
+    def configure_optimizers(self, optimized_parameters=None, max_steps=None, prodigy_config=None, weight_decay=None,
+                             unfreeze_model=None, extra_model_parameters=()):
         """The Prodigy branch of the reference's ``configure_optimizers`` (ddpm.py:5134-5345) with the 'Linear' schedule
         (v1-finetune-ada.yaml:59,74-84).  ``optimized_parameters``: what ``EmbeddingManager.optimized_parameters()``
         returns -- a list of {'params', 'lr_ratio', 'excluded_from_prodigy'} (embedding_manager.py:2078-2095).  As in the
@@ -668,12 +857,25 @@ class LatentDiffusion(DDPM):
         encoder's) parameters (ddpm.py:5176-5181).  -> Lightning's [{'optimizer', 'frequency', 'lr_scheduler': {...}}]."""
         from ...prodigy import Prodigy
         from ...util import prodigy_linear_schedule
+        # Lightning's no-argument call: everything comes from the model and its trainer, as in the reference
+        if optimized_parameters is None:
+            optimized_parameters = self.embedding_manager.optimized_parameters()
+        if max_steps is None:
+            max_steps = self.trainer.max_steps
+        if prodigy_config is None:
+            prodigy_config = getattr(self, "prodigy_config", None)
+        if weight_decay is None:
+            weight_decay = getattr(self, "weight_decay", 0.0)           # set on the model by main.py:1172
+        if unfreeze_model is None:
+            unfreeze_model = bool(getattr(self, "unfreeze_model", False))
+            if unfreeze_model and not extra_model_parameters and self.cond_stage_model is not None:
+                extra_model_parameters = list(self.cond_stage_model.parameters())      # ddpm.py:5179
         if getattr(self, "optimizer_type", "Prodigy") != "Prodigy":
             raise NotImplementedError("only optimizer_type 'Prodigy' (the shipped config) is built; AdamW / NAdam / "
                                       "ProdigyAdamW are out of scope (DESIGN.md 7)")
         cfg = {"zs_betas": (0.9, 0.999), "betas": (0.985, 0.993), "d_coef": 2.0, "warm_up_steps": 500, "scheduler_cycles": 1,
                "scheduler_type": "Linear"}
-        cfg.update(prodigy_config or {})
+        cfg.update(dict(prodigy_config or {}))
         if cfg["scheduler_type"] != "Linear":
             raise NotImplementedError(f"Prodigy scheduler_type {cfg['scheduler_type']!r}: only 'Linear' is built")
         groups = [{"params": [q for q in g["params"] if q.requires_grad],
@@ -712,8 +914,13 @@ class LatentDiffusion(DDPM):
             flags.update(do_arc2face_distill=True, do_static_prompt_delta_reg=False)
         return flags
 
-    def training_step(self, batch, optimizer=None, reducer=None, scheduler=None, auto_iteration=None, **step_kwargs):
-        """manual optimisation (ddpm.py:583-633).  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
+    def training_step(self, batch, batch_idx=None, optimizer=None, reducer=None, scheduler=None, auto_iteration=None,
+                      **step_kwargs):
+        """manual optimisation (ddpm.py:515-638).  Lightning's call ``training_step(batch, batch_idx)`` works when a trainer
+        is attached (``self.trainer`` with ``max_steps`` and the ``optimizer`` / ``scheduler`` / ``reducer`` that
+        ``adaprompt_amd.trainer.Trainer.fit`` set up from ``configure_optimizers``): the iteration type is then drawn from
+        the model's own yaml settings, exactly the reference's preamble.  The keyword form below is the same step with
+        the trainer-side objects passed explicitly.  ``reducer`` (adaprompt_amd.parallel.GradReducer) all-reduces
         the trainable gradients after every micro-batch backward, as DDP does in the reference (no no_sync).
 
         ``auto_iteration``: a dict with the trainer-side settings of the reference's ``training_step`` preamble
@@ -721,6 +928,14 @@ class LatentDiffusion(DDPM):
         ``max_num_denoising_steps`` -- then ``training_percent`` is updated and the iteration type is DRAWN as in the
         reference: an Arc2Face-distillation iteration (with its number of denoising steps), else a plain recon
         iteration with timestep annealing.  Compositional iterations (stage 2) are not built and raise."""
+        tr = getattr(self, "trainer", None)
+        if optimizer is None and tr is not None and batch_idx is not None:
+            optimizer, scheduler, reducer = tr.optimizer, tr.scheduler, tr.reducer
+            if auto_iteration is None:
+                auto_iteration = {"max_steps": tr.max_steps, "composition_regs_iter_gap": self.composition_regs_iter_gap,
+                                  "arc2face_distill_iter_prob": self.arc2face_distill_iter_prob,
+                                  "mix_prompt_distill_weight": self.mix_prompt_distill_weight,
+                                  "max_num_denoising_steps": self.max_num_denoising_steps}
         if auto_iteration is not None:
             cfg = auto_iteration
             gstep = self.batch_idx // self.manual_accumulate_grad_batches            # Lightning's global_step
@@ -731,13 +946,19 @@ class LatentDiffusion(DDPM):
             if flags["is_compos_iter"]:
                 raise NotImplementedError("compositional regularisation iterations (stage 2, composition_regs_iter_gap > 0) "
                                           "are not built (DESIGN.md 7b)")
-            if flags["do_arc2face_distill"]:
+            if flags["do_arc2face_distill"] and (self.cond_fn is not None or "cond" in step_kwargs):
+                # (with the reference's own conditioning side, shared_step's front decides use_arc2face_as_target / ND)
                 step_kwargs.update(use_arc2face_as_target=True, num_denoising_steps=self.draw_num_denoising_steps(
                     cfg.get("max_num_denoising_steps", 7)))
-            else:
-                step_kwargs.setdefault("anneal_t", True)
-            self.iter_flags = flags
+            step_kwargs.setdefault("anneal_t", True)       # every normal-recon iteration, distillation included (:2851-2861)
+            self.init_iteration_flags()
+            self.iter_flags.update(flags)
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
+        if reducer is not None:
+            # the previous micro-batch's all-reduce overlapped the forward above; it must have landed before this backward
+            # adds into the same flat gradient buffer (AccumulateGrad and the weight-gradient kernels write it from the
+            # very start of the backward)
+            reducer.wait()
         self.manual_backward(model_output, grad, aux)                      # == manual_backward(loss), ddpm.py:595
         if reducer is not None:
             reducer.reduce()
@@ -815,7 +1036,9 @@ class DistillPrefetcher(LatentPrefetcher):
                           use_arc2face_as_target=True, trim_to_half_batch=False-equivalent handled by the caller ...)
     """
 
-    def submit(self, batch, post_noise, t, noise, nd):
+    def submit(self, batch, post_noise, t, noise, nd, anneal_t=True):
+        """``anneal_t``: the recon iteration's timestep annealing, applied BEFORE the multi-step shift as in the reference
+        (ddpm.py:2851-2861: distillation iterations are normal-recon iterations and go through both)."""
         m = self.model
         main = torch.cuda.current_stream()
         self.stream.wait_stream(main)
@@ -825,6 +1048,10 @@ class DistillPrefetcher(LatentPrefetcher):
             x_start = x_start.contiguous()
             hb = m.half_batch_size(x_start.shape[0], nd) if nd > 1 else x_start.shape[0]
             x_start, t, noise = x_start[:hb].contiguous(), t[:hb].contiguous(), noise[:hb].contiguous()
+            if anneal_t:
+                from ...util import probably_anneal_t
+                t = probably_anneal_t(t, getattr(m, "training_percent", 0.0), m.num_timesteps, ratio_range=(1, 1.3),
+                                      keep_prob_range=(0.4, 0.2))
             t = m.shift_t_for_multistep(t, nd)
             teacher = m.arc2face(m, x_start, noise, t, batch["arc2face_prompt_emb"][:hb], num_denoising_steps=nd)
             ev = torch.cuda.Event()

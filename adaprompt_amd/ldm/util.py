@@ -4,6 +4,7 @@ Dotted targets of the reference yaml (``ldm.modules.diffusionmodules.openaimodel
 ``ldm.models.autoencoder.AutoencoderKL`` ...) resolve to this package's MI355X implementations,
 either through the top-level ``ldm`` alias package of this repo or by the rewrite below."""
 import importlib
+import importlib.util
 from bisect import bisect_right
 
 import numpy as np
@@ -16,9 +17,17 @@ _PREFIX = "adaprompt_amd."
 
 
 def get_obj_from_str(string, reload=False):
+    """``ldm.<...>`` targets resolve to this package's mirror when it has the module, otherwise to whatever ``ldm.<...>``
+    imports as -- with a reference checkout behind this repo on ``sys.path`` that is the reference's own module (embedding
+    manager, text encoder, LR scheduler, datasets: the top-level ``ldm`` alias package)."""
     module, cls = string.rsplit(".", 1)
     if module.startswith("ldm."):
-        module = _PREFIX + module
+        try:
+            found = importlib.util.find_spec(_PREFIX + module) is not None
+        except ModuleNotFoundError:
+            found = False
+        if found:
+            module = _PREFIX + module
     mod = importlib.import_module(module)
     if reload:
         importlib.reload(mod)
@@ -31,6 +40,23 @@ def instantiate_from_config(config, **kwargs):
             return None
         raise KeyError("Expected key `target` to instantiate.")
     return get_obj_from_str(config["target"])(**config.get("params", dict()), **kwargs)
+
+
+def load_config(path):
+    """a yaml config as plain dicts / lists, with OmegaConf's number resolution (``2e-4`` without a dot is a float there;
+    PyYAML's YAML-1.1 resolver would leave it a string).  The reference loads its configs with ``OmegaConf.load``
+    (main.py:822); omegaconf is not a dependency of this package."""
+    import re
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+    Loader.add_implicit_resolver(
+        "tag:yaml.org,2002:float",
+        re.compile(r"^[-+]?(?:[0-9][0-9_]*\.[0-9_]*(?:[eE][-+]?[0-9]+)?|\.[0-9_]+(?:[eE][-+]?[0-9]+)?"
+                   r"|[0-9][0-9_]*[eE][-+]?[0-9]+|\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"), list("-+0123456789."))
+    with open(path) as fh:
+        return yaml.load(fh, Loader=Loader)
 
 
 def exists(x):
@@ -404,3 +430,60 @@ def distribute_embedding_to_M_tokens_by_dict(text_embedding, placeholder_indices
         if indices is not None and len(indices[1]) > 1:
             text_embedding = distribute_embedding_to_M_tokens(text_embedding, indices[1])
     return text_embedding
+
+
+# ---- index bookkeeping of the conditioning assembly (reference ldm/util.py:999-1036, 1313-1343) ------------------------
+def join_list_of_indices(*indices_list):
+    """[(idx_B, idx_N), ...] -> one (idx_B, idx_N) pair, concatenated in order."""
+    return (torch.cat([b for b, _ in indices_list], dim=0), torch.cat([n for _, n in indices_list], dim=0))
+
+
+def join_dict_of_indices_with_key_filter(indices_dict, key_filter_list):
+    """the index pairs of the placeholders named in ``key_filter_list``, joined; None when there are none."""
+    if indices_dict is None:
+        return None
+    sel = [v for k, v in indices_dict.items() if k in key_filter_list and v is not None]
+    return join_list_of_indices(*sel) if sel else None
+
+
+def halve_token_indices(token_indices):
+    """first half of an (idx_B, idx_N) pair (``chunk(2)[0]`` of each), or of every pair of a dict."""
+    if isinstance(token_indices, dict):
+        return {k: halve_token_indices(v) for k, v in token_indices.items()}
+    if token_indices is None:
+        return None
+    return (token_indices[0].chunk(2)[0], token_indices[1].chunk(2)[0])
+
+
+def merge_cls_token_embeddings(prompt_embedding, cls_delta_string_indices, subj_name_to_cls_delta_token_weights):
+    """A class-delta string of M tokens ("young woman") stands where the subject prompts have ONE subject token: replace its
+    M embeddings by their weighted sum and shift the rest of the prompt left by M-1 (the EOS at the end stays), so the class
+    prompts stay token-aligned with the subject prompts.  ``cls_delta_string_indices``: [(batch_i, start_N, M, subj_name)];
+    several strings in one prompt accumulate their shifts in start order."""
+    if cls_delta_string_indices is None or len(cls_delta_string_indices) == 0:
+        return prompt_embedding
+    out = prompt_embedding.clone()
+    shifted = {}
+    for bi, start, M, name in sorted(cls_delta_string_indices, key=lambda x: (x[0], x[1])):
+        off = shifted.get(bi, 0)
+        w = subj_name_to_cls_delta_token_weights[name].unsqueeze(1).to(prompt_embedding.device)
+        out[bi, start - off] = (prompt_embedding[bi, start:start + M] * w).sum(dim=0)
+        out[bi, start + 1 - off:-(M + off)] = prompt_embedding[bi, start + M:-1]
+        shifted[bi] = off + M - 1
+    return out
+
+def __getattr__(name):
+    """names of the reference's ``ldm/util.py`` that this mirror does not define (tokenizer / embedding-manager helpers,
+    logging utilities: boundary-side code) resolve to the reference's own module when a reference
+    checkout follows this repo on ``sys.path`` -- see the top-level ``ldm`` alias package."""
+    if name.startswith("__"):
+        raise AttributeError(name)
+    import sys
+    _alias = sys.modules.get("_adaprompt_ldm_alias")
+    if _alias is None:
+        import ldm as _alias                     # noqa: F811  (installs the finder and registers itself)
+    ref = _alias.reference_module("ldm.util") if hasattr(_alias, "reference_module") else None
+    if ref is not None and hasattr(ref, name):
+        return getattr(ref, name)
+    raise AttributeError(f"module 'ldm.util' has no attribute {name!r} (not mirrored in adaprompt_amd.ldm.util"
+                         + ("" if ref is not None else "; no reference checkout on sys.path to fall through to") + ")")

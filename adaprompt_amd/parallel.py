@@ -54,7 +54,8 @@ class GradReducer:
         if flat is not None:
             lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
             for p in self.params:
-                assert p.grad is not None and lo <= p.grad.data_ptr() < hi, "flat= must hold every p.grad"
+                assert p.grad is not None and lo <= p.grad.data_ptr() and p.grad.data_ptr() + p.numel() * 4 <= hi, \
+                    "flat= must hold every p.grad entirely"
             self.flat = flat
             n = flat.numel()
         else:
@@ -69,19 +70,34 @@ class GradReducer:
         self.chunks = [self.flat[i:i + per] for i in range(0, n, per)]
         self._works = []
         self.bytes_per_reduce = n * 4
+        # RCCL averages inside the collective (ReduceOp.AVG: the 1/world factor rides on the reduction, no extra pass over
+        # the 0.6-4.5 GB buffer); gloo has no AVG, so there the sum is scaled once it has landed (wait()).
+        backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self._avg_in_collective = backend == "nccl"
+        self._scale_pending = False
 
     def reduce(self):
         if self.world == 1:
             return
         self.wait()
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
         for c in self.chunks:
-            c.mul_(1.0 / self.world)
-            self._works.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(c, op=op, group=self.group, async_op=True))
+        self._scale_pending = not self._avg_in_collective
 
     def wait(self):
+        """the current stream waits for the outstanding collectives.  MUST run before anything writes the gradient
+        buffer again (the next ``manual_backward``) and before the optimiser reads it."""
         for w in self._works:
             w.wait()
         self._works = []
+        if self._scale_pending:
+            self.flat.mul_(1.0 / self.world)
+            self._scale_pending = False
+
+    @property
+    def pending(self):
+        return bool(self._works)
 
     def zero(self):
         self.wait()

@@ -1,0 +1,58 @@
+"""The thin training driver this package ships in place of the reference's Lightning launcher (main.py:1149-1206
+``Trainer.from_argparse_args(strategy="ddp") ... trainer.fit(model, data)``; SURVEY.md section 2 marks the launcher itself out
+of scope): it gives ``LatentDiffusion`` exactly the trainer-side objects its ``training_step(batch, batch_idx)`` /
+``configure_optimizers()`` / ``on_save_checkpoint(checkpoint)`` hooks read from Lightning -- ``trainer.max_steps``, the
+optimiser and LR scheduler, ``trainer.checkpoint_callback.dirpath`` -- plus the data-parallel gradient exchange
+(``parallel.GradReducer`` on the optimiser's flat buffer, one process per GPU over RCCL).  No callbacks, loggers or
+dataloader management."""
+import os
+from types import SimpleNamespace
+
+
+class Trainer:
+    def __init__(self, max_steps, ckpt_dir=None, every_n_train_steps=500, process_group=None):
+        """``max_steps`` / ``every_n_train_steps``: yaml:178-180, 190 (``lightning.trainer.max_steps``,
+        ``modelcheckpoint.params.every_n_train_steps``), counted in optimiser steps (Lightning's ``global_step``)."""
+        self.max_steps = int(max_steps)
+        self.checkpoint_callback = SimpleNamespace(dirpath=ckpt_dir)
+        self.every_n_train_steps = every_n_train_steps
+        self.process_group = process_group
+        self.optimizer = self.scheduler = self.reducer = None
+        self.logged = []
+
+    def attach(self, model):
+        """``configure_optimizers()`` (Lightning's return shape) -> optimiser, scheduler, reducer on the flat gradient buffer."""
+        from .parallel import GradReducer
+        object.__setattr__(model, "trainer", self)
+        conf = model.configure_optimizers()[0]
+        self.optimizer = conf["optimizer"]
+        self.scheduler = conf["lr_scheduler"]["scheduler"]
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        self.reducer = GradReducer(params, process_group=self.process_group, flat=getattr(self.optimizer, "grad_buffer", None))
+        return self
+
+    def fit(self, model, batches):
+        """one epoch over ``batches`` (an iterable of batch dicts), stopping at ``max_steps`` optimiser steps."""
+        if self.optimizer is None:
+            self.attach(model)
+        last_saved = -1
+        for batch_idx, batch in enumerate(batches):
+            if model.global_step >= self.max_steps:
+                break
+            loss, _aux = model.training_step(batch, batch_idx)
+            self.logged.append(loss)
+            gs = model.global_step
+            if self.every_n_train_steps and gs > 0 and gs % self.every_n_train_steps == 0 and gs != last_saved:
+                self.save_checkpoint(model)
+                last_saved = gs
+        if self.reducer is not None:
+            self.reducer.wait()
+        return self.logged
+
+    def save_checkpoint(self, model):
+        ckpt = {"state_dict": {}, "global_step": model.global_step}
+        d = self.checkpoint_callback.dirpath
+        if d is not None:
+            os.makedirs(d, exist_ok=True)
+        model.on_save_checkpoint(ckpt)
+        return ckpt

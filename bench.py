@@ -77,7 +77,7 @@ def build_model(device, seed=0):
     from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     with torch.device(device):        # parameters are created (and default-initialised) directly in HBM
-        ld = LatentDiffusion(
+        ld = LatentDiffusion.hot_path(
             {"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": dict(synth.SD15_VAE_DD), "embed_dim": 4}},
             {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.SD15_UNET)})
     ld = ld.to(device)
@@ -153,6 +153,11 @@ def main():
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks here, one process per GPU (the reference's launcher does the
+        # same through Lightning, main.py:829 strategy="ddp").  This parent has made no HIP call and never will.
+        raise SystemExit(spawn_ranks(args.gpus))
+
     from adaprompt_amd import _lib, ops
     from adaprompt_amd.parallel import GradReducer, init_distributed
 
@@ -174,6 +179,8 @@ def main():
     from adaprompt_amd.ldm.util import prodigy_linear_schedule
     opt = Prodigy(params, lr=1.0, betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, weight_decay=0.0)
     reducer = GradReducer(params, flat=opt.grad_buffer)      # the exchange runs on the optimiser's flat buffer
+    allreduce_bytes = reducer.bytes_per_reduce if world > 1 else 0
+    dist_backend = dist.get_backend() if world > 1 else None
     sched = prodigy_linear_schedule(opt, max_steps=60000, warm_up_steps=500, scheduler_cycles=1)
     B = args.batch
     batches = [synthetic_batch(B, device, 1234 + rank * 100 + i) for i in range(2)]
@@ -610,7 +617,7 @@ def main():
                                    "gradient through the captured attnscore) + prompt-delta loss, "
                                    "hook stand-in with 149M trainable fp32 params, clip 0.5 + Prodigy step + LR schedule every 2nd micro-batch",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "grad_allreduce_bytes": reducer_bytes(world)},
+                       "grad_allreduce_bytes": allreduce_bytes, "dist_backend": dist_backend},
             "model_tflops_per_step": round(GFLOP_PER_IMAGE * B / 1e3, 2),
             "achieved_model_tflops_per_gpu": round(GFLOP_PER_IMAGE * B / 1e3 / (ms * 1e-3), 1),
             "final_loss": round(loss_val, 5),
@@ -630,6 +637,43 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """Start ``n`` copies of this script as child processes, rank r on GPU r (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their env, which is what torchrun would have set), forward rank 0's stdout, and return a non-zero exit code if any
+    rank fails.  The parent touches no GPU: children are started with ``subprocess`` (never ``exec``) before any HIP
+    call.  With fewer than ``n`` GPUs on the box (a rehearsal) the ranks share devices over gloo -- RCCL refuses two
+    ranks on one device -- and the line says so (``config.dist_backend``)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ndev = torch.cuda.device_count()            # counts devices without initialising the runtime on this image
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if ndev < n:
+            env.setdefault("ADAP_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    if ndev < n:
+        print(f"warning: --gpus {n} on a box with {ndev} GPU(s): ranks share devices, gradient exchange over gloo",
+              file=sys.stderr)
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad:                                 # a rank died: the others would wait in a collective for ever
+            rc = bad[0]
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
 
 
 def in_kernel_clock(device):
@@ -680,10 +724,6 @@ def pmc_traffic(kernel):
         if e:
             return e["traffic_bytes_per_launch"], os.path.relpath(path, here)
     return None, None
-
-
-def reducer_bytes(world):
-    return 149_000_000 // (16 * 77 * 768) * (16 * 77 * 768) * 4 if world > 1 else 0
 
 
 if __name__ == "__main__":

@@ -85,7 +85,7 @@ def test_checkpoint_api_roundtrip(tmp_path):
     sd["cond_stage_model.transformer.text_model.final_layer_norm.weight"] = torch.ones(4)     # an "unexpected" key
     ck = os.path.join(tmp_path, "m.ckpt")
     torch.save({"state_dict": sd, "global_step": 7}, ck)
-    ld = LatentDiffusion(*cfgs)
+    ld = LatentDiffusion.hot_path(*cfgs)
     missing, unexpected = ld.init_from_ckpt(ck)
     assert unexpected == ["cond_stage_model.transformer.text_model.final_layer_norm.weight"]
     buffers = {n for n, _ in ld.named_buffers()}
@@ -95,7 +95,7 @@ def test_checkpoint_api_roundtrip(tmp_path):
     from safetensors.torch import save_file
     st = os.path.join(tmp_path, "m.safetensors")
     save_file({k_: v.contiguous() for k_, v in sd.items()}, st)
-    ld2 = LatentDiffusion(*cfgs)
+    ld2 = LatentDiffusion.hot_path(*cfgs)
     ld2.init_from_ckpt(st, ignore_keys=["cond_stage_model"])
     assert torch.equal(ld2.state_dict()[k], sd[k])
     ld2.freeze_unet()
@@ -412,7 +412,10 @@ def test_training_step_auto_iteration_dispatch():
 
     class Stub:
         manual_accumulate_grad_batches, prompt_emb_delta_reg_weight, batch_idx = 2, 2e-4, 0
+        do_static_prompt_delta_reg = True
+        cond_fn = staticmethod(lambda batch: None)          # the context comes from a cond_fn: training_step draws ND itself
         draw_iteration_flags = LatentDiffusion.draw_iteration_flags
+        init_iteration_flags = LatentDiffusion.init_iteration_flags
         draw_num_denoising_steps = staticmethod(LatentDiffusion.draw_num_denoising_steps)
         manual_backward = staticmethod(lambda *a: None)
 
@@ -431,7 +434,9 @@ def test_training_step_auto_iteration_dispatch():
                                                                "max_num_denoising_steps": 5})
         kw = st.calls[-1]
         if kw.get("use_arc2face_as_target"):
-            assert kw["num_denoising_steps"] in (1, 3, 5) and "anneal_t" not in kw
+            # distillation iterations are normal-recon iterations: t is annealed too (reference ddpm.py:2851-2861)
+            assert kw["num_denoising_steps"] in (1, 3, 5) and kw["anneal_t"] is True
+            assert st.iter_flags["do_arc2face_distill"] and not st.iter_flags["do_static_prompt_delta_reg"]
             kinds.append(1)
         else:
             assert kw == {"anneal_t": True}

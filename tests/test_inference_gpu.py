@@ -52,7 +52,7 @@ def test_ddim_sampler_vs_oracle_and_decode_first_stage():
     from oracle import ldm_oracle as O
     ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL",
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL",
                           "params": {"ddconfig": vdd, "embed_dim": 4, "with_decoder": True}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
     usd = synth.synthetic_unet_state_dict(ucfg)

@@ -237,7 +237,7 @@ def test_training_step_matches_oracle():
     from oracle import ldm_oracle as O
     ucfg = dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
     usd = synth.synthetic_unet_state_dict(ucfg)
     vsd = synth.synthetic_vae_state_dict(vdd)
@@ -294,7 +294,7 @@ def test_recon_step_with_regularizers_matches_oracle():
     from oracle import regs_oracle as R
     ucfg = dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
                          fg_bg_xlayer_consist_loss_weight=2.0, prompt_emb_delta_reg_weight=3.0,
                          fg_bg_complementary_loss_weight=1.5)
@@ -414,7 +414,7 @@ def test_training_loop_prodigy_two_optimizer_steps_vs_oracle():
     hook = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
     hook.load_state_dict(hook_ref.state_dict())
     hook = hook.to(dev())
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
                          cond_fn=make_cond_fn(hook, capture=False))
     usd = synth.synthetic_unet_state_dict(ucfg)
@@ -484,7 +484,7 @@ def test_arc2face_distill_step_vs_oracle():
     from oracle import distill_oracle as D
     ucfg = dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
     usd = synth.synthetic_unet_state_dict(ucfg)
     ld.load_state_dict(usd, strict=False)
@@ -577,7 +577,7 @@ def test_guided_denoise_cfg_pixel_recon_vs_oracle():
     from oracle import ldm_oracle as O
     ucfg = dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
     usd = synth.synthetic_unet_state_dict(ucfg)
     ld.load_state_dict(usd, strict=False)
@@ -623,7 +623,7 @@ def test_distill_prefetcher_matches_inline_path():
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion, Arc2FaceWrapper
     ucfg = dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
-    ld = LatentDiffusion({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
     ld.load_state_dict({**synth.synthetic_unet_state_dict(ucfg), **synth.synthetic_vae_state_dict(vdd)}, strict=False)
     ld = ld.to(dev())

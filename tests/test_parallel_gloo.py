@@ -119,3 +119,75 @@ def test_grad_reducer_on_a_shared_flat_buffer_world2_gloo():
         assert p.exitcode == 0
     for rank, ok, pad0, pad1 in res:
         assert ok and pad0 == 0.0 and pad1 == 0.0, (rank, ok, pad0, pad1)
+
+
+def _worker_training_step(rank, world, port, q):
+    """the PRODUCT's ``LatentDiffusion.training_step`` under a reducer, two ranks: the all-reduce issued after micro-batch i
+    must have landed before micro-batch i+1's backward adds into the same flat buffer, and the step sees
+    mean_r(g_1) + mean_r(g_2).  The UNet itself needs the GPU, so ``shared_step`` is replaced by a small differentiable
+    model; everything else (the wait / backward / reduce / step / zero sequence) is the shipped code."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.parallel import GradReducer, init_distributed
+    init_distributed(backend="gloo")
+    torch.manual_seed(0)
+
+    class Toy(LatentDiffusion):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.lin = torch.nn.Linear(6, 3)
+            self.manual_accumulate_grad_batches, self.grad_clip, self.batch_idx = 2, 0.0, 0
+            self.cond_fn = None
+
+        def shared_step(self, batch, **kw):
+            out = self.lin(batch["x"])
+            return out.detach().sum(), torch.ones_like(out), out, {}
+
+    events = []
+
+    class Spy(GradReducer):
+        def reduce(self):
+            events.append("reduce")
+            super().reduce()
+
+        def wait(self):
+            events.append("wait:pending" if self.pending else "wait")
+            super().wait()
+
+    m = Toy()
+    params = list(m.lin.parameters())
+    red = Spy(params, bucket_bytes=32)
+    hooks = [p.register_hook(lambda g: events.append("backward") or g) for p in params[:1]]
+    opt = torch.optim.SGD(params, lr=0.5)
+    w0 = m.lin.weight.detach().clone()
+    xs = [torch.full((2, 6), float(rank + 1 + 3 * i)) for i in range(2)]
+    for i in range(2):
+        m.training_step({"x": xs[i]}, optimizer=opt, reducer=red)
+    # every backward is preceded by a wait, and the 2nd one found a pending exchange and awaited it
+    order_ok = all(events[j - 1].startswith("wait") for j, e in enumerate(events) if e == "backward") \
+        and "wait:pending" in events[events.index("reduce"):]
+    # expected update: -lr * (mean_r g_1 + mean_r g_2); d sum(lin(x)) / dW = ones(3,1) * sum_rows(x)
+    g = sum(torch.stack([torch.full((2, 6), float(r + 1 + 3 * i)).sum(0) for r in range(world)]).mean(0) for i in range(2))
+    want = w0 - 0.5 * g.expand(3, 6)
+    ok = torch.allclose(m.lin.weight.detach(), want, rtol=1e-6, atol=1e-6)
+    zeroed = float(red.flat.abs().sum()) == 0.0 and m.batch_idx == 2
+    for h in hooks:
+        h.remove()
+    q.put((rank, bool(order_ok), bool(ok), bool(zeroed), events))
+    dist.destroy_process_group()
+
+
+def test_training_step_waits_for_the_previous_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_training_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, order_ok, ok, zeroed, events in res:
+        assert order_ok and ok and zeroed, (rank, order_ok, ok, zeroed, events)
