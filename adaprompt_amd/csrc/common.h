@@ -78,11 +78,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+// sigmoid through v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division costs ~12 more VALU instructions per element, which is
+// what the HBM-bound norm / activation kernels were spending their issue slots on
+__device__ __forceinline__ float sigmoid_f(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
 
 // d silu(z) / dz
 __device__ __forceinline__ float dsilu_f(float z) {
-    float s = 1.0f / (1.0f + __expf(-z));
+    float s = sigmoid_f(z);
     return s * (1.0f + z * (1.0f - s));
 }
 

@@ -254,6 +254,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
     }
 }
 
+// single-launch path (defined below the two-pass kernels): returns 1 when it took the call
+static int gn_fused_fwd_try(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, float* y32, long ldy32,
+                            void* y16, long ldy16, float* mean, float* rstd, float* workspace, int* sync, int B, int HW, int C,
+                            float eps, int act, hipStream_t s);
+static int gn_fused_bwd_try(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx, const float* gamma,
+                            const float* beta, const float* mean, const float* rstd, float* dx32, long lddx32, int accumulate,
+                            void* dx16, long lddx16, const float* add_src, long ldadd, float* workspace, int* sync, int B, int HW,
+                            int C, int act, hipStream_t s);
+static void gn_note_two_pass();
+
 static void gn_chunks(int HW, int C, int* nchunks, int* rows_per_chunk) {
     long elems = (long)HW * C;
     int n = (int)(elems / 8192);
@@ -269,12 +279,14 @@ static void gn_chunks(int HW, int C, int* nchunks, int* rows_per_chunk) {
 extern "C" long adap_groupnorm_workspace_floats(int B, int HW, int C) {
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
-    return (long)B * n * GN_G * 2;
+    long two_pass = (long)B * n * GN_G * 2;
+    long fused = 512L * 64;                 // single-launch path: one 64-float record per workgroup, <= 512 workgroups
+    return two_pass > fused ? two_pass : fused;
 }
 
 extern "C" int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta,
                                   float* y32, long ldy32, void* y16, long ldy16,
-                                  float* mean, float* rstd, float* workspace,
+                                  float* mean, float* rstd, float* workspace, void* sync,
                                   int B, int HW, int C, float eps, int act, void* stream) {
     ADAP_REQUIRE(x && gamma && beta && mean && rstd && workspace && (y32 || y16), ADAP_ERR_SHAPE, "groupnorm_fwd: null pointer");
     ADAP_REQUIRE(x_dtype == 0 || x_dtype == 1, ADAP_ERR_UNSUPPORTED, "groupnorm_fwd: x_dtype %d", x_dtype);
@@ -286,6 +298,10 @@ extern "C" int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const fl
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
     hipStream_t s = (hipStream_t)stream;
+    if (sync && gn_fused_fwd_try(x, x_dtype, ldx, gamma, beta, y32, ldy32, y16, ldy16, mean, rstd, workspace, (int*)sync, B, HW, C,
+                                 eps, act, s))
+        return adap_check_launch("groupnorm_fwd (single launch)");
+    gn_note_two_pass();
     if (x_dtype == 1) {
         hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, rpc, workspace);
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, gamma, beta, workspace, n, eps, act,
@@ -483,7 +499,7 @@ extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const
                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
                                   const float* add_src, long ldadd,
-                                  float* workspace, int B, int HW, int C, int act, void* stream) {
+                                  float* workspace, void* sync, int B, int HW, int C, int act, void* stream) {
     ADAP_REQUIRE(dy && x && gamma && beta && mean && rstd && workspace && (dx32 || dx16), ADAP_ERR_SHAPE, "groupnorm_bwd: null pointer");
     ADAP_REQUIRE(C % GN_G == 0 && C % 8 == 0 && C <= 256 * 8 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_bwd: C=%d", C);
     ADAP_REQUIRE((dy_dtype == 0 || dy_dtype == 1) && (x_dtype == 0 || x_dtype == 1), ADAP_ERR_UNSUPPORTED, "groupnorm_bwd: dtype");
@@ -500,6 +516,10 @@ extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
     hipStream_t s = (hipStream_t)stream;
+    if (sync && gn_fused_bwd_try(dy, dy_dtype, lddy, x, x_dtype, ldx, gamma, beta, mean, rstd, dx32, lddx32, accumulate, dx16,
+                                 lddx16, add_src, ldadd, workspace, (int*)sync, B, HW, C, act, s))
+        return adap_check_launch("groupnorm_bwd (single launch)");
+    gn_note_two_pass();
 #define GN_BWD(XB, DYB) gn_bwd_launch<XB, DYB>(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx32, lddx32, accumulate, dx16, lddx16, \
                                                add_src, ldadd, \
                                               workspace, B, HW, C, act, n, rpc, s)
@@ -509,6 +529,473 @@ extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const
     else GN_BWD(false, false);
 #undef GN_BWD
     return adap_check_launch("groupnorm_bwd");
+}
+
+// =============================================================================================
+// Single-launch GroupNorm (forward and backward) for tensors whose slab per workgroup fits the register
+// file: the UNet's shapes at the training batch sizes (<= 64x64x960 at bs 4).
+//
+// The two-pass kernels above read x twice and pay two launches; on a 21 MB tensor each launch is
+// 6-17 us of mostly latency.  Here ONE grid of <= 256 workgroups (<= one per CU,
+// so all are resident) of 512 threads walks the tensor ONCE: a workgroup loads its slab of whole
+// pixel rows into registers (every load issued before the first use: ~10 x 16 B in flight per thread),
+// reduces it to 32 x 2 group partials through LDS in a fixed order, publishes the 256-byte record
+// write-through, meets the other workgroups of its SAMPLE at an arrival counter, reads the sample's
+// records back (fp64 finish, fixed order: bit-reproducible), and normalises / differentiates the
+// slab it still holds.  HBM traffic = the algorithmic bytes: x once, y once.
+//
+// Hand-off (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility",
+// the measured row "agent-scope atomic adds: one lane of each storing workgroup / a global_load_dword
+// sc1 poll of that counter / a workgroup barrier between that poll and EVERY load of the bytes"):
+// the record is two whole 128-byte lines written by ONE store instruction of wave 0
+// (relaxed agent-scope atomic stores = global_store_dword sc1), wave 0 drains (s_waitcnt vmcnt(0)),
+// lane 0 adds 1 to the sample's arrival counter and polls it with sc1 loads (bounded spin),
+// __syncthreads(), then every record is read with dword sc1 loads.  Counters are self-resetting: the
+// last workgroup of a sample to leave zeroes both, so the caller hands in a zero-initialised buffer
+// once (one per stream) and never memsets it again.  A spin that exceeds its bound sets the poison
+// word (sync[GN_SYNC_POISON]) and carries on with whatever it read: the grid always drains.
+// =============================================================================================
+#define GN_FT 512              // threads per workgroup
+#define GN_SYNC_POISON 4095    // index of the poison word in the caller's int[4096] sync buffer
+#define GN_SYNC_INTS 4096
+#define GN_SPIN_LIMIT (1u << 22)
+
+__device__ __forceinline__ void gn_slab_sync(int* sync, int b, int nslab) {
+    // wave 0 only enters with its record stores issued
+    if ((threadIdx.x >> 6) == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            int* arrive = sync + 2 * b;
+            __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nslab) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > GN_SPIN_LIMIT) {
+                    __hip_atomic_store(sync + GN_SYNC_POISON, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// after the workgroup has read every record it needs (and a barrier): the last leaver resets the sample's counters
+__device__ __forceinline__ void gn_slab_leave(int* sync, int b, int nslab) {
+    if (threadIdx.x == 0) {
+        int* depart = sync + 2 * b + 1;
+        int old = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nslab - 1) {
+            __hip_atomic_store(sync + 2 * b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// per-thread (group g0, group g0+1) partials of two statistics -> the 32 x 2 group sums of the workgroup, in thread
+// t < 64 (g = t & 31, stat = t >> 5).  red: float4[GN_FT] in LDS.  Fixed order: rows, then octs.
+__device__ __forceinline__ float gn_fused_block_reduce(float4* red, float a0, float b0, float a1, float b1, int Q, int rpp,
+                                                       int cpg, int tid) {
+    red[tid] = make_float4(a0, b0, a1, b1);
+    __syncthreads();
+    float acc = 0.f;
+    if (tid < 64) {
+        const int g = tid & 31, stat = tid >> 5;
+        const int q_lo = (g * cpg) >> 3, q_hi = ((g + 1) * cpg - 1) >> 3;
+        for (int q = q_lo; q <= q_hi; ++q) {
+            const int g0 = (8 * q) / cpg;          // first group the oct touches
+            const int comp = (g == g0 ? 0 : 2) + stat;
+            for (int r0 = 0; r0 < rpp; ++r0) {
+                const float4 v = red[r0 * Q + q];
+                acc += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
+            }
+        }
+    }
+    __syncthreads();
+    return acc;
+}
+
+// sum over the sample's slabs of record entry (g, stat) in fp64; 8 threads per group (tid >> 3 = g, tid < 256)
+__device__ __forceinline__ void gn_fused_finish(const float* partial, int b, int nslab, int tid, double* su, double* sq) {
+    const int g = (tid >> 3) & 31, part = tid & 7;
+    double a = 0.0, c2 = 0.0;
+    const float* rec = partial + (size_t)b * nslab * 64;
+    for (int c = part; c < nslab; c += 8) {
+        a += (double)__hip_atomic_load(rec + c * 64 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c2 += (double)__hip_atomic_load(rec + c * 64 + 32 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 8);
+        c2 += __shfl_down(c2, o, 8);
+    }
+    *su = a;
+    *sq = c2;
+}
+
+// ---- buffer addressing of a slab: one descriptor per tensor (base = the slab's first row: wave-uniform, SGPRs), ONE
+// per-thread byte offset (row r0, oct c0) and a SCALAR row step per pass -- the 64-bit address arithmetic per row and
+// tensor that plain pointers need would otherwise sit in registers next to the slab itself.  A pass whose row lies beyond
+// the slab (or a thread beyond the last whole row of a pass) gets an out-of-range offset: the load returns 0, the
+// store is dropped (hardware range check), no branch.
+typedef unsigned int gn_u32x4 __attribute__((ext_vector_type(4)));
+#define GN_OOB 0xC0000000u
+
+struct GnSlab {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;     // bytes, this thread's oct in pass 0 (GN_OOB for idle threads)
+    unsigned step;     // bytes per pass
+};
+
+__device__ __forceinline__ GnSlab gn_slab(const void* base, long ld, int esz, size_t first_row, int r0, int c0, int rpp,
+                                          bool live) {
+    GnSlab t;
+    t.rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + first_row * (size_t)ld * esz), 0, 0x80000000u, 0x00020000);
+    t.voff = live ? (unsigned)((r0 * ld + c0) * esz) : GN_OOB;
+    t.step = (unsigned)(rpp * ld * esz);
+    return t;
+}
+
+template <bool BF> struct GnOct;
+template <> struct GnOct<false> {
+    gn_u32x4 a, b;
+    __device__ __forceinline__ void load(const GnSlab& t, unsigned voff, int k) {
+        a = __builtin_amdgcn_raw_buffer_load_b128(t.rs, voff, k * t.step, 0);
+        b = __builtin_amdgcn_raw_buffer_load_b128(t.rs, voff + 16, k * t.step, 0);
+    }
+    // the compiler must not carry values DERIVED from these registers across the hand-off (it would keep xhat and dyh of
+    // every oct alive through the spin: twice the registers, spills): make them opaque at that point
+    __device__ __forceinline__ void opaque() {
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+    }
+    // (whole-vector bit casts: per-element `bit_cast(float, a[e])` makes hipcc 7.2 narrow the b128 load to ONE dword)
+    __device__ __forceinline__ void get(float* o) const {
+        const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+        o[0] = fa.x; o[1] = fa.y; o[2] = fa.z; o[3] = fa.w;
+        o[4] = fb.x; o[5] = fb.y; o[6] = fb.z; o[7] = fb.w;
+    }
+};
+template <> struct GnOct<true> {
+    gn_u32x4 a;
+    __device__ __forceinline__ void load(const GnSlab& t, unsigned voff, int k) {
+        a = __builtin_amdgcn_raw_buffer_load_b128(t.rs, voff, k * t.step, 0);
+    }
+    __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+    __device__ __forceinline__ void get(float* o) const {
+        uint4 v = make_uint4(a.x, a.y, a.z, a.w);
+        unpack_bf16x8(v, o);
+    }
+};
+
+__device__ __forceinline__ void gn_store_f32(const GnSlab& t, unsigned voff, int k, const float* o) {
+    const f32x4 fa = {o[0], o[1], o[2], o[3]}, fb = {o[4], o[5], o[6], o[7]};
+    const gn_u32x4 a = __builtin_bit_cast(gn_u32x4, fa), b = __builtin_bit_cast(gn_u32x4, fb);
+    __builtin_amdgcn_raw_buffer_store_b128(a, t.rs, voff, k * t.step, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(b, t.rs, voff + 16, k * t.step, 0);
+}
+
+__device__ __forceinline__ void gn_store_bf16(const GnSlab& t, unsigned voff, int k, const float* o) {
+    uint4 w = pack_bf16x8(o);
+    gn_u32x4 a = {w.x, w.y, w.z, w.w};
+    __builtin_amdgcn_raw_buffer_store_b128(a, t.rs, voff, k * t.step, 0);
+}
+
+__device__ __forceinline__ void gn_load_f32x8(const float* p, float* o) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+template <bool XB, int NO, bool ACT>
+__global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restrict__ x, long ldx, int HW, int C,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int rows_per_slab,
+                                                             float* __restrict__ y32, long ldy32, uint16_t* __restrict__ y16,
+                                                             long ldy16, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, float* partial, int* sync) {
+    __shared__ float4 red[GN_FT];
+    __shared__ float lmean[GN_G], lrstd[GN_G];
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x, nslab = gridDim.x, b = blockIdx.y;
+    const int Q = C >> 3, cpg = C / GN_G;
+    const int rpp = GN_FT / Q;
+    const int lir = tid % Q, r0 = tid / Q;
+    const bool live = r0 < rpp;
+    const int row_begin = slab * rows_per_slab;
+    const int nrows = min(HW, row_begin + rows_per_slab) - row_begin;
+    const size_t first = (size_t)b * HW + row_begin;
+    const int c0 = 8 * lir, g0 = min(c0 / cpg, GN_G - 1);
+    const int n0 = min(8, (g0 + 1) * cpg - c0);          // channels of this oct that belong to g0; the rest to g0 + 1
+    const GnSlab tx = gn_slab(x, ldx, XB ? 2 : 4, first, r0, c0, rpp, live);
+
+    GnOct<XB> xr[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) xr[k].load(tx, (r0 + k * rpp < nrows) ? tx.voff : GN_OOB, k);
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        float v[8];
+        xr[k].get(v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] += v[e];
+            ss[e] += v[e] * v[e];
+        }
+    }
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (e < n0) { a0 += s[e]; b0 += ss[e]; }
+        else { a1 += s[e]; b1 += ss[e]; }
+    }
+    const float mine = gn_fused_block_reduce(red, a0, b0, a1, b1, Q, rpp, cpg, tid);
+    if (tid < 64) __hip_atomic_store(partial + ((size_t)b * nslab + slab) * 64 + tid, mine, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    gn_slab_sync(sync, b, nslab);
+    if (tid < 256) {
+        double su, sq;
+        gn_fused_finish(partial, b, nslab, tid, &su, &sq);
+        if ((tid & 7) == 0) {
+            const int grp = tid >> 3;
+            double n = (double)cpg * HW;
+            double mean = su / n;
+            double var = sq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            lmean[grp] = (float)mean;
+            lrstd[grp] = rstd;
+            if (slab == 0) {
+                mean_out[b * GN_G + grp] = (float)mean;
+                rstd_out[b * GN_G + grp] = rstd;
+            }
+        }
+    }
+    __syncthreads();
+    gn_slab_leave(sync, b, nslab);
+    if (!live) return;
+    float sc[8], sh[8];
+    {
+        float ga[8], be[8];
+        gn_load_f32x8(gamma + c0, ga);
+        gn_load_f32x8(beta + c0, be);
+        const int g1 = min(g0 + 1, GN_G - 1);
+        const float rs0 = lrstd[g0], rs1 = lrstd[g1], mu0 = lmean[g0], mu1 = lmean[g1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = (e < n0 ? rs0 : rs1) * ga[e];
+            sc[e] = a;
+            sh[e] = be[e] - (e < n0 ? mu0 : mu1) * a;
+        }
+    }
+    const GnSlab t32 = gn_slab(y32, ldy32, 4, first, r0, c0, rpp, y32 != nullptr);
+    const GnSlab t16 = gn_slab(y16, ldy16, 2, first, r0, c0, rpp, y16 != nullptr);
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const bool ok = r0 + k * rpp < nrows;
+        float v[8], o[8];
+        xr[k].get(v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = v[e] * sc[e] + sh[e];
+            if (ACT) o[e] = silu_f(o[e]);
+        }
+        gn_store_f32(t32, ok ? t32.voff : GN_OOB, k, o);
+        gn_store_bf16(t16, ok ? t16.voff : GN_OOB, k, o);
+    }
+}
+
+template <bool XB, bool DYB, int NO, bool ACT>
+__global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restrict__ dy, long lddy, const void* __restrict__ x,
+                                                             long ldx, int HW, int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int rows_per_slab,
+                                                             float* __restrict__ dx32, long lddx32, int accumulate,
+                                                             uint16_t* __restrict__ dx16, long lddx16,
+                                                             const float* __restrict__ add_src, long ldadd, float* partial,
+                                                             int* sync) {
+    __shared__ float4 red[GN_FT];
+    __shared__ float lA[GN_G], lB[GN_G];
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x, nslab = gridDim.x, b = blockIdx.y;
+    const int Q = C >> 3, cpg = C / GN_G;
+    const int rpp = GN_FT / Q;
+    const int lir = tid % Q, r0 = tid / Q;
+    const bool live = r0 < rpp;
+    const int row_begin = slab * rows_per_slab;
+    const int nrows = min(HW, row_begin + rows_per_slab) - row_begin;
+    const size_t first = (size_t)b * HW + row_begin;
+    const int c0 = 8 * lir, g0 = min(c0 / cpg, GN_G - 1), g1 = min(g0 + 1, GN_G - 1);
+    const int n0 = min(8, (g0 + 1) * cpg - c0);
+    const GnSlab tx = gn_slab(x, ldx, XB ? 2 : 4, first, r0, c0, rpp, live);
+    const GnSlab td = gn_slab(dy, lddy, DYB ? 2 : 4, first, r0, c0, rpp, live);
+
+    GnOct<XB> xr[NO];
+    GnOct<DYB> dr[NO];
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const bool ok = r0 + k * rpp < nrows;
+        xr[k].load(tx, ok ? tx.voff : GN_OOB, k);
+        dr[k].load(td, ok ? td.voff : GN_OOB, k);
+    }
+    // per-channel constants: xhat = x * sc + sh, z = xhat * ga + be
+    float sc[8], sh[8], ga[8], be[8];
+    {
+        const int cc = live ? c0 : 0;
+        gn_load_f32x8(gamma + cc, ga);
+        gn_load_f32x8(beta + cc, be);
+        const float rs0 = rstd[b * GN_G + g0], rs1 = rstd[b * GN_G + g1];
+        const float mu0 = mean[b * GN_G + g0], mu1 = mean[b * GN_G + g1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = e < n0 ? rs0 : rs1;
+            sh[e] = -(e < n0 ? mu0 : mu1) * sc[e];
+        }
+    }
+    float sA[8], sB[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sA[e] = 0.f; sB[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        float xv[8], d[8];
+        xr[k].get(xv);
+        dr[k].get(d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = xv[e] * sc[e] + sh[e];
+            float dz = d[e];                                     // zero for the padding rows: they add nothing
+            if (ACT) dz *= dsilu_f(xh * ga[e] + be[e]);
+            const float dyh = dz * ga[e];
+            sA[e] += dyh;
+            sB[e] += dyh * xh;
+        }
+        __builtin_amdgcn_sched_barrier(0);       // one oct at a time: the unrolled chains would otherwise all be live at once
+    }
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (e < n0) { a0 += sA[e]; b0 += sB[e]; }
+        else { a1 += sA[e]; b1 += sB[e]; }
+    }
+    const float mine = gn_fused_block_reduce(red, a0, b0, a1, b1, Q, rpp, cpg, tid);
+    if (tid < 64) __hip_atomic_store(partial + ((size_t)b * nslab + slab) * 64 + tid, mine, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    gn_slab_sync(sync, b, nslab);
+    if (tid < 256) {
+        double a, bb;
+        gn_fused_finish(partial, b, nslab, tid, &a, &bb);
+        if ((tid & 7) == 0) {
+            double n = (double)cpg * HW;
+            lA[tid >> 3] = (float)(a / n);
+            lB[tid >> 3] = (float)(bb / n);
+        }
+    }
+    __syncthreads();
+    gn_slab_leave(sync, b, nslab);
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        xr[k].opaque();
+        dr[k].opaque();
+    }
+    const float mA0 = lA[g0], mA1 = lA[g1], mB0 = lB[g0], mB1 = lB[g1];
+    const GnSlab t32 = gn_slab(dx32, lddx32, 4, first, r0, c0, rpp, dx32 != nullptr);
+    const GnSlab t16 = gn_slab(dx16, lddx16, 2, first, r0, c0, rpp, dx16 != nullptr);
+    const GnSlab tad = gn_slab(add_src, ldadd, 4, first, r0, c0, rpp, dx32 != nullptr && accumulate);
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        const bool ok = r0 + k * rpp < nrows;
+        float xv[8], d[8], o[8], ac[8];
+        GnOct<false> acr;
+        acr.load(tad, ok ? tad.voff : GN_OOB, k);                // zeros when there is nothing to add
+        xr[k].get(xv);
+        dr[k].get(d);
+        acr.get(ac);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = xv[e] * sc[e] + sh[e];
+            float dz = d[e];
+            if (ACT) dz *= dsilu_f(xh * ga[e] + be[e]);
+            const float dyh = dz * ga[e];
+            o[e] = sc[e] * (dyh - (e < n0 ? mA0 : mA1) - xh * (e < n0 ? mB0 : mB1)) + ac[e];
+        }
+        gn_store_f32(t32, ok ? t32.voff : GN_OOB, k, o);
+        gn_store_bf16(t16, ok ? t16.voff : GN_OOB, k, o);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// geometry of the single-launch path: slabs per sample so that B * nslab <= the CU count; 0 octs = not eligible
+static int g_gn_cus = 0;
+static int g_gn_last_variant = 0;          // 0 = two-pass, N > 0 = single launch with N octs per thread
+static int gn_fused_geom(int B, int HW, int C, int max_octs, int* nslab, int* rows_per_slab) {
+    if (getenv("ADAP_GN_TWO_PASS")) return 0;
+    if (g_gn_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 0;
+        g_gn_cus = n > 0 ? n : -1;
+    }
+    const int Q = C >> 3;
+    if (g_gn_cus <= 0 || Q > GN_FT || B > g_gn_cus || 2 * B + 2 > GN_SYNC_POISON) return 0;
+    const int rpp = GN_FT / Q;
+    int ns = g_gn_cus / B;
+    if (ns > HW) ns = HW;
+    int rps = (HW + ns - 1) / ns;
+    rps = (rps + rpp - 1) / rpp * rpp;                 // whole passes: no half-empty last pass inside a slab
+    ns = (HW + rps - 1) / rps;
+    const int octs = rps / rpp;
+    if (octs > max_octs) return 0;
+    if ((long)rps * C * 4 >= (1L << 30)) return 0;     // 32-bit byte offsets inside a slab
+    *nslab = ns;
+    *rows_per_slab = rps;
+    return octs;
+}
+
+extern "C" int adap_groupnorm_last_variant(void) { return g_gn_last_variant; }
+extern "C" long adap_groupnorm_sync_ints(void) { return GN_SYNC_INTS; }
+
+static void gn_note_two_pass() { g_gn_last_variant = 0; }
+
+static int gn_fused_fwd_try(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, float* y32, long ldy32,
+                            void* y16, long ldy16, float* mean, float* rstd, float* workspace, int* sync, int B, int HW, int C,
+                            float eps, int act, hipStream_t s) {
+    int nslab, rps;
+    const int octs = gn_fused_geom(B, HW, C, 16, &nslab, &rps);
+    if (!octs) return 0;
+#define GN_FF(XB, NO, ACT) hipLaunchKernelGGL((gn_fused_fwd_kernel<XB, NO, ACT>), dim3(nslab, B), dim3(GN_FT), 0, s, x, ldx, HW, C, \
+                                              gamma, beta, eps, rps, y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd, workspace, sync)
+#define GN_FF2(XB, ACT) do { if (octs <= 6) GN_FF(XB, 6, ACT); else if (octs <= 12) GN_FF(XB, 12, ACT); else GN_FF(XB, 16, ACT); } while (0)
+    if (x_dtype == 1) { if (act) GN_FF2(true, true); else GN_FF2(true, false); }
+    else { if (act) GN_FF2(false, true); else GN_FF2(false, false); }
+#undef GN_FF2
+#undef GN_FF
+    g_gn_last_variant = octs;
+    return 1;
+}
+
+static int gn_fused_bwd_try(const void* dy, int dy_dtype, long lddy, const void* x, int x_dtype, long ldx, const float* gamma,
+                            const float* beta, const float* mean, const float* rstd, float* dx32, long lddx32, int accumulate,
+                            void* dx16, long lddx16, const float* add_src, long ldadd, float* workspace, int* sync, int B, int HW,
+                            int C, int act, hipStream_t s) {
+    int nslab, rps;
+    const int octs = gn_fused_geom(B, HW, C, 8, &nslab, &rps);
+    if (!octs) return 0;
+#define GN_FB(XB, DYB, NO, ACT) hipLaunchKernelGGL((gn_fused_bwd_kernel<XB, DYB, NO, ACT>), dim3(nslab, B), dim3(GN_FT), 0, s, dy, \
+                                                   lddy, x, ldx, HW, C, gamma, beta, mean, rstd, rps, dx32, lddx32, accumulate, \
+                                                   (uint16_t*)dx16, lddx16, add_src, ldadd, workspace, sync)
+// (12 rows of f32 x + dy per thread do not fit 256 registers next to the per-channel constants: such shapes -- 64x64x640 at
+// bs 4 -- take the two-pass path in the backward)
+#define GN_FB2(XB, DYB) do { if (act) { if (octs <= 4) GN_FB(XB, DYB, 4, true); else GN_FB(XB, DYB, 8, true); }      \
+                             else { if (octs <= 4) GN_FB(XB, DYB, 4, false); else GN_FB(XB, DYB, 8, false); } } while (0)
+    if (x_dtype == 1 && dy_dtype == 1) GN_FB2(true, true);
+    else if (x_dtype == 1) GN_FB2(true, false);
+    else if (dy_dtype == 1) GN_FB2(false, true);
+    else GN_FB2(false, false);
+#undef GN_FB2
+#undef GN_FB
+    g_gn_last_variant = octs;
+    return 1;
 }
 
 // ---------------------------------------------------------------------------------------------

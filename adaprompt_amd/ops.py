@@ -227,6 +227,24 @@ def batched_matmul_nt(a, b, out_dtype=F32, alpha=1.0):
 # norms
 # --------------------------------------------------------------------------------------------
 
+_GN_SYNC = {}
+
+
+def gn_sync_buffer(device):
+    """the zero-initialised arrival-counter buffer of the single-launch GroupNorm kernels, one per (device, stream): kernels
+    of one stream run in order and the counters reset themselves, so the buffer is allocated and zeroed once."""
+    key = (device.index, _stream())
+    buf = _GN_SYNC.get(key)
+    if buf is None:
+        buf = _GN_SYNC[key] = torch.zeros(_lib.call_long("adap_groupnorm_sync_ints"), device=device, dtype=torch.int32)
+    return buf
+
+
+def gn_sync_poisoned():
+    """True if a single-launch GroupNorm ever gave up waiting for its sample's other workgroups (tests assert it is False)."""
+    return any(int(b[-1]) != 0 for b in _GN_SYNC.values())
+
+
 def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     """x f32 / bf16 [B, ..., C] pixel-major -> (y32, y16, mean[B,32], rstd[B,32])"""
     B, C = x.shape[0], x.shape[-1]
@@ -239,7 +257,8 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_groupnorm_fwd", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
-              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), B, HW, C, float(eps), int(act), _stream())
+              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), gn_sync_buffer(x.device).data_ptr(), B, HW, C, float(eps),
+              int(act), _stream())
     if e0 is not None:
         # algorithmic bytes: read x once (4 B) + write y (2 B bf16 / 4 B f32) per element
         TIMER.stop("groupnorm_fwd", float(x.numel()) * (x.element_size() + (4 if out_f32 else 0) + (2 if out_bf16 else 0)), e0)
@@ -268,8 +287,8 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=Fa
     lddx32 = _rows_ld(dx32)[1] if dx32 is not None else 0
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     _lib.call("adap_groupnorm_bwd", dy.data_ptr(), _dt(dy), lddy, x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
-              mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, add_ptr, ldadd, ws.data_ptr(), B, HW, C,
-              int(act), _stream())
+              mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, add_ptr, ldadd, ws.data_ptr(),
+              gn_sync_buffer(x.device).data_ptr(), B, HW, C, int(act), _stream())
     return dx32, dx16
 
 

@@ -90,11 +90,21 @@ int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O, int I, int
  * model.py:39-40 (+ nonlinearity model.py:34-36).  x [B][HW][C] f32 (residual stream) or bf16 (block-internal
  * tensors), C % 32 == 0; statistics in fp32/fp64; mean/rstd [B][32] are saved for
  * the backward; workspace holds adap_groupnorm_workspace_floats(B,HW,C) floats.  act: 0 none, 1 SiLU.
+ *
+ * sync: NULL, or a device buffer of adap_groupnorm_sync_ints() int32 that the caller zero-initialised ONCE and then
+ * hands to every call issued on the same stream (one buffer per stream).  With it, tensors whose per-workgroup slab
+ * fits the register file (every UNet shape at the training batch sizes) take a SINGLE launch that reads x once: the
+ * workgroups of a sample meet at a self-resetting arrival counter in `sync` between the statistics and the
+ * normalisation (norms.hip).  The last int is a poison word, set if a bounded spin ever gave up (never, unless more
+ * spinning kernels are in flight than the chip can hold); adap_groupnorm_last_variant(): 0 = two launches, N = single
+ * launch with N pixel rows per thread.
  */
 long adap_groupnorm_workspace_floats(int B, int HW, int C);
+long adap_groupnorm_sync_ints(void);
+int adap_groupnorm_last_variant(void);
 int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta,
                        float* y32, long ldy32, void* y16, long ldy16,
-                       float* mean, float* rstd, float* workspace,
+                       float* mean, float* rstd, float* workspace, void* sync,
                        int B, int HW, int C, float eps, int act, void* stream);
 /* dx (f32 and/or bf16) from dy (f32 or bf16).  accumulate: dx32 = dx + add_src (the residual-stream gradient
  * coming down the skip path); add_src NULL = dx32 itself (in place), otherwise any f32 tensor of the same shape,
@@ -103,7 +113,7 @@ int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const void* x, i
                        const float* gamma, const float* beta, const float* mean, const float* rstd,
                        float* dx32, long lddx32, int accumulate, void* dx16, long lddx16,
                        const float* add_src, long ldadd,
-                       float* workspace, int B, int HW, int C, int act, void* stream);
+                       float* workspace, void* sync, int B, int HW, int C, int act, void* stream);
 
 /* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3, attention.py:267-269,275-285.
  * bwd: dx (f32, optionally accumulated into) and optionally dx16, a bf16 copy of the final dx. */

@@ -157,6 +157,91 @@ def test_linear_and_batched_matmul():
 # ---------------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------------
+def _gn_variant():
+    from adaprompt_amd import _lib
+    return _lib.call_long("adap_groupnorm_last_variant")
+
+
+@pytest.mark.parametrize("B,C,H,rows_fwd,rows_bwd", [
+    (4, 320, 64, 6, 6),        # the 64x64 level of the UNet at the training batch size
+    (4, 640, 64, 11, 0),       # fwd: 12-row variant; bwd: two-pass (12 rows of x + dy do not fit the register file)
+    (4, 960, 64, 16, 0),
+    (4, 1920, 32, 8, 8),
+    (4, 1280, 16, 2, 2),
+    (4, 2560, 8, 1, 1),
+    (1, 320, 64, 2, 2),        # one instance (the distillation mix): 171 slabs of 24 rows
+    (7, 640, 32, 5, 5),        # the student's batched passes
+    (3, 352, 24, 4, 4),        # odd sizes: 11 channels per group, 576 pixels, ragged last slab
+    (16, 320, 64, 0, 0),       # too large for the register-resident path: two-pass
+])
+def test_groupnorm_single_launch_path(B, C, H, rows_fwd, rows_bwd):
+    """the single-launch GroupNorm (one read of x, workgroups of a sample meeting at an arrival counter) against the
+    two-pass kernels on the same inputs -- same fixed-order fp64 finish, so results agree to f32 round-off -- and against
+    torch in f64; which path ran is read back from the library.  Repeated launches reuse the self-resetting counters."""
+    import os
+    x = torch.randn(B, H, H, C, generator=torch.Generator().manual_seed(1)) * 1.5 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    gy = torch.randn(B, H, H, C, generator=torch.Generator().manual_seed(4))
+    addend = torch.randn(B, H, H, C, generator=torch.Generator().manual_seed(5))
+    xd, gyd, ad = x.to(dev()), gy.to(dev()), addend.to(dev())
+    ref_in = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    for act, eps in ((1, 1e-5), (0, 1e-6)):
+        ref = F.group_norm(ref_in, 32, gamma.double(), beta.double(), eps)
+        if act:
+            ref = F.silu(ref)
+        (gref,) = torch.autograd.grad(ref, ref_in, gy.double().permute(0, 3, 1, 2))
+        ref_nhwc, gref_nhwc = ref.detach().permute(0, 2, 3, 1), gref.permute(0, 2, 3, 1)
+        for xdt, gdt in ((torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)):
+            xi, gi = xd.to(xdt), gyd.to(gdt)
+            outs = {}
+            for mode in ("single", "two_pass"):
+                if mode == "two_pass":
+                    os.environ["ADAP_GN_TWO_PASS"] = "1"
+                try:
+                    for rep in range(3):                                    # back-to-back launches: counters must reset
+                        y32, y16, mean, rstd = ops.groupnorm_fwd(xi, gamma.to(dev()), beta.to(dev()), eps, act, out_f32=True,
+                                                                 out_bf16=True)
+                    vf = _gn_variant()
+                    dx32, dx16 = ops.groupnorm_bwd(gi, xi, gamma.to(dev()), beta.to(dev()), mean, rstd, act, out_bf16=True,
+                                                   add_from=ad)
+                    vb = _gn_variant()
+                    _, dx16_only = ops.groupnorm_bwd(gi, xi, gamma.to(dev()), beta.to(dev()), mean, rstd, act, out_f32=False,
+                                                     out_bf16=True)
+                finally:
+                    os.environ.pop("ADAP_GN_TWO_PASS", None)
+                assert (vf, vb) == ((rows_fwd, rows_bwd) if mode == "single" else (0, 0)), (mode, vf, vb)
+                outs[mode] = (y32, y16, mean, rstd, dx32, dx16, dx16_only)
+            s, t = outs["single"], outs["two_pass"]
+            assert rel(s[2], t[2]) < 1e-6 and rel(s[3], t[3]) < 1e-6            # mean / rstd: same partial order per slab? no -- same math
+            assert rel(s[0], t[0]) < 2e-6 and rel(s[4], t[4]) < 2e-5
+            assert rel(s[1].float(), t[1].float()) < 2e-3 and rel(s[5].float(), t[5].float()) < 2e-3
+            if xdt == torch.float32 and gdt == torch.float32:
+                assert rel(s[0].cpu(), ref_nhwc) < 1e-5
+                assert rel((s[4] - ad).cpu(), gref_nhwc) < 3e-5
+            assert rel(s[6].float(), (s[4] - ad)) < 5e-3
+    assert not ops.gn_sync_poisoned()
+
+
+def test_groupnorm_single_launch_on_two_streams():
+    """the VAE prefetch stream and the main stream both issue single-launch GroupNorms: each stream has its own arrival
+    counters, kernels of both are in flight together, results stay exact."""
+    B, C, H = 4, 320, 64
+    g, b = (1 + 0.1 * rnd(C, seed=2)).to(dev()), (0.1 * rnd(C, seed=3)).to(dev())
+    xs = [torch.randn(B, H, H, C, device=dev(), generator=torch.Generator(device=dev()).manual_seed(i)) for i in range(2)]
+    want = [ops.groupnorm_fwd(x, g, b, 1e-5, 1, out_f32=True)[0].clone() for x in xs]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    got = [[], []]
+    for it in range(20):
+        with torch.cuda.stream(side):
+            got[1].append(ops.groupnorm_fwd(xs[1], g, b, 1e-5, 1, out_f32=True)[0])
+        got[0].append(ops.groupnorm_fwd(xs[0], g, b, 1e-5, 1, out_f32=True)[0])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for y in got[i]:
+            assert torch.equal(y, want[i])
+    assert not ops.gn_sync_poisoned()
+
 @pytest.mark.parametrize("B,C,H,eps,act", [(2, 320, 16, 1e-5, 1), (2, 1920, 8, 1e-5, 1), (1, 2560, 8, 1e-5, 1),
                                            (2, 640, 8, 1e-6, 0), (2, 128, 40, 1e-6, 1), (2, 32, 8, 1e-5, 1),
                                            (4, 960, 32, 1e-5, 1)])

@@ -645,34 +645,44 @@ def test_distill_prefetcher_matches_inline_path():
         return (synth.synthetic_input("pf.pn", (B, 4, 64, 64)).to(dev()), torch.tensor([300, 720, 5, 999], device=dev()),
                 synth.synthetic_input("pf.noise", (B, 4, 64, 64)).to(dev()))
 
-    # inline
-    torch.manual_seed(11)
-    pn, t, noise = inputs()
-    c1 = ctx.to(dev()).clone().requires_grad_(True)
-    loss1, g1, o1, aux1 = ld.shared_step(batch, t=t, noise=noise, post_noise=pn, cond=(c1, None, extra),
-                                         num_denoising_steps=nd, use_arc2face_as_target=True)
-    torch.autograd.backward(o1, g1)
-    # prefetched
-    torch.manual_seed(11)
-    pf = ld.make_distill_prefetcher()
-    pn, t, noise = inputs()
-    pf.submit(batch, pn, t, noise, nd)
-    del pn, t, noise
-    junk = [torch.full((B, 4, 64, 64), float("nan"), device=dev()) for _ in range(8)]      # reuse freed blocks, if any
-    junk.append(torch.full((B,), 123456789, device=dev(), dtype=torch.long))
-    x_start, t2, noise2, teacher_out, hb = pf.get()
-    assert hb == 2
-    b2 = {k: v[:hb] for k, v in batch.items()}
-    c2 = ctx.to(dev()).clone().requires_grad_(True)
-    loss2, g2, o2, aux2 = ld.shared_step(b2, t=t2, noise=noise2, x_start=x_start, cond=(c2, None, extra),
-                                         num_denoising_steps=nd, use_arc2face_as_target=True,
-                                         trim_to_half_batch=False, teacher_out=teacher_out)
-    torch.autograd.backward(o2, g2)
-    del junk
-    for a, b in zip(aux1["teacher"][3], aux2["teacher"][3]):
-        assert torch.equal(a, b)
-    assert torch.equal(loss1, loss2)
-    assert torch.equal(c1.grad, c2.grad)
+    # with and without the recon iteration's timestep annealing (applied before the multi-step shift on both paths,
+    # reference ddpm.py:2851-2861; device tensors draw it from torch's generator, so the seed pins it)
+    for anneal in (False, True):
+        ld.training_percent = 0.3
+        # inline
+        import random
+        torch.manual_seed(11)
+        random.seed(2)                  # the keep / redraw decision of the annealing is one random.random() (2 -> redraw)
+        pn, t, noise = inputs()
+        c1 = ctx.to(dev()).clone().requires_grad_(True)
+        loss1, g1, o1, aux1 = ld.shared_step(batch, t=t, noise=noise, post_noise=pn, cond=(c1, None, extra),
+                                             num_denoising_steps=nd, use_arc2face_as_target=True, anneal_t=anneal)
+        torch.autograd.backward(o1, g1)
+        # prefetched
+        torch.manual_seed(11)
+        random.seed(2)
+        pf = ld.make_distill_prefetcher()
+        pn, t, noise = inputs()
+        pf.submit(batch, pn, t, noise, nd, anneal_t=anneal)
+        del pn, t, noise
+        junk = [torch.full((B, 4, 64, 64), float("nan"), device=dev()) for _ in range(8)]      # reuse freed blocks, if any
+        junk.append(torch.full((B,), 123456789, device=dev(), dtype=torch.long))
+        x_start, t2, noise2, teacher_out, hb = pf.get()
+        assert hb == 2
+        b2 = {k: v[:hb] for k, v in batch.items()}
+        c2 = ctx.to(dev()).clone().requires_grad_(True)
+        loss2, g2, o2, aux2 = ld.shared_step(b2, t=t2, noise=noise2, x_start=x_start, cond=(c2, None, extra),
+                                             num_denoising_steps=nd, use_arc2face_as_target=True,
+                                             trim_to_half_batch=False, teacher_out=teacher_out, anneal_t=anneal)
+        torch.autograd.backward(o2, g2)
+        del junk
+        for a, b in zip(aux1["teacher"][3], aux2["teacher"][3]):
+            assert torch.equal(a, b), anneal
+        assert torch.equal(loss1, loss2)
+        assert torch.equal(c1.grad, c2.grad)
+        if anneal:          # annealing only ever raises t (ratio in [1, 1.3]) before the shift
+            shifted_plain = ld.shift_t_for_multistep(inputs()[1][:hb], nd)
+            assert bool((aux2["teacher"][3][0] >= shifted_plain).all())
 
 
 def test_cpu_tensor_fails_loudly():
