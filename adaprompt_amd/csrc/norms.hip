@@ -544,93 +544,125 @@ extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const
 // records back (fp64 finish, fixed order: bit-reproducible), and normalises / differentiates the
 // slab it still holds.  HBM traffic = the algorithmic bytes: x once, y once.
 //
-// Hand-off (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility",
-// the measured row "agent-scope atomic adds: one lane of each storing workgroup / a global_load_dword
-// sc1 poll of that counter / a workgroup barrier between that poll and EVERY load of the bytes"):
-// the record is two whole 128-byte lines written by ONE store instruction of wave 0
-// (relaxed agent-scope atomic stores = global_store_dword sc1), wave 0 drains (s_waitcnt vmcnt(0)),
-// lane 0 adds 1 to the sample's arrival counter and polls it with sc1 loads (bounded spin),
-// __syncthreads(), then every record is read with dword sc1 loads.  Counters are self-resetting: the
-// last workgroup of a sample to leave zeroes both, so the caller hands in a zero-initialised buffer
-// once (one per stream) and never memsets it again.  A spin that exceeds its bound sets the poison
-// word (sync[GN_SYNC_POISON]) and carries on with whatever it read: the grid always drains.
+// Hand-off (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md
+// Guideline 16, form R2 "the data IS the flag"): a workgroup's record is 64 granules of 8 bytes {value, tag = the launch's
+// epoch}, each written by ONE relaxed agent-scope atomic store (global_store_dwordx2 sc1, write-through) of wave 0;
+// consumers re-read the granules they need with 8-byte sc1 loads until every tag is this launch's -- no drain, no flag,
+// no arrival counter on the critical path (the first version had all three: ~4 us more per launch).  Records and epoch
+// live in a buffer the caller zero-initialises ONCE per stream: tags only ever grow, so a stale record can never match.
+// The epoch word is advanced by the last workgroup of the launch to finish its sweep (a departure counter, off the
+// critical path); every workgroup has read the epoch by then, because a sweep completes only after all workgroups of
+// its sample have published.  A sweep that exceeds its bound sets the poison word and carries on with what it read: the
+// grid always drains.
 // =============================================================================================
 #define GN_FT 512              // threads per workgroup
-#define GN_SYNC_POISON 4095    // index of the poison word in the caller's int[4096] sync buffer
-#define GN_SYNC_INTS 4096
-#define GN_SPIN_LIMIT (1u << 22)
+// the caller's persistent int32 buffer: [0] launch epoch, [1] poison, [2] departures, [64 ...) the records:
+// GN_MAX_WGS x 64 granules of 8 bytes {value bits, tag}
+#define GN_SYNC_EPOCH 0
+#define GN_SYNC_POISON 1
+#define GN_SYNC_DEPART 2
+#define GN_SYNC_HDR 64
+#define GN_MAX_WGS 512
+#define GN_SYNC_INTS (GN_SYNC_HDR + GN_MAX_WGS * 64 * 2)
+#define GN_SPIN_LIMIT (1u << 20)
 
-__device__ __forceinline__ void gn_slab_sync(int* sync, int b, int nslab) {
-    // wave 0 only enters with its record stores issued
-    if ((threadIdx.x >> 6) == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) {
-            int* arrive = sync + 2 * b;
-            __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nslab) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > GN_SPIN_LIMIT) {
-                    __hip_atomic_store(sync + GN_SYNC_POISON, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+typedef unsigned long long gn_u64;
+
+// publish this workgroup's 64 group partials: entry t (thread t < 64, one wave, one 512-byte store instruction) as the
+// 8-byte granule {tag = epoch, value}: the data IS the flag -- no drain, no flag store, no arrival counter
+__device__ __forceinline__ void gn_publish(int* sync, int wg, int tid, float v, unsigned tag) {
+    if (tid < 64) {
+        gn_u64* g = (gn_u64*)(sync + GN_SYNC_HDR) + (size_t)wg * 64 + tid;
+        __hip_atomic_store(g, ((gn_u64)tag << 32) | (gn_u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Sum over the sample's slabs of every record entry, in fp64, fixed order.  Thread t sweeps entry (t & 63) of the records
+// t >> 6, (t >> 6) + 8, ...: all of a thread's 8-byte sc1 loads are issued together and re-issued until every tag is this
+// launch's (bounded: a give-up sets the poison word and carries on, so the grid always drains); wave w folds its records
+// in order, then thread t < 64 folds the 8 waves in order.  Returns entry t's total in threads t < 64.
+__device__ __forceinline__ double gn_sweep(int* sync, int first_wg, int nslab, int tid, unsigned tag, double* lds8x64) {
+    const int e = tid & 63, w = tid >> 6;
+    const gn_u64* rec = (const gn_u64*)(sync + GN_SYNC_HDR) + (size_t)first_wg * 64 + e;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int c0 = w; c0 < nslab; c0 += 64) {
+        float v[8];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 8 * j;
+                if (c < nslab) {
+                    const gn_u64 x = __hip_atomic_load(rec + (size_t)c * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[j] = __builtin_bit_cast(float, (unsigned)x);
+                    ok &= (unsigned)(x >> 32) == tag;
+                } else {
+                    v[j] = 0.f;
                 }
             }
+            if (__all(ok)) break;
+            if (++spins > GN_SPIN_LIMIT) {
+                if (e == 0) __hip_atomic_store(sync + GN_SYNC_POISON, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (double)v[j];
     }
+    lds8x64[w * 64 + e] = acc;
     __syncthreads();
+    double tot = 0.0;
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += lds8x64[k * 64 + tid];
+    }
+    return tot;
 }
 
-// after the workgroup has read every record it needs (and a barrier): the last leaver resets the sample's counters
-__device__ __forceinline__ void gn_slab_leave(int* sync, int b, int nslab) {
-    if (threadIdx.x == 0) {
-        int* depart = sync + 2 * b + 1;
-        int old = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == nslab - 1) {
-            __hip_atomic_store(sync + 2 * b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+// every workgroup, once its sweep is done (issued early, the returned count is only looked at when the kernel ends):
+// the last one of the LAUNCH to leave resets the counter and opens the next epoch.  All workgroups have read the epoch
+// by then: a sweep only completes after every workgroup of its sample has published, and the count after every sample.
+__device__ __forceinline__ int gn_depart(int* sync) {
+    return __hip_atomic_fetch_add(sync + GN_SYNC_DEPART, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gn_close(int* sync, int departed_before, int total_wgs) {
+    if (departed_before == total_wgs - 1) {
+        __hip_atomic_store(sync + GN_SYNC_DEPART, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sync + GN_SYNC_EPOCH, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// per-thread (group g0, group g0+1) partials of two statistics -> the 32 x 2 group sums of the workgroup, in thread
-// t < 64 (g = t & 31, stat = t >> 5).  red: float4[GN_FT] in LDS.  Fixed order: rows, then octs.
-__device__ __forceinline__ float gn_fused_block_reduce(float4* red, float a0, float b0, float a1, float b1, int Q, int rpp,
-                                                       int cpg, int tid) {
+// per-thread (group g0, group g0+1) partials of two statistics -> the 32 x 2 group sums of the workgroup, returned in
+// thread t < 64 (g = t & 31, stat = t >> 5).  red: float4[GN_FT] in LDS.  8 threads per output (o = tid >> 3): thread p of
+// them adds the contributions p, p + 8, ... (rows outer, octs inner) and a fixed 8-lane tree folds them: same order on
+// every launch (bit-reproducible), ~5 LDS reads deep instead of ~40.
+__device__ __forceinline__ float gn_fused_block_reduce(float4* red, float* out64, float a0, float b0, float a1, float b1, int Q,
+                                                       int rpp, int cpg, int tid) {
     red[tid] = make_float4(a0, b0, a1, b1);
     __syncthreads();
-    float acc = 0.f;
-    if (tid < 64) {
-        const int g = tid & 31, stat = tid >> 5;
+    {
+        const int o = tid >> 3, p = tid & 7;
+        const int g = o & 31, stat = o >> 5;
         const int q_lo = (g * cpg) >> 3, q_hi = ((g + 1) * cpg - 1) >> 3;
-        for (int q = q_lo; q <= q_hi; ++q) {
+        const int nq = q_hi - q_lo + 1, n = nq * rpp;
+        float acc = 0.f;
+        for (int i = p; i < n; i += 8) {
+            const int r0 = i / nq, q = q_lo + (i - r0 * nq);
             const int g0 = (8 * q) / cpg;          // first group the oct touches
+            const float4 v = red[r0 * Q + q];
             const int comp = (g == g0 ? 0 : 2) + stat;
-            for (int r0 = 0; r0 < rpp; ++r0) {
-                const float4 v = red[r0 * Q + q];
-                acc += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
-            }
+            acc += comp == 0 ? v.x : comp == 1 ? v.y : comp == 2 ? v.z : v.w;
         }
+#pragma unroll
+        for (int w = 4; w > 0; w >>= 1) acc += __shfl_down(acc, w, 8);
+        if (p == 0) out64[o] = acc;
     }
     __syncthreads();
-    return acc;
-}
-
-// sum over the sample's slabs of record entry (g, stat) in fp64; 8 threads per group (tid >> 3 = g, tid < 256)
-__device__ __forceinline__ void gn_fused_finish(const float* partial, int b, int nslab, int tid, double* su, double* sq) {
-    const int g = (tid >> 3) & 31, part = tid & 7;
-    double a = 0.0, c2 = 0.0;
-    const float* rec = partial + (size_t)b * nslab * 64;
-    for (int c = part; c < nslab; c += 8) {
-        a += (double)__hip_atomic_load(rec + c * 64 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c2 += (double)__hip_atomic_load(rec + c * 64 + 32 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-        a += __shfl_down(a, o, 8);
-        c2 += __shfl_down(c2, o, 8);
-    }
-    *su = a;
-    *sq = c2;
+    return tid < 64 ? out64[tid] : 0.f;
 }
 
 // ---- buffer addressing of a slab: one descriptor per tensor (base = the slab's first row: wave-uniform, SGPRs), ONE
@@ -687,17 +719,36 @@ template <> struct GnOct<true> {
     }
 };
 
-__device__ __forceinline__ void gn_store_f32(const GnSlab& t, unsigned voff, int k, const float* o) {
-    const f32x4 fa = {o[0], o[1], o[2], o[3]}, fb = {o[4], o[5], o[6], o[7]};
-    const gn_u32x4 a = __builtin_bit_cast(gn_u32x4, fa), b = __builtin_bit_cast(gn_u32x4, fb);
-    __builtin_amdgcn_raw_buffer_store_b128(a, t.rs, voff, k * t.step, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(b, t.rs, voff + 16, k * t.step, 0);
+// Stores go through plain global stores (uniform base + 32-bit offset, exec-masked): a 16-byte raw_buffer_store with an SGPR
+// soffset is NOT safe on gfx950 with hipcc 7.2 -- the compiler reuses the data registers two instructions after the store
+// (it knows no hazard for that form) and under back-pressure the store then ships the NEW contents of its second dword
+// (measured: 40-150 corrupted octs per 5.2 M elements, always elements 2-3 of the packed bf16 oct).
+struct GnOut {
+    char* base;        // the slab's first row (wave-uniform)
+    unsigned voff;     // bytes, this thread's oct in pass 0
+    unsigned step;     // bytes per pass
+    bool on;
+};
+
+__device__ __forceinline__ GnOut gn_out(void* p, long ld, int esz, size_t first_row, int r0, int c0, int rpp, bool on) {
+    GnOut t;
+    t.base = (char*)p + first_row * (size_t)ld * esz;
+    t.voff = (unsigned)((r0 * ld + c0) * esz);
+    t.step = (unsigned)(rpp * ld * esz);
+    t.on = on;
+    return t;
 }
 
-__device__ __forceinline__ void gn_store_bf16(const GnSlab& t, unsigned voff, int k, const float* o) {
-    uint4 w = pack_bf16x8(o);
-    gn_u32x4 a = {w.x, w.y, w.z, w.w};
-    __builtin_amdgcn_raw_buffer_store_b128(a, t.rs, voff, k * t.step, 0);
+__device__ __forceinline__ void gn_store_f32(const GnOut& t, bool ok, int k, const float* o) {
+    if (t.on && ok) {
+        float4* p = (float4*)(t.base + (size_t)(t.voff + (unsigned)k * t.step));
+        p[0] = make_float4(o[0], o[1], o[2], o[3]);
+        p[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+__device__ __forceinline__ void gn_store_bf16(const GnOut& t, bool ok, int k, const float* o) {
+    if (t.on && ok) *(uint4*)(t.base + (size_t)(t.voff + (unsigned)k * t.step)) = pack_bf16x8(o);
 }
 
 __device__ __forceinline__ void gn_load_f32x8(const float* p, float* o) {
@@ -713,9 +764,11 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
                                                              long ldy16, float* __restrict__ mean_out,
                                                              float* __restrict__ rstd_out, float* partial, int* sync) {
     __shared__ float4 red[GN_FT];
-    __shared__ float lmean[GN_G], lrstd[GN_G];
+    __shared__ double fin[GN_FT];
+    __shared__ float out64[64], lmean[GN_G], lrstd[GN_G];
     const int tid = threadIdx.x;
     const int slab = blockIdx.x, nslab = gridDim.x, b = blockIdx.y;
+    const unsigned tag = (unsigned)__hip_atomic_load(sync + GN_SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int Q = C >> 3, cpg = C / GN_G;
     const int rpp = GN_FT / Q;
     const int lir = tid % Q, r0 = tid / Q;
@@ -749,36 +802,34 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
         if (e < n0) { a0 += s[e]; b0 += ss[e]; }
         else { a1 += s[e]; b1 += ss[e]; }
     }
-    const float mine = gn_fused_block_reduce(red, a0, b0, a1, b1, Q, rpp, cpg, tid);
-    if (tid < 64) __hip_atomic_store(partial + ((size_t)b * nslab + slab) * 64 + tid, mine, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    gn_slab_sync(sync, b, nslab);
-    if (tid < 256) {
-        double su, sq;
-        gn_fused_finish(partial, b, nslab, tid, &su, &sq);
-        if ((tid & 7) == 0) {
-            const int grp = tid >> 3;
-            double n = (double)cpg * HW;
-            double mean = su / n;
-            double var = sq / n - mean * mean;
+    const float mine = gn_fused_block_reduce(red, out64, a0, b0, a1, b1, Q, rpp, cpg, tid);
+    gn_publish(sync, b * nslab + slab, tid, mine, tag);
+    float ga[8], be[8];                                      // fetched under the hand-off's latency
+    gn_load_f32x8(gamma + (live ? c0 : 0), ga);              // (idle threads: every store is masked)
+    gn_load_f32x8(beta + (live ? c0 : 0), be);
+    int departed = 0;
+    {
+        const double tot = gn_sweep(sync, b * nslab, nslab, tid, tag, fin);      // entry t: sum (t < 32) / sum of squares
+        if (tid == 0) departed = gn_depart(sync);
+        if (tid < 64) fin[tid] = tot;
+        __syncthreads();
+        if (tid < GN_G) {
+            const double n = (double)cpg * HW;
+            const double mean = fin[tid] / n;
+            double var = fin[32 + tid] / n - mean * mean;
             if (var < 0.0) var = 0.0;
-            float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            lmean[grp] = (float)mean;
-            lrstd[grp] = rstd;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            lmean[tid] = (float)mean;
+            lrstd[tid] = rstd;
             if (slab == 0) {
-                mean_out[b * GN_G + grp] = (float)mean;
-                rstd_out[b * GN_G + grp] = rstd;
+                mean_out[b * GN_G + tid] = (float)mean;
+                rstd_out[b * GN_G + tid] = rstd;
             }
         }
     }
     __syncthreads();
-    gn_slab_leave(sync, b, nslab);
-    if (!live) return;
     float sc[8], sh[8];
     {
-        float ga[8], be[8];
-        gn_load_f32x8(gamma + c0, ga);
-        gn_load_f32x8(beta + c0, be);
         const int g1 = min(g0 + 1, GN_G - 1);
         const float rs0 = lrstd[g0], rs1 = lrstd[g1], mu0 = lmean[g0], mu1 = lmean[g1];
 #pragma unroll
@@ -788,8 +839,8 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
             sh[e] = be[e] - (e < n0 ? mu0 : mu1) * a;
         }
     }
-    const GnSlab t32 = gn_slab(y32, ldy32, 4, first, r0, c0, rpp, y32 != nullptr);
-    const GnSlab t16 = gn_slab(y16, ldy16, 2, first, r0, c0, rpp, y16 != nullptr);
+    const GnOut t32 = gn_out(y32, ldy32, 4, first, r0, c0, rpp, live && y32 != nullptr);
+    const GnOut t16 = gn_out(y16, ldy16, 2, first, r0, c0, rpp, live && y16 != nullptr);
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
         const bool ok = r0 + k * rpp < nrows;
@@ -800,9 +851,10 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
             o[e] = v[e] * sc[e] + sh[e];
             if (ACT) o[e] = silu_f(o[e]);
         }
-        gn_store_f32(t32, ok ? t32.voff : GN_OOB, k, o);
-        gn_store_bf16(t16, ok ? t16.voff : GN_OOB, k, o);
+        gn_store_f32(t32, ok, k, o);
+        gn_store_bf16(t16, ok, k, o);
     }
+    if (tid == 0) gn_close(sync, departed, nslab * gridDim.y);
 }
 
 template <bool XB, bool DYB, int NO, bool ACT>
@@ -815,9 +867,11 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
                                                              const float* __restrict__ add_src, long ldadd, float* partial,
                                                              int* sync) {
     __shared__ float4 red[GN_FT];
-    __shared__ float lA[GN_G], lB[GN_G];
+    __shared__ double fin[GN_FT];
+    __shared__ float out64[64], lA[GN_G], lB[GN_G];
     const int tid = threadIdx.x;
     const int slab = blockIdx.x, nslab = gridDim.x, b = blockIdx.y;
+    const unsigned tag = (unsigned)__hip_atomic_load(sync + GN_SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int Q = C >> 3, cpg = C / GN_G;
     const int rpp = GN_FT / Q;
     const int lir = tid % Q, r0 = tid / Q;
@@ -877,31 +931,28 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
         if (e < n0) { a0 += sA[e]; b0 += sB[e]; }
         else { a1 += sA[e]; b1 += sB[e]; }
     }
-    const float mine = gn_fused_block_reduce(red, a0, b0, a1, b1, Q, rpp, cpg, tid);
-    if (tid < 64) __hip_atomic_store(partial + ((size_t)b * nslab + slab) * 64 + tid, mine, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    gn_slab_sync(sync, b, nslab);
-    if (tid < 256) {
-        double a, bb;
-        gn_fused_finish(partial, b, nslab, tid, &a, &bb);
-        if ((tid & 7) == 0) {
-            double n = (double)cpg * HW;
-            lA[tid >> 3] = (float)(a / n);
-            lB[tid >> 3] = (float)(bb / n);
+    const float mine = gn_fused_block_reduce(red, out64, a0, b0, a1, b1, Q, rpp, cpg, tid);
+    gn_publish(sync, b * nslab + slab, tid, mine, tag);
+    int departed = 0;
+    {
+        const double tot = gn_sweep(sync, b * nslab, nslab, tid, tag, fin);
+        if (tid == 0) departed = gn_depart(sync);
+        if (tid < 64) {
+            const double n = (double)cpg * HW;
+            if (tid < 32) lA[tid] = (float)(tot / n);
+            else lB[tid - 32] = (float)(tot / n);
         }
     }
     __syncthreads();
-    gn_slab_leave(sync, b, nslab);
-    if (!live) return;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
         xr[k].opaque();
         dr[k].opaque();
     }
     const float mA0 = lA[g0], mA1 = lA[g1], mB0 = lB[g0], mB1 = lB[g1];
-    const GnSlab t32 = gn_slab(dx32, lddx32, 4, first, r0, c0, rpp, dx32 != nullptr);
-    const GnSlab t16 = gn_slab(dx16, lddx16, 2, first, r0, c0, rpp, dx16 != nullptr);
-    const GnSlab tad = gn_slab(add_src, ldadd, 4, first, r0, c0, rpp, dx32 != nullptr && accumulate);
+    const GnOut t32 = gn_out(dx32, lddx32, 4, first, r0, c0, rpp, live && dx32 != nullptr);
+    const GnOut t16 = gn_out(dx16, lddx16, 2, first, r0, c0, rpp, live && dx16 != nullptr);
+    const GnSlab tad = gn_slab(add_src, ldadd, 4, first, r0, c0, rpp, live && dx32 != nullptr && accumulate);
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
         const bool ok = r0 + k * rpp < nrows;
@@ -919,10 +970,11 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
             const float dyh = dz * ga[e];
             o[e] = sc[e] * (dyh - (e < n0 ? mA0 : mA1) - xh * (e < n0 ? mB0 : mB1)) + ac[e];
         }
-        gn_store_f32(t32, ok ? t32.voff : GN_OOB, k, o);
-        gn_store_bf16(t16, ok ? t16.voff : GN_OOB, k, o);
+        gn_store_f32(t32, ok, k, o);
+        gn_store_bf16(t16, ok, k, o);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (tid == 0) gn_close(sync, departed, nslab * gridDim.y);
 }
 
 // geometry of the single-launch path: slabs per sample so that B * nslab <= the CU count; 0 octs = not eligible
@@ -937,10 +989,12 @@ static int gn_fused_geom(int B, int HW, int C, int max_octs, int* nslab, int* ro
         g_gn_cus = n > 0 ? n : -1;
     }
     const int Q = C >> 3;
-    if (g_gn_cus <= 0 || Q > GN_FT || B > g_gn_cus || 2 * B + 2 > GN_SYNC_POISON) return 0;
+    if (g_gn_cus <= 0 || Q > GN_FT || B > g_gn_cus || g_gn_cus > GN_MAX_WGS) return 0;
+    if (C / GN_G < 8) return 0;      // the kernels assume an 8-channel oct touches at most two groups
     const int rpp = GN_FT / Q;
     int ns = g_gn_cus / B;
-    if (ns > HW) ns = HW;
+    if (ns > 128) ns = 128;          // every workgroup sweeps all of its sample's records: past ~128 the sweep costs more than
+    if (ns > HW) ns = HW;            // the extra CUs bring (one instance: 5 MB tensors)
     int rps = (HW + ns - 1) / ns;
     rps = (rps + rpp - 1) / rpp * rpp;                 // whole passes: no half-empty last pass inside a slab
     ns = (HW + rps - 1) / rps;

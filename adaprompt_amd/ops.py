@@ -228,21 +228,37 @@ def batched_matmul_nt(a, b, out_dtype=F32, alpha=1.0):
 # --------------------------------------------------------------------------------------------
 
 _GN_SYNC = {}
+_GN_SYNC_STREAM = {}
+
+
+def set_gn_single_launch_stream(device, raw_stream):
+    """which stream's GroupNorms may take the single-launch path on ``device`` (default: the device's default stream)."""
+    _GN_SYNC_STREAM[device.index] = raw_stream
 
 
 def gn_sync_buffer(device):
-    """the zero-initialised arrival-counter buffer of the single-launch GroupNorm kernels, one per (device, stream): kernels
-    of one stream run in order and the counters reset themselves, so the buffer is allocated and zeroed once."""
-    key = (device.index, _stream())
-    buf = _GN_SYNC.get(key)
+    """-> data pointer of the zero-initialised arrival-counter buffer of the single-launch GroupNorm kernels, or 0.
+
+    The workgroups of such a kernel wait for each other inside the launch, so all of them must be resident together.  One
+    kernel of <= 256 workgroups always is; two of them in flight on different streams could each hold part of the chip and
+    wait for the rest for ever.  Hence exactly ONE stream per device takes that path (the default stream, where the UNet's
+    forward / backward run); GroupNorms issued on any other stream (the prefetchers' side streams) run the two-launch
+    kernels.  Kernels of one stream run in order and the counters reset themselves: allocated and zeroed once."""
+    st = _stream()
+    owner = _GN_SYNC_STREAM.get(device.index)
+    if owner is None:
+        owner = _GN_SYNC_STREAM[device.index] = torch.cuda.default_stream(device).cuda_stream
+    if st != owner:
+        return 0
+    buf = _GN_SYNC.get(device.index)
     if buf is None:
-        buf = _GN_SYNC[key] = torch.zeros(_lib.call_long("adap_groupnorm_sync_ints"), device=device, dtype=torch.int32)
-    return buf
+        buf = _GN_SYNC[device.index] = torch.zeros(_lib.call_long("adap_groupnorm_sync_ints"), device=device, dtype=torch.int32)
+    return buf.data_ptr()
 
 
 def gn_sync_poisoned():
     """True if a single-launch GroupNorm ever gave up waiting for its sample's other workgroups (tests assert it is False)."""
-    return any(int(b[-1]) != 0 for b in _GN_SYNC.values())
+    return any(int(b[1]) != 0 for b in _GN_SYNC.values())          # word 1 = poison (norms.hip GN_SYNC_POISON)
 
 
 def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
@@ -257,7 +273,7 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_groupnorm_fwd", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
-              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), gn_sync_buffer(x.device).data_ptr(), B, HW, C, float(eps),
+              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), gn_sync_buffer(x.device), B, HW, C, float(eps),
               int(act), _stream())
     if e0 is not None:
         # algorithmic bytes: read x once (4 B) + write y (2 B bf16 / 4 B f32) per element
@@ -288,7 +304,7 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, act, out_f32=True, out_bf16=Fa
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     _lib.call("adap_groupnorm_bwd", dy.data_ptr(), _dt(dy), lddy, x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
               mean.data_ptr(), rstd.data_ptr(), _ptr(dx32), lddx32, acc, _ptr(dx16), C, add_ptr, ldadd, ws.data_ptr(),
-              gn_sync_buffer(x.device).data_ptr(), B, HW, C, int(act), _stream())
+              gn_sync_buffer(x.device), B, HW, C, int(act), _stream())
     return dx32, dx16
 
 

@@ -94,10 +94,10 @@ int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O, int I, int
  * sync: NULL, or a device buffer of adap_groupnorm_sync_ints() int32 that the caller zero-initialised ONCE and then
  * hands to every call issued on the same stream (one buffer per stream).  With it, tensors whose per-workgroup slab
  * fits the register file (every UNet shape at the training batch sizes) take a SINGLE launch that reads x once: the
- * workgroups of a sample meet at a self-resetting arrival counter in `sync` between the statistics and the
- * normalisation (norms.hip).  The last int is a poison word, set if a bounded spin ever gave up (never, unless more
- * spinning kernels are in flight than the chip can hold); adap_groupnorm_last_variant(): 0 = two launches, N = single
- * launch with N pixel rows per thread.
+ * workgroups of a sample exchange their group partials through tagged 8-byte records in `sync` between the statistics
+ * and the normalisation (norms.hip).  sync[1] is a poison word, set if a bounded wait ever gave up (never, unless
+ * more such kernels are in flight than the chip can hold: hand `sync` to ONE stream per device only);
+ * adap_groupnorm_last_variant(): 0 = two launches, N = single launch with N pixel rows per thread.
  */
 long adap_groupnorm_workspace_floats(int B, int HW, int C);
 long adap_groupnorm_sync_ints(void);
