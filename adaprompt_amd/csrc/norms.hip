@@ -563,10 +563,21 @@ extern "C" int adap_groupnorm_bwd(const void* dy, int dy_dtype, long lddy, const
 #define GN_SYNC_DEPART 2
 #define GN_SYNC_HDR 64
 #define GN_MAX_WGS 512
-#define GN_SYNC_INTS (GN_SYNC_HDR + GN_MAX_WGS * 64 * 2)
+#define GN_SYNC_STAMPS_ON 3      // diagnostic: non-zero -> workgroup w stores 6 shader-clock stamps (s_memtime) at GN_SYNC_STAMPS + 16 w
+#define GN_SYNC_STAMPS (GN_SYNC_HDR + GN_MAX_WGS * 64 * 2)
+#define GN_SYNC_INTS (GN_SYNC_STAMPS + GN_MAX_WGS * 16)
 #define GN_SPIN_LIMIT (1u << 20)
 
 typedef unsigned long long gn_u64;
+
+// tools/gn_probe.py stamps: where a launch spends its time (loads landed / published / sweep done / stores issued).  The
+// stamp values go only to the stamp area of the sync buffer, which nothing else reads; off (one uniform branch) by default.
+__device__ __forceinline__ void gn_stamp(int* sync, bool on, int wg, int slot) {
+    if (on && threadIdx.x == 0) {
+        const gn_u64 t = __builtin_amdgcn_s_memtime();
+        ((gn_u64*)(sync + GN_SYNC_STAMPS))[(size_t)wg * 8 + slot] = t;
+    }
+}
 
 // publish this workgroup's 64 group partials: entry t (thread t < 64, one wave, one 512-byte store instruction) as the
 // 8-byte granule {tag = epoch, value}: the data IS the flag -- no drain, no flag store, no arrival counter
@@ -759,7 +770,7 @@ __device__ __forceinline__ void gn_load_f32x8(const float* p, float* o) {
 template <bool XB, int NO, bool ACT>
 __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restrict__ x, long ldx, int HW, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float eps, int rows_per_slab,
+                                                             float eps, int rows_per_slab, double inv_n,
                                                              float* __restrict__ y32, long ldy32, uint16_t* __restrict__ y16,
                                                              long ldy16, float* __restrict__ mean_out,
                                                              float* __restrict__ rstd_out, float* partial, int* sync) {
@@ -768,7 +779,8 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
     __shared__ float out64[64], lmean[GN_G], lrstd[GN_G];
     const int tid = threadIdx.x;
     const int slab = blockIdx.x, nslab = gridDim.x, b = blockIdx.y;
-    const unsigned tag = (unsigned)__hip_atomic_load(sync + GN_SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int wg = b * nslab + slab;
+    const gn_u64 t_start = __builtin_amdgcn_s_memtime();
     const int Q = C >> 3, cpg = C / GN_G;
     const int rpp = GN_FT / Q;
     const int lir = tid % Q, r0 = tid / Q;
@@ -783,6 +795,11 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
     GnOct<XB> xr[NO];
 #pragma unroll
     for (int k = 0; k < NO; ++k) xr[k].load(tx, (r0 + k * rpp < nrows) ? tx.voff : GN_OOB, k);
+    // the epoch (an sc1 load, served by the memory side) is issued BEHIND the slab's loads: vmcnt retires in order, so in
+    // front of them it would hold up the first use of x
+    const unsigned tag = (unsigned)__hip_atomic_load(sync + GN_SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const bool stamps = sync[GN_SYNC_STAMPS_ON] != 0;
+    if (stamps && tid == 0) ((gn_u64*)(sync + GN_SYNC_STAMPS))[(size_t)wg * 8 + 0] = t_start;
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
@@ -803,6 +820,7 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
         else { a1 += s[e]; b1 += ss[e]; }
     }
     const float mine = gn_fused_block_reduce(red, out64, a0, b0, a1, b1, Q, rpp, cpg, tid);
+    gn_stamp(sync, stamps, wg, 1);                           // slab loaded and reduced
     gn_publish(sync, b * nslab + slab, tid, mine, tag);
     float ga[8], be[8];                                      // fetched under the hand-off's latency
     gn_load_f32x8(gamma + (live ? c0 : 0), ga);              // (idle threads: every store is masked)
@@ -810,15 +828,19 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
     int departed = 0;
     {
         const double tot = gn_sweep(sync, b * nslab, nslab, tid, tag, fin);      // entry t: sum (t < 32) / sum of squares
+        gn_stamp(sync, stamps, wg, 2);                       // every record of the sample read
         if (tid == 0) departed = gn_depart(sync);
         if (tid < 64) fin[tid] = tot;
         __syncthreads();
         if (tid < GN_G) {
-            const double n = (double)cpg * HW;
-            const double mean = fin[tid] / n;
-            double var = fin[32 + tid] / n - mean * mean;
+            // (fp64 only where the cancellation is: an fp64 divide / sqrt is a ~1 us software sequence on the critical path)
+            // inv_n = 1 / (channels per group * pixels), from the host
+            const double mean = fin[tid] * inv_n;
+            double var = fin[32 + tid] * inv_n - mean * mean;
             if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float vf = (float)(var + (double)eps);
+            float rstd = __builtin_amdgcn_rsqf(vf);
+            rstd = rstd * (1.5f - 0.5f * vf * rstd * rstd);       // one Newton step: <= 1 ulp of the correctly rounded value
             lmean[tid] = (float)mean;
             lrstd[tid] = rstd;
             if (slab == 0) {
@@ -828,6 +850,7 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
         }
     }
     __syncthreads();
+    gn_stamp(sync, stamps, wg, 5);                           // statistics finished
     float sc[8], sh[8];
     {
         const int g1 = min(g0 + 1, GN_G - 1);
@@ -854,14 +877,16 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_fwd_kernel(const void* __restr
         gn_store_f32(t32, ok, k, o);
         gn_store_bf16(t16, ok, k, o);
     }
+    gn_stamp(sync, stamps, wg, 3);                           // stores issued
     if (tid == 0) gn_close(sync, departed, nslab * gridDim.y);
+    gn_stamp(sync, stamps, wg, 4);
 }
 
 template <bool XB, bool DYB, int NO, bool ACT>
 __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restrict__ dy, long lddy, const void* __restrict__ x,
                                                              long ldx, int HW, int C, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, int rows_per_slab,
+                                                             const float* __restrict__ rstd, int rows_per_slab, double inv_n,
                                                              float* __restrict__ dx32, long lddx32, int accumulate,
                                                              uint16_t* __restrict__ dx16, long lddx16,
                                                              const float* __restrict__ add_src, long ldadd, float* partial,
@@ -871,7 +896,6 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
     __shared__ float out64[64], lA[GN_G], lB[GN_G];
     const int tid = threadIdx.x;
     const int slab = blockIdx.x, nslab = gridDim.x, b = blockIdx.y;
-    const unsigned tag = (unsigned)__hip_atomic_load(sync + GN_SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int Q = C >> 3, cpg = C / GN_G;
     const int rpp = GN_FT / Q;
     const int lir = tid % Q, r0 = tid / Q;
@@ -892,6 +916,7 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
         xr[k].load(tx, ok ? tx.voff : GN_OOB, k);
         dr[k].load(td, ok ? td.voff : GN_OOB, k);
     }
+    const unsigned tag = (unsigned)__hip_atomic_load(sync + GN_SYNC_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     // per-channel constants: xhat = x * sc + sh, z = xhat * ga + be
     float sc[8], sh[8], ga[8], be[8];
     {
@@ -938,9 +963,8 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
         const double tot = gn_sweep(sync, b * nslab, nslab, tid, tag, fin);
         if (tid == 0) departed = gn_depart(sync);
         if (tid < 64) {
-            const double n = (double)cpg * HW;
-            if (tid < 32) lA[tid] = (float)(tot / n);
-            else lB[tid - 32] = (float)(tot / n);
+            if (tid < 32) lA[tid] = (float)(tot * inv_n);
+            else lB[tid - 32] = (float)(tot * inv_n);
         }
     }
     __syncthreads();
@@ -1018,7 +1042,8 @@ static int gn_fused_fwd_try(const void* x, int x_dtype, long ldx, const float* g
     const int octs = gn_fused_geom(B, HW, C, 16, &nslab, &rps);
     if (!octs) return 0;
 #define GN_FF(XB, NO, ACT) hipLaunchKernelGGL((gn_fused_fwd_kernel<XB, NO, ACT>), dim3(nslab, B), dim3(GN_FT), 0, s, x, ldx, HW, C, \
-                                              gamma, beta, eps, rps, y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd, workspace, sync)
+                                              gamma, beta, eps, rps, 1.0 / ((double)(C / GN_G) * HW), y32, ldy32, (uint16_t*)y16,    \
+                                              ldy16, mean, rstd, workspace, sync)
 #define GN_FF2(XB, ACT) do { if (octs <= 6) GN_FF(XB, 6, ACT); else if (octs <= 12) GN_FF(XB, 12, ACT); else GN_FF(XB, 16, ACT); } while (0)
     if (x_dtype == 1) { if (act) GN_FF2(true, true); else GN_FF2(true, false); }
     else { if (act) GN_FF2(false, true); else GN_FF2(false, false); }
@@ -1036,7 +1061,8 @@ static int gn_fused_bwd_try(const void* dy, int dy_dtype, long lddy, const void*
     const int octs = gn_fused_geom(B, HW, C, 8, &nslab, &rps);
     if (!octs) return 0;
 #define GN_FB(XB, DYB, NO, ACT) hipLaunchKernelGGL((gn_fused_bwd_kernel<XB, DYB, NO, ACT>), dim3(nslab, B), dim3(GN_FT), 0, s, dy, \
-                                                   lddy, x, ldx, HW, C, gamma, beta, mean, rstd, rps, dx32, lddx32, accumulate, \
+                                                   lddy, x, ldx, HW, C, gamma, beta, mean, rstd, rps,                           \
+                                                   1.0 / ((double)(C / GN_G) * HW), dx32, lddx32, accumulate,                  \
                                                    (uint16_t*)dx16, lddx16, add_src, ldadd, workspace, sync)
 // (12 rows of f32 x + dy per thread do not fit 256 registers next to the per-channel constants: such shapes -- 64x64x640 at
 // bs 4 -- take the two-pass path in the backward)

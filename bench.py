@@ -415,8 +415,9 @@ def main():
                                          "fwd_GBps": round(gn_bytes_f / t_gn / 1e9, 1), "bwd_GBps": round(gn_bytes_b / t_gnb / 1e9, 1),
                                          "fwd_frac_of_hbm_peak": round(gn_bytes_f / t_gn / 8e12, 4),
                                          "bwd_frac_of_hbm_peak": round(gn_bytes_b / t_gnb / 8e12, 4),
-                                         "note": "two launches each (statistics, apply): 21 MB tensors are launch-latency bound; "
-                                                 "the 134 MB+ VAE shapes reach 4.2 TB/s"},
+                                         "note": "ONE launch each (norms.hip gn_fused_*: x read once, the sample's workgroups exchange their "
+                                                 "group partials through tagged 8-byte records inside the launch); in-kernel stamps: ~3 us load, "
+                                                 "~4 us hand-off (publish + sweep = memory-side round trips), ~1.2 us finish, ~1.2 us store issue"},
         }
         del qkv, o_, lse_, do_, xr, er, xg, go, dy16
 
