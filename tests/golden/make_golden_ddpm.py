@@ -1,0 +1,203 @@
+"""Golden vectors from the reference's OWN ``ldm/models/diffusion/ddpm.py`` methods (SURVEY.md 8c said the file "cannot be
+imported": it can, once the third-party names it only mentions at import time are present -- pytorch_lightning, insightface,
+cv2, clip, kornia, taming, diffusers, torchvision, a removed ``transformers`` name -- as inert stand-ins; no arithmetic of the
+reference is replaced).  The methods are called UNBOUND on a bare object that carries only the attributes they read, so no
+checkpoint / CLIP / Lightning is needed:
+
+    DDPM.register_schedule, q_sample, predict_start_from_noise        (ddpm.py:240-292, 416-419, 358-362)
+    LatentDiffusion.calc_recon_loss                                   (:3571-3595)
+    LatentDiffusion.calc_fg_bg_complementary_loss / calc_fg_mb_suppress_loss / calc_fg_bg_xlayer_consist_loss  (:3932-4387)
+    LatentDiffusion.forward's conditioning assembly                   (:1940-2179), with tests/stubs.py as the text encoder
+    Arc2FaceWrapper.forward's rollout schedule                        (:5432-5478), a closed-form "UNet"
+
+    python tests/golden/make_golden_ddpm.py          # writes tests/golden/ddpm_methods.npz  (own process: sys.modules games)
+
+tests/test_ddpm_golden.py holds the oracle restatements AND the product mirrors to these numbers."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+OUT = os.path.join(HERE, "ddpm_methods.npz")
+
+
+def import_reference_ddpm():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    sys.path.insert(0, REF)
+    stub("cv2")
+    import adaface.subj_basis_generator  # noqa: F401   (before the torchvision stand-in: transformers probes torchvision.__spec__)
+    del sys.modules["ldm"]               # subj_basis_generator.py:23 rebinds it to the adaface package
+    tv = stub("torchvision")
+    tv.utils = stub("torchvision.utils", make_grid=None, draw_bounding_boxes=None)
+    tv.transforms = stub("torchvision.transforms")
+    pl = stub("pytorch_lightning", LightningModule=nn.Module)
+    pl.utilities = stub("pytorch_lightning.utilities")
+    pl.utilities.distributed = stub("pytorch_lightning.utilities.distributed", rank_zero_only=lambda f: f)
+    stub("insightface")
+    stub("insightface.app", FaceAnalysis=object)
+    stub("clip")
+    stub("kornia")
+    stub("taming")
+    stub("taming.modules")
+    stub("taming.modules.vqvae")
+    stub("taming.modules.vqvae.quantize", VectorQuantizer2=object)
+    oc = stub("omegaconf")
+    oc.listconfig = stub("omegaconf.listconfig", ListConfig=list)
+    stub("diffusers", UNet2DConditionModel=object)
+    stub("evaluation")
+    stub("evaluation.clip_eval", CLIPEvaluator=object)
+    import transformers
+    if not hasattr(transformers, "ViTFeatureExtractor"):
+        transformers.ViTFeatureExtractor = object        # removed upstream; ddpm.py:24 only names it
+    import ldm.models.diffusion.ddpm as D
+    assert D.__file__.startswith(REF)
+    return D
+
+
+def seeded(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ---- shared with tests/test_ddpm_golden.py: the inputs of every case, by seed ------------------------------------------
+ATTN_N = {7: 64, 8: 64, 12: 16, 16: 64, 17: 64, 18: 64, 19: 256, 20: 256, 21: 256, 22: 1024, 23: 1024, 24: 1024}
+
+
+def attn_case(B=2, heads=2, seed=100):
+    sc = {li: seeded((B, heads, n, 77), seed + li, 1.5) for li, n in ATTN_N.items()}
+    subj = (torch.arange(B).repeat_interleave(9), torch.arange(4, 13).repeat(B))
+    bg = (torch.arange(B).repeat_interleave(4), torch.arange(20, 24).repeat(B))
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 32), torch.linspace(-1, 1, 32), indexing="ij")
+    fg = ((xx / 0.6) ** 2 + (yy / 0.7) ** 2 <= 1.0).float()[None, None].repeat(B, 1, 1, 1)
+    return sc, subj, bg, fg
+
+
+def recon_case(seed):
+    out, tgt = seeded((3, 4, 16, 16), seed), seeded((3, 4, 16, 16), seed + 1)
+    img = (torch.rand(3, 1, 16, 16, generator=torch.Generator().manual_seed(seed + 2)) > 0.2).float()
+    fg = (torch.rand(3, 1, 16, 16, generator=torch.Generator().manual_seed(seed + 3)) > 0.6).float()
+    return out, tgt, img, fg
+
+
+def prompts_case(B=3):
+    subj_single = [f"a photo of a z , , , , , , , , and y , , , number{i}" for i in range(B)]
+    subj_comp = [p + " riding a horse in the snow" for p in subj_single]
+    cls_single = [p.replace(" z ", " person ") for p in subj_single]
+    cls_comp = [p.replace(" z ", " person ") for p in subj_comp]
+    return subj_single, subj_comp, cls_single, cls_comp
+
+
+def main():
+    D = import_reference_ddpm()
+    rec = {}
+    # ---- A / B: schedule, q_sample, predict_start_from_noise
+    m = nn.Module.__new__(D.LatentDiffusion)          # no __init__: only the attributes the methods below read
+    nn.Module.__init__(m)
+    m.parameterization, m.v_posterior, m.loss_type, m.num_timesteps_cond = "eps", 0.0, "l2", 1
+    D.LatentDiffusion.register_schedule(m, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.012)
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+        rec["sched/" + k] = getattr(m, k).numpy()
+    x0, nz = seeded((4, 4, 8, 8), 1), seeded((4, 4, 8, 8), 2)
+    t = torch.tensor([0, 17, 500, 999])
+    xt = D.DDPM.q_sample(m, x0, t, nz)
+    rec["q_sample"] = xt.numpy()
+    rec["predict_x0"] = D.DDPM.predict_start_from_noise(m, xt, t, nz * 0.9 + 0.05).numpy()
+    # ---- C: calc_recon_loss
+    for i, (fw, bw, use_masks) in enumerate([(1, 1, True), (1, 0.1, True), (1.0, 0.0, True), (1, 0.05, False)]):
+        out, tgt, img, fg = recon_case(10 + 10 * i)
+        out.requires_grad_(True)
+        loss, px = D.LatentDiffusion.calc_recon_loss(m, out, tgt, img if use_masks else None, fg if use_masks else None, fw, bw)
+        loss.backward()
+        rec[f"recon/{i}/loss"] = np.float64(loss.item())
+        rec[f"recon/{i}/grad"] = out.grad.numpy()
+        rec[f"recon/{i}/cfg"] = np.array([fw, bw, float(use_masks)])
+    # ---- D: the recon iteration's attention losses
+    sc, subj, bg, fg = attn_case()
+    for tag, kw in (("full", dict(bg=bg, fg_mask=fg, inst=None, sqrt=False)),
+                    ("nobg", dict(bg=None, fg_mask=fg, inst=None, sqrt=False)),
+                    ("nomask", dict(bg=bg, fg_mask=None, inst=None, sqrt=False)),
+                    ("inst", dict(bg=bg, fg_mask=fg, inst=torch.tensor([1.0, 0.0]), sqrt=True))):
+        leaf = {li: v.clone().requires_grad_(True) for li, v in sc.items()}
+        losses = D.LatentDiffusion.calc_fg_bg_complementary_loss(
+            m, leaf, subj, kw["bg"], 2, fg_grad_scale=0.1, fg_mask=kw["fg_mask"], instance_mask=kw["inst"], do_sqrt_norm=kw["sqrt"])
+        tot = sum(l for l in losses if torch.is_tensor(l))
+        if torch.is_tensor(tot) and tot.requires_grad:
+            tot.backward()
+        rec[f"complem/{tag}/losses"] = np.array([float(l) for l in losses])
+        rec[f"complem/{tag}/gnorm"] = np.array([0.0 if leaf[li].grad is None else float(leaf[li].grad.double().norm()) for li in ATTN_N])
+    leaf = {li: v.clone().requires_grad_(True) for li, v in sc.items()}
+    lfg, lbg = D.LatentDiffusion.calc_fg_bg_xlayer_consist_loss(m, leaf, subj, bg, 2)
+    (lfg + lbg).backward()
+    rec["xlayer/losses"] = np.array([float(lfg), float(lbg)])
+    rec["xlayer/gnorm"] = np.array([0.0 if leaf[li].grad is None else float(leaf[li].grad.double().norm()) for li in ATTN_N])
+    leaf = {li: v.clone().requires_grad_(True) for li, v in sc.items()}
+    lfg1, lbg1 = D.LatentDiffusion.calc_fg_bg_xlayer_consist_loss(m, leaf, subj, None, 1)
+    rec["xlayer_nobg/losses"] = np.array([float(lfg1), float(lbg1)])
+    # ---- E: forward()'s conditioning assembly, with the test stand-ins as text encoder / embedding manager
+    sys.path.insert(0, ROOT)
+    from tests.stubs import StubEmbeddingManager, StubTextEncoder
+    for mode in ("recon_delta", "recon_plain", "mix", "ada_delta"):
+        enc = StubTextEncoder(dim=16)
+        em = StubEmbeddingManager(text_embedder=enc, dim=16)
+        fake = types.SimpleNamespace()
+        fake.num_timesteps, fake.device = 1000, torch.device("cpu")
+        fake.model = types.SimpleNamespace(conditioning_key="crossattn")
+        fake.cond_stage_trainable, fake.N_CA_LAYERS, fake.prompt_mix_scheme = True, 16, "mix_hijk"
+        fake.apply_arc2face_inverse_embs, fake.shorten_cond_schedule, fake.cached_inits = False, False, {}
+        prompts = prompts_case(3)
+        fake.iter_flags = {"do_static_prompt_delta_reg": mode != "recon_plain", "do_mix_prompt_distillation": mode == "mix",
+                           "do_ada_prompt_delta_reg": mode in ("mix", "ada_delta"), "do_normal_recon": mode.startswith("recon"),
+                           "do_arc2face_distill": False, "reuse_init_conds": False, "delta_prompts": prompts,
+                           "zs_clip_features": None, "zs_id_embs": None}
+
+        def glc(cond_in, zs_clip_features=None, zs_id_embs=None, randomize_clip_weights=False,
+                apply_arc2face_inverse_embs=False, _enc=enc, _em=em):
+            emb = _enc.encode(cond_in, embedding_manager=_em)
+            return emb, cond_in, {"placeholder2indices": dict(_em.placeholder2indices), "prompt_emb_mask": _em.prompt_emb_mask}
+        fake.get_learned_conditioning = glc
+        fake.p_losses = lambda x_start, cond, t: cond
+        torch.manual_seed(0)
+        c_emb, c_in, extra = D.LatentDiffusion.forward(fake, torch.zeros(3, 4, 8, 8), list(prompts[0]))
+        rec[f"fwd/{mode}/c_emb"] = c_emb.detach().numpy()
+        rec[f"fwd/{mode}/c_in"] = np.array(list(c_in))
+        rec[f"fwd/{mode}/keys"] = np.array(sorted(extra.keys()))
+        rec[f"fwd/{mode}/iter_type"] = np.array(extra["iter_type"])
+        for name in ("placeholder2indices", "placeholder2indices_1b", "placeholder2indices_2b"):
+            if name in extra:
+                for ph, (ib, it) in extra[name].items():
+                    rec[f"fwd/{mode}/{name}/{ph}"] = np.stack([ib.numpy(), it.numpy()])
+        for name in ("c_static_emb_4b", "c_static_emb_1b"):
+            if name in extra:
+                rec[f"fwd/{mode}/{name}"] = extra[name].detach().numpy()
+    # ---- F: the teacher rollout's timestep schedule and x0 chain (closed-form eps model in place of the diffusers UNet)
+    for nd in (1, 3, 5):
+        wrap = types.SimpleNamespace()
+        wrap.unet = lambda sample, timestep, encoder_hidden_states, return_dict=False: (
+            (0.3 * sample + 0.01 * timestep.view(-1, 1, 1, 1).float() / 1000 + encoder_hidden_states.mean()).float(),)
+        torch.manual_seed(40 + nd)
+        x0, nz = seeded((2, 4, 8, 8), 50 + nd), seeded((2, 4, 8, 8), 60 + nd)
+        t = torch.tensor([900, 431])
+        ctx = seeded((2, 21, 16), 70 + nd, 0.1)
+        preds, x0s, noises, ts = D.Arc2FaceWrapper.forward.__wrapped__(wrap, m, x0, nz, t, ctx, num_denoising_steps=nd) \
+            if hasattr(D.Arc2FaceWrapper.forward, "__wrapped__") else D.Arc2FaceWrapper.forward(wrap, m, x0, nz, t, ctx, num_denoising_steps=nd)
+        rec[f"rollout/{nd}/ts"] = torch.stack(ts).numpy()
+        rec[f"rollout/{nd}/pred_last"] = preds[-1].numpy()
+        rec[f"rollout/{nd}/x0_last"] = x0s[-1].numpy()
+        rec[f"rollout/{nd}/noise_last"] = noises[-1].numpy()
+    np.savez_compressed(OUT, **rec)
+    print("wrote", OUT, len(rec), "arrays", os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
