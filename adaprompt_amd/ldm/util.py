@@ -376,8 +376,20 @@ def probably_anneal_t(t, training_percent, num_timesteps, ratio_range, keep_prob
 # used by LatentDiffusion.forward, ddpm.py:1710-2042)
 # ----------------------------------------------------------------------------------------------------------------
 def repeat_selected_instances(sel_indices, REPEAT, *args):
-    """every non-None tensor: pick ``sel_indices`` along dim 0 and tile that REPEAT times along dim 0."""
-    return [None if a is None else a[sel_indices].repeat([REPEAT] + [1] * (a.ndim - 1)) for a in args]
+    """every non-None argument: pick ``sel_indices`` along dim 0 and tile that REPEAT times along dim 0 (tensors), or
+    slice and repeat the list / tuple (subject names, is_face flags) -- the active definition in the reference is the
+    second one, ldm/util.py:1856-1870."""
+    out = []
+    for a in args:
+        if a is None:
+            out.append(None)
+        elif torch.is_tensor(a):
+            out.append(a[sel_indices].repeat([REPEAT] + [1] * (a.ndim - 1)))
+        elif isinstance(a, (list, tuple)):
+            out.append(a[sel_indices] * REPEAT)
+        else:
+            raise TypeError(f"repeat_selected_instances: {type(a)}")
+    return out
 
 
 def add_noise_to_tensor(ts, noise_std, noise_std_is_relative=True, keep_norm=False, std_dim=-1, norm_dim=-1):

@@ -22,6 +22,13 @@ import torch
 import torch.nn as nn
 
 sys.dont_write_bytecode = True
+
+
+def _no_breakpoints(*a, **k):
+    raise RuntimeError("the reference reached a breakpoint() (its way of asserting): the inputs of this case are not valid for it")
+
+
+sys.breakpointhook = _no_breakpoints        # never wait on stdin
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
@@ -95,6 +102,45 @@ def prompts_case(B=3):
     cls_single = [p.replace(" z ", " person ") for p in subj_single]
     cls_comp = [p.replace(" z ", " person ") for p in subj_comp]
     return subj_single, subj_comp, cls_single, cls_comp
+
+
+def shared_step_batch(B=4):
+    """a batch dict with the keys ``shared_step`` reads (ldm/data/personalized.py:510-833), prompts as in ``prompts_case``."""
+    ss, sc, cs, cc = prompts_case(B)
+    bgify = lambda ps: [p + " with background y" for p in ps]          # noqa: E731
+    return {"subject_name": ["alice", "bob", "alice", "bob"][:B], "is_in_mix_subj_folder": [False] * B,
+            "image_path": [f"/data/{i}.jpg" for i in range(B)], "has_fg_mask": torch.ones(B, dtype=torch.bool),
+            "has_wds_comp": torch.zeros(B, dtype=torch.bool),
+            "aug_mask": torch.ones(B, 16, 16), "fg_mask": (seeded((B, 16, 16), 5) > 0).float(),
+            "image_unnorm": torch.zeros(B, 16, 16, 3, dtype=torch.uint8),
+            "zs_clip_features": seeded((B, 514, 8), 6), "zs_id_embs": seeded((B, 512), 7),
+            "caption": list(ss), "caption_bg": bgify(ss),
+            "subj_prompt_single": list(ss), "subj_prompt_comp": list(sc), "cls_prompt_single": list(cs),
+            "cls_prompt_comp": list(cc),
+            "subj_prompt_single_bg": bgify(ss), "subj_prompt_comp_bg": bgify(sc),
+            "cls_prompt_single_bg": bgify(cs), "cls_prompt_comp_bg": bgify(cc)}
+
+
+SHARED_STEP_CASES = [("recon", False, 11), ("recon", False, 12), ("distill", True, 21), ("distill", True, 22), ("distill", True, 23),
+                     ("distill", True, 24), ("distill", True, 25), ("distill", True, 26)]
+
+
+def flags_record(fl, x_start, captions, em_calls):
+    keep = ("use_background_token", "gen_arc2face_rand_face", "add_noise_to_real_id_embs", "use_arc2face_as_target",
+            "num_denoising_steps", "same_subject_in_batch", "use_wds_comp", "use_fp_trick", "comp_init_fg_from_training_image",
+            "reuse_init_conds", "do_teacher_filter")
+    out = {k: int(fl.get(k, 0)) for k in keep}
+    out["bs"] = int(x_start.shape[0])
+    out["captions"] = list(captions)
+    out["n_delta_prompts"] = -1 if fl.get("delta_prompts") is None else len(fl["delta_prompts"][0])
+    out["masks_none"] = [fl["img_mask"] is None, fl["fg_mask"] is None]
+    out["have_fg"] = [bool(v) for v in fl["batch_have_fg_mask"].tolist()]
+    out["zs_id_shape"] = list(fl["zs_id_embs"].shape)
+    out["zs_clip_shape"] = list(fl["zs_clip_features"].shape)
+    out["zs_id_norms"] = [round(float(v), 5) for v in fl["zs_id_embs"].norm(dim=-1)]
+    out["a2f"] = None if fl.get("arc2face_prompt_emb") is None else list(fl["arc2face_prompt_emb"].shape)
+    out["embman_names"] = [c for c in em_calls if c[0] == "set_curr_batch_subject_names"][-1][1:]
+    return out
 
 
 def main():
@@ -195,6 +241,41 @@ def main():
         rec[f"rollout/{nd}/pred_last"] = preds[-1].numpy()
         rec[f"rollout/{nd}/x0_last"] = x0s[-1].numpy()
         rec[f"rollout/{nd}/noise_last"] = noises[-1].numpy()
+    # ---- G: the front of shared_step (ddpm.py:1436-1938): iteration flags and the order random / np.random are consumed in
+    import json
+    import random
+    from tests.stubs import StubEmbeddingManager as _EM
+    cases = []
+    for kind, distill, seed in SHARED_STEP_CASES:
+        class Fake:                                  # callable: shared_step ends in ``self(x_start, captions)``
+            def __call__(self, x_start, captions):
+                return x_start, captions
+        fake = Fake()
+        fake.first_stage_key, fake.training_percent = "image", 0.3
+        fake.do_static_prompt_delta_reg, fake.use_fp_trick, fake.use_background_token = True, True, True
+        fake.do_clip_teacher_filtering, fake.do_zero_shot, fake.cached_inits = True, True, {}
+        fake.p_gen_arc2face_rand_face, fake.p_add_noise_to_real_id_embs, fake.max_num_denoising_steps = 0.4, 0.6, 5
+        fake.apply_arc2face_inverse_embs = False
+        fake.embedding_manager = _EM(dim=8)
+        batch = shared_step_batch(4)
+        fake.get_input = lambda b, k: (seeded((len(b["subject_name"]), 4, 2, 2), 9), None)
+        fake.encode_zero_shot_image_features = lambda images, fg, image_paths=None, is_face=True, calc_avg=False: (
+            batch["zs_clip_features"], batch["zs_id_embs"], 0)
+        fake.arc2face = types.SimpleNamespace(gen_arc2face_prompt_embs=lambda n, pre_face_embs=None: (
+            n, pre_face_embs if pre_face_embs is not None else seeded((n, 512), 8), seeded((n, 21, 8), 10)))
+        fake.iter_flags = {}
+        D.DDPM.init_iteration_flags(fake)
+        fake.iter_flags["do_arc2face_distill"] = distill
+        if distill:
+            fake.iter_flags["do_static_prompt_delta_reg"] = False          # training_step switches it off (ddpm.py:572)
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        x_start, captions = D.LatentDiffusion.shared_step(fake, batch)
+        r = flags_record(fake.iter_flags, x_start, captions, fake.embedding_manager.calls)
+        r["after"] = [random.random(), float(np.random.rand())]            # where the two host RNG streams stand afterwards
+        cases.append(r)
+    rec["shared_step/cases"] = np.array(json.dumps(cases))
     np.savez_compressed(OUT, **rec)
     print("wrote", OUT, len(rec), "arrays", os.path.getsize(OUT), "bytes")
 

@@ -17,7 +17,7 @@ def test_library_builds_and_exports_header_symbols():
     for name in protos:
         assert hasattr(lib, name), f"{name} declared in include/adaprompt_hip.h but not exported"
     lib.adap_abi_version.restype = ctypes.c_int
-    assert lib.adap_abi_version() == 1
+    assert lib.adap_abi_version() == _lib.ABI_VERSION          # bumped with every argument-list change
 
 
 def test_bad_arguments_return_status_not_crash():

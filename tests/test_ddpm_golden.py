@@ -171,3 +171,52 @@ def test_teacher_rollout_schedule(nd):
     assert torch.allclose(preds[-1], T(f"rollout/{nd}/pred_last"), rtol=1e-5, atol=1e-6)
     assert torch.allclose(x0s[-1], T(f"rollout/{nd}/x0_last"), rtol=1e-5, atol=1e-5)
     assert torch.equal(ns[-1], T(f"rollout/{nd}/noise_last"))
+
+
+def test_shared_step_front_flags_and_rng_order():
+    """``prepare_recon_iteration`` (the mirror of the front of the reference's ``shared_step``, ddpm.py:1436-1938) on the
+    batches and seeds the reference's own ``shared_step`` ran on: every iteration flag, the prompt lists picked, the batch
+    trimming of multi-step distillation, what the embedding manager is told -- and both host RNG streams end in the same
+    state, i.e. ``random`` / ``np.random`` were consumed in the same order and number."""
+    import json
+    import random
+    from adaprompt_amd.ldm.models.diffusion.conditioning import ConditioningMixin
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from tests.stubs import StubEmbeddingManager
+    cases = json.loads(str(FIX["shared_step/cases"]))
+    assert len(cases) == len(G.SHARED_STEP_CASES)
+    seen = set()
+    for (kind, distill, seed), want in zip(G.SHARED_STEP_CASES, cases):
+        me = types.SimpleNamespace()
+        me.training_percent, me.do_static_prompt_delta_reg, me.use_background_token, me.do_zero_shot = 0.3, True, True, True
+        me.p_gen_arc2face_rand_face, me.p_add_noise_to_real_id_embs, me.max_num_denoising_steps = 0.4, 0.6, 5
+        me.apply_arc2face_inverse_embs = False
+        me.embedding_manager = StubEmbeddingManager(dim=8)
+        me.draw_num_denoising_steps = LatentDiffusion.draw_num_denoising_steps
+        me.half_batch_size = LatentDiffusion.half_batch_size
+        me.zero_shot_features = lambda *a, **k: ConditioningMixin.zero_shot_features(me, *a, **k)
+        me.arc2face = types.SimpleNamespace(gen_arc2face_prompt_embs=lambda n, pre_face_embs=None: (
+            n, pre_face_embs if pre_face_embs is not None else G.seeded((n, 512), 8), G.seeded((n, 21, 8), 10)))
+        me.do_static_prompt_delta_reg = True
+        LatentDiffusion.init_iteration_flags(me)
+        me.iter_flags["do_arc2face_distill"] = distill
+        if distill:
+            me.iter_flags["do_static_prompt_delta_reg"] = False
+        batch = G.shared_step_batch(4)
+        x0 = G.seeded((4, 4, 2, 2), 9)
+        img_mask = torch.nn.functional.interpolate(batch["aug_mask"][:, None], size=(2, 2), mode="nearest")
+        fg_mask = torch.nn.functional.interpolate(batch["fg_mask"][:, None], size=(2, 2), mode="nearest")
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        x_start, im, fm, captions = ConditioningMixin.prepare_recon_iteration(me, batch, x0, img_mask, fg_mask)
+        got = G.flags_record(me.iter_flags, x_start, captions, me.embedding_manager.calls)
+        got["after"] = [random.random(), float(np.random.rand())]
+        for k, v in want.items():
+            g = got[k]
+            if k == "embman_names":
+                g = [list(g[0]), g[1]]
+            assert g == v, (kind, seed, k, g, v)
+        seen.add((want["gen_arc2face_rand_face"], want["add_noise_to_real_id_embs"], want["use_arc2face_as_target"],
+                  want["num_denoising_steps"] > 1))
+    assert len(seen) >= 4          # the seeds cover random faces, noised ids, both targets, single- and multi-step
