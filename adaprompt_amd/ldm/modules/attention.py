@@ -67,6 +67,22 @@ class BasicTransformerBlock(nn.Module):
         self.checkpoint = checkpoint
 
 
+class KeyMasks:
+    """img_mask [B,1,h,w] -> the self-attention key mask [B, H*W] uint8 of a level (attention.py:223-232, :332: nearest
+    resize, != 0), computed once per resolution and forward instead of once per transformer."""
+
+    def __init__(self, img_mask):
+        self.img_mask = img_mask
+        self._by_res = {}
+
+    def at(self, H, W):
+        m = self._by_res.get((H, W))
+        if m is None:
+            m2 = F.interpolate(self.img_mask.float(), size=(H, W), mode="nearest")
+            m = self._by_res[(H, W)] = (m2.reshape(m2.shape[0], H * W) != 0).to(torch.uint8).contiguous()
+        return m
+
+
 class SpatialTransformer(nn.Module):
     """forward(x, context, mask): x pixel-major [B,H,W,C] f32; ``context`` is a tensor, a
     (v_context, k_context) tuple or -- as UNetModel passes it -- a callable returning
@@ -136,8 +152,8 @@ class SpatialTransformer(nn.Module):
         v_ctx = k_ctx if same else v_ctx.contiguous().float()
         key_mask = None
         if mask is not None:
-            m2 = F.interpolate(mask.float(), size=(H, W), mode="nearest")
-            key_mask = (m2.reshape(B, H * W) != 0).to(torch.uint8).contiguous()
+            # UNetModel.forward hands over a per-resolution cache (KeyMasks): the 16 transformers run at 4 resolutions
+            key_mask = mask.at(H, W) if hasattr(mask, "at") else KeyMasks(mask).at(H, W)
         capture = bool(blk.attn2.save_attn_vars)
         # token weights [B, 77, G] set by UNetModel.forward when the conditioning side names the subject / background
         # token positions: the capture then also returns the per-head token maps (functional / ops.attention_capture)

@@ -323,11 +323,17 @@ class UNetModel(nn.Module):
         M2, Cctx = context.shape[-2], context.shape[-1]
         # [16*B, M, C] -> [16, B, M, C]: one small copy, so every layer's context is a packed view
         ctx_l = context.reshape(B, 16, M2, Cctx).permute(1, 0, 2, 3).contiguous().float()
+        # unbind, not 16 x select: its backward is ONE stack of the 16 layers' gradients (a select's backward materialises
+        # a zero [16,B,M,C] tensor per layer and autograd then adds the 16 of them)
+        ctx_layers = ctx_l.unbind(0)
+        if img_mask is not None:
+            from ..attention import KeyMasks
+            img_mask = KeyMasks(img_mask)
 
         def get_layer_context(layer_idx):
             if layer_idx not in LAYER2CA:
                 return None, None
-            c = ctx_l[LAYER2CA[layer_idx]]
+            c = ctx_layers[LAYER2CA[layer_idx]]
             if iter_type == "mix_hijk":
                 v, k = c.chunk(2, dim=1)
                 return (v.contiguous(), k.contiguous()), placeholder2indices
