@@ -348,6 +348,312 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
 }
 
 // =============================================================================================
+// forward, ping-pong form (long sequences, short heads: the 64x64 level, N = 4096, d = 40)
+// =============================================================================================
+// At d = 40 a 64 x 64 score tile costs a wave 28 MFMAs (896 matrix-pipe cycles) and ~1100 cycles of softmax VALU issue
+// (66 v_exp at 8 cycles, 64 fma, 32 max3, 32 cvt): neither pipe can hide behind the other inside ONE wave's dependent
+// stream, and in the kernel above the two waves of a SIMD (different workgroups) drift through the same phases together
+// (MFMA pipe 27 % busy).  Here a workgroup is 8 waves = 512 queries, waves w and w + 4 share a SIMD, and the two halves run
+// HALF A TILE APART across one barrier per phase: while waves 0-3 exponentiate tile t (VALU), waves 4-7 multiply
+// (P V of tile t-1, then Q K^T of tile t: 28 back-to-back MFMAs), then they swap.  Every SIMD always has one wave in its
+// matrix phase and one in its vector phase.  K tiles are double-, V tiles and the key bias triple-buffered in LDS, staged
+// through registers one tile ahead by all 512 threads; the running max is only raised when it would grow by more than
+// 2^PP_THR (guide T13: the rescale of O then almost never runs; p <= 2^PP_THR stays exact in the f32 exponent path and
+// bf16 keeps its relative precision), which keeps the vector phase branch-free in the common case.
+#define PP_THR 5.0f
+
+template <int KS, int VT>
+__global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
+    using G = TileGeom<KS>;
+    constexpr int KSTRIDE = G::RSTRIDE;
+    constexpr int VSTRIDE = VGeom<VT>::VSTRIDE;
+    constexpr int NCH = G::NCH;
+    constexpr int KT = 64 * KSTRIDE, VTB = 64 * VSTRIDE;
+    static_assert(64 * NCH <= 512, "one 16-byte chunk per thread and tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                                    // [2][64][KSTRIDE]
+    char* sV = smem + 2 * KT;                           // [3][64][VSTRIDE]
+    float* sBiasAll = (float*)(smem + 2 * KT + 3 * VTB);  // [3][68]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2;                          // 0: waves 0-3, 1: waves 4-7 (the SIMD partners), half a tile behind
+    const int c = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
+    const int q0 = blockIdx.x * 512 + wave * 64 + c;    // query of block qb: q0 + 32 * qb
+    const int d = p.d;
+    const float cs = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            int ch = 2 * s + h, q = q0 + 32 * qb;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.N && ch * 8 < d) v = *(const uint4*)(p.q + ((size_t)b * p.N + q) * p.ldq + head * d + ch * 8);
+            qf[qb][s] = __builtin_bit_cast(bf16x8, v);
+        }
+    f32x16 O[2][VT];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[qb][vt][r] = 0.f;
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    const bool ones_col = 32 * VT > d && (d >> 3) < NCH;
+
+    const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
+    const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
+    const int ntiles = (p.M + 63) / 64;
+    // staging map: thread -> chunk (row, 16-byte column) of a 64-row tile
+    const int srow = tid / NCH, sch = tid - srow * NCH;
+    const bool sin = tid < 64 * NCH && sch * 8 < d;       // chunk holds data (else zero padding)
+    const bool slive = tid < 64 * NCH;
+    const bool sone = slive && ones_col && sch == (d >> 3);
+    uint4 rK = make_uint4(0, 0, 0, 0), rV = make_uint4(0, 0, 0, 0);
+    auto stage_load = [&](int s) {
+        const int key0 = s * 64, nvalid = min(64, p.M - key0);
+        rK = make_uint4(0, 0, 0, 0);
+        rV = make_uint4(0, 0, 0, 0);
+        if (sin && srow < nvalid) {
+            rK = *(const uint4*)(kb + (size_t)(key0 + srow) * p.ldk + sch * 8);
+            rV = *(const uint4*)(vb + (size_t)(key0 + srow) * p.ldv + sch * 8);
+        }
+        if (sone) rV.x = 0x3F80u;
+    };
+    auto stage_store = [&](int s) {
+        if (slive) {
+            *(uint4*)(sK + (s & 1) * KT + srow * KSTRIDE + sch * 16) = rK;
+            *(uint4*)(sV + (s % 3) * VTB + srow * VSTRIDE + sch * 16) = rV;
+        }
+        if (tid < 64) {
+            float* sBias = sBiasAll + (s % 3) * 68;
+            const int key = s * 64 + tid;
+            float bias = 0.f;
+            if (key >= p.M) bias = -INFINITY;
+            else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
+            sBias[tid] = bias;
+            unsigned long long any = __ballot(bias != 0.f);
+            if (tid == 0) sBias[64] = any ? 1.f : 0.f;
+        }
+    };
+    f32x16 S[2][2];
+    bf16x8 pf[2][2][2];
+    // The matrix phase as ONE software-pipelined stream of fragment groups: the LDS reads of group i + 1 are issued BEFORE
+    // the MFMAs of group i, so a read's latency hides under 2-4 MFMAs instead of stalling the pipe in front of every group
+    // (left to itself hipcc sinks each ds_read to just above its first use: 14 exposed LDS round trips per tile).
+    //   groups 0..3  : P V of tile t, (tt, sh) = (g >> 1, g & 1): VT transposed V fragments, 2 * VT MFMAs
+    //   groups 4..4+2*KS-1 : Q K^T of tile t + 1, (tt, s) = ((g-4) / KS, (g-4) % KS): one K fragment, 2 MFMAs
+    auto v_frag = [&](const char* vt_, int g, int vt) { return lds_tr_frag(vt_, VSTRIDE, 32 * (g >> 1) + 16 * (g & 1), 32 * vt, lane); };
+    auto k_frag = [&](const char* kt, int g) {
+        const int tt = g / KS, s = g - tt * KS;
+        return *(const bf16x8*)(kt + (32 * tt + c) * KSTRIDE + (2 * s + h) * 16);
+    };
+    auto mm_phase = [&](int t, bool do_pv, bool do_qk) {
+        const char* vt_ = sV + (t % 3) * VTB;
+        const char* kt = sK + ((t + 1) & 1) * KT;
+        bf16x8 vcur[VT], vnext[VT], kcur, knext;
+        if (do_pv) {
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) vcur[vt] = v_frag(vt_, 0, vt);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) {
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) vnext[vt] = v_frag(vt_, g + 1, vt);
+                } else if (do_qk) {
+                    knext = k_frag(kt, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+                        O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[vt], pf[qb][g >> 1][g & 1], O[qb][vt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) vcur[vt] = vnext[vt];
+            }
+        } else if (do_qk) {
+            knext = k_frag(kt, 0);
+        }
+        if (do_qk) {
+#pragma unroll
+            for (int g = 0; g < 2 * KS; ++g) {
+                kcur = knext;
+                if (g + 1 < 2 * KS) knext = k_frag(kt, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int tt = g / KS, s = g - tt * KS;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (s == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        S[qb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[qb][s], z, 0, 0, 0);
+                    } else {
+                        S[qb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur, qf[qb][s], S[qb][tt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto softmax = [&](int t) {                             // S -> P (bf16 fragments), running max with a threshold
+        const float* sBias = sBiasAll + (t % 3) * 68;
+        const bool biased = sBias[64] != 0.f;               // wave-uniform: ragged / masked tile
+        if (biased) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float4 bv = *(const float4*)(sBias + 32 * tt + 8 * g + 4 * h);
+                        S[qb][tt][4 * g] += bv.x; S[qb][tt][4 * g + 1] += bv.y;
+                        S[qb][tt][4 * g + 2] += bv.z; S[qb][tt][4 * g + 3] += bv.w;
+                    }
+        }
+        // both query blocks in ONE straight-line region (their chains interleave), one rare branch for the rescale
+        float mcand[2];
+        bool grow[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][tt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mcand[qb] = mx * cs;                            // exp2 domain (cs > 0)
+            // raise the reference point only when the row's max outgrows it by more than 2^PP_THR (or it is still -inf)
+            grow[qb] = mcand[qb] > m[qb] + PP_THR;
+        }
+        if (__any(grow[0] || grow[1])) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float mnew = grow[qb] ? mcand[qb] : m[qb];
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);      // 1 for rows that keep their reference
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
+                l[qb] *= alpha;
+                m[qb] = mnew;
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[qb][tt][r] = fmaf(S[qb][tt][r], cs, -m[qb]);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[qb][tt][r] = __builtin_amdgcn_exp2f(S[qb][tt][r]);
+        if (!ones_col) {                                    // (d = 40, 80: the denominator comes out of the P V MFMA)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float psum = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) psum += S[qb][tt][r];
+                l[qb] += psum;
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) pf[qb][tt][sh] = acc_to_frag(S[qb][tt], sh);
+    };
+
+    // ---- prologue: tiles 0 and 1 in LDS, S(0) in registers
+    stage_load(0);
+    stage_store(0);
+    if (ntiles > 1) {
+        stage_load(1);
+        stage_store(1);
+    }
+    __syncthreads();
+    mm_phase(-1, false, true);                              // S = K(0) Q^T
+    // ---- phases: group g exponentiates tile t in phase 2t + g and multiplies (P V of t, Q K^T of t + 1) in phase 2t + 1 + g
+    const int nphases = 2 * ntiles + 1;
+    // diagnostic (tools/attn_stamps.py): workgroup (0,0)'s waves 0 and 4 stamp every phase: entry, work done, barrier passed
+    unsigned long long* stamps = (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0)
+                                     ? (unsigned long long*)p.part : nullptr;
+    for (int ph = 0; ph < nphases; ++ph) {
+        if (stamps) stamps[(ph * 2 + grp) * 3 + 0] = __builtin_amdgcn_s_memtime();
+        if ((ph & 1) == 0) {                                // tile ph/2 + 2 starts its trip to LDS
+            const int s = (ph >> 1) + 2;
+            if (s < ntiles) stage_load(s);
+        }
+        const int r = ph - grp;
+        if (r >= 0 && (r >> 1) < ntiles) {
+            const int t = r >> 1;
+            if ((r & 1) == 0) {
+                __builtin_amdgcn_s_setprio(0);
+                softmax(t);
+            } else {
+                // the matrix phase issues first: its 28 MFMAs take 8 issue cycles each and keep the pipe busy for 32; left at equal
+                // priority the vector-phase partner (when it is the older wave) starves them (stamps: 2340 vs 1590 ticks)
+                __builtin_amdgcn_s_setprio(2);
+                mm_phase(t, true, t + 1 < ntiles);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        if (ph & 1) {                                       // ... and lands: its buffers' last readers passed the previous barrier
+            const int s = (ph + 3) >> 1;
+            if (s < ntiles) stage_store(s);
+        }
+        if (stamps) stamps[(ph * 2 + grp) * 3 + 1] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (stamps) stamps[(ph * 2 + grp) * 3 + 2] = __builtin_amdgcn_s_memtime();
+    }
+    // ---- epilogue (as in attn_fwd_kernel)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + 32 * qb;
+        float ltot;
+        if (ones_col) {
+            const int vt0 = d >> 5, rin = d & 31, hh = (rin >> 2) & 1, reg = (rin & 3) + 4 * (rin >> 3);
+            float lv = 0.f;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (vt == vt0 && r == reg) lv = O[qb][vt][r];
+            ltot = __shfl(lv, c + 32 * hh, 64);
+        } else {
+            ltot = l[qb] + __shfl_xor(l[qb], 32, 64);
+        }
+        const float inv = 1.0f / ltot;
+        if (q < p.N) {
+            uint16_t* orow = p.o + ((size_t)b * p.N + q) * p.ldo + head * d;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int d0 = 32 * vt + 8 * g + 4 * h;
+                    if (d0 < d) {
+                        uint2 w;
+                        w.x = pack_bf16x2(O[qb][vt][4 * g] * inv, O[qb][vt][4 * g + 1] * inv);
+                        w.y = pack_bf16x2(O[qb][vt][4 * g + 2] * inv, O[qb][vt][4 * g + 3] * inv);
+                        *(uint2*)(orow + d0) = w;
+                    }
+                }
+            if (h == 0 && p.lse) p.lse[((size_t)b * p.H + head) * p.N + q] = (m[qb] + log2f(ltot)) * 0.6931471805599453f;
+        }
+    }
+}
+
+// =============================================================================================
 // backward, part 0: delta[b][h][n] = sum_d dO * O      (one wave per token row)
 // =============================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, long ldo,
@@ -734,6 +1040,10 @@ static int dkv_qsplit(int B, int H, int N, int M, int d) {
 // =============================================================================================
 // host dispatch
 // =============================================================================================
+static void* g_attn_stamps = nullptr;
+extern "C" int adap_attention_set_stamp_buffer(void* buf) { g_attn_stamps = buf; return ADAP_OK; }
+static int g_attn_fwd_variant = 0;       // 1 / 2: attn_fwd_kernel with QB = 1 / 2 query blocks per wave; 3: ping-pong kernel
+
 template <int KS, int VT, int QB>
 static int launch_fwd_q(const AttnParams& p, hipStream_t s) {
     size_t lds = 2 * (64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE) + 2 * 68 * 4;
@@ -744,11 +1054,34 @@ static int launch_fwd_q(const AttnParams& p, hipStream_t s) {
     }
     dim3 grid((p.N + 128 * QB - 1) / (128 * QB), p.B * p.H);
     hipLaunchKernelGGL((attn_fwd_kernel<KS, VT, QB>), grid, dim3(256), lds, s, p);
+    g_attn_fwd_variant = QB;
     return adap_check_launch("attn_fwd");
 }
 
 template <int KS, int VT>
+static int launch_fwd_pp(const AttnParams& p, hipStream_t s) {
+    size_t lds = 2 * 64 * TileGeom<KS>::RSTRIDE + 3 * 64 * VGeom<VT>::VSTRIDE + 3 * 68 * 4;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<KS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.N + 511) / 512, p.B * p.H);
+    AttnParams pp = p;
+    pp.part = (float*)g_attn_stamps;          // diagnostic stamps (null in normal runs)
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<KS, VT>), grid, dim3(512), lds, s, pp);
+    g_attn_fwd_variant = 3;
+    return adap_check_launch("attn_fwd (ping-pong)");
+}
+
+template <int KS, int VT>
 static int launch_fwd(const AttnParams& p, hipStream_t s) {
+    // long sequences with short heads: the ping-pong kernel, when its 512-query workgroups still fill the chip
+    if constexpr (KS <= 4) {
+        if (getenv("ADAP_ATTN_FORCE_PP") ||
+            (!getenv("ADAP_ATTN_NO_PP") && p.M >= 512 && (long)((p.N + 511) / 512) * p.B * p.H >= 192))
+            return launch_fwd_pp<KS, VT>(p, s);
+    }
     // two query blocks per wave when that still leaves >= 2 workgroups per CU's worth of work (the 64x64 level)
     if (KS <= 4 && (long)((p.N + 255) / 256) * p.B * p.H >= 512) return launch_fwd_q<KS, VT, 2>(p, s);
     return launch_fwd_q<KS, VT, 1>(p, s);
@@ -806,6 +1139,8 @@ extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long l
     p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
     ATTN_DISPATCH(launch_fwd, p, (hipStream_t)stream);
 }
+
+extern "C" int adap_attention_fwd_last_variant(void) { return g_attn_fwd_variant; }
 
 extern "C" long adap_attention_bwd_workspace_floats(int B, int H, int N, int M, int d) {
     long delta = ((long)B * H * N + 3) & ~3L;

@@ -131,6 +131,12 @@ int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, con
 int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                        const uint8_t* key_mask, void* out, long ldo, float* lse,
                        int B, int H, int N, int M, int d, float scale, void* stream);
+/* which forward kernel the last adap_attention_fwd dispatched to: 1 / 2 = query-stationary kernel with 1 / 2 query blocks per
+ * wave, 3 = the ping-pong kernel (512-query workgroups, SIMD partners half a tile apart; N >= 512 keys, d <= 64) */
+int adap_attention_fwd_last_variant(void);
+/* Diagnostic (tools/attn_stamps.py): with a non-NULL device buffer of 6 * (2 * ceil(M/64) + 1) uint64, workgroup (0,0) of the
+ * ping-pong forward stores shader-clock stamps (entry / work done / barrier passed) per phase and wave half.  NULL = off. */
+int adap_attention_set_stamp_buffer(void* buf);
 /* dq/dk/dv as f32 and/or bf16; workspace: adap_attention_bwd_workspace_floats(...) floats of scratch (the row
  * dots delta = sum(dO * O) and, when few key blocks exist -- cross attention, M = 77 -- the f32 partials of the
  * query-split dK/dV pass, summed in a fixed order). */

@@ -346,6 +346,41 @@ ATTN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(2, 8, 300, 333, 40, True), (1, 8, 1024, 1024, 40, False), (2, 8, 520, 77, 40, False),
+                                  (1, 8, 64, 64, 32, False), (2, 8, 96, 40, 8, False), (1, 8, 700, 700, 64, True),
+                                  (4, 8, 4096, 4096, 40, False)])
+def test_attention_fwd_ping_pong_kernel(case):
+    """the ping-pong forward (8-wave workgroups, SIMD partners half a tile apart, thresholded running max) on ragged,
+    masked, single-tile and full-size shapes: output and LSE against fp32 torch, and against the query-stationary kernel."""
+    import os
+    from adaprompt_amd import _lib
+    B, H, N, M, d, use_mask = case
+    C = H * d
+    q, k, v = bf(rnd(B, N, C, seed=1)), bf(rnd(B, M, C, seed=2)), bf(rnd(B, M, C, seed=3))
+    mask = None
+    if use_mask:
+        mask = (torch.rand(B, M, generator=torch.Generator().manual_seed(5)) > 0.3).to(dev())
+        mask[:, 0] = True
+    km = mask.to(torch.uint8).contiguous() if mask is not None else None
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    os.environ["ADAP_ATTN_FORCE_PP"] = "1"
+    try:
+        out, lse = ops.attention_fwd(qb, kb, vb, H, km)
+        assert _lib.call_long("adap_attention_fwd_last_variant") == 3
+    finally:
+        os.environ.pop("ADAP_ATTN_FORCE_PP", None)
+    os.environ["ADAP_ATTN_NO_PP"] = "1"
+    try:
+        out0, lse0 = ops.attention_fwd(qb, kb, vb, H, km)
+        assert _lib.call_long("adap_attention_fwd_last_variant") in (1, 2)
+    finally:
+        os.environ.pop("ADAP_ATTN_NO_PP", None)
+    ref, sim, _ = ref_attention(q, k, v, H, mask)
+    assert rel(out.float(), ref) < 6e-3, rel(out.float(), ref)
+    assert rel(lse, torch.logsumexp(sim, dim=-1)) < 1e-4
+    assert rel(out.float(), out0.float()) < 6e-3 and rel(lse, lse0) < 1e-4       # two roundings of the same bf16 P sums
+
+
 @pytest.mark.parametrize("case", ATTN_CASES)
 def test_attention_fwd_bwd(case):
     B, H, N, M, d, use_mask = case

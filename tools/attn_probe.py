@@ -30,4 +30,5 @@ for (B, H, N, M, d) in [(4, 8, 4096, 4096, 40), (4, 8, 1024, 1024, 80), (4, 8, 2
     torch.cuda.synchronize()
     f = 4.0 * B * H * N * M * d
     t1, t2 = e[0].elapsed_time(e[1]) / 5, e[1].elapsed_time(e[2]) / 5
-    print(f"N={N} M={M} d={d}: fwd {t1 * 1e3:7.1f} us {f / t1 / 1e9:6.1f} TF/s   bwd {t2 * 1e3:7.1f} us {2.5 * f / t2 / 1e9:6.1f} TF/s (2.5x fwd flops)")
+    from adaprompt_amd import _lib
+    print(f"[fwd variant {_lib.call_long('adap_attention_fwd_last_variant')}] N={N} M={M} d={d}: fwd {t1 * 1e3:7.1f} us {f / t1 / 1e9:6.1f} TF/s   bwd {t2 * 1e3:7.1f} us {2.5 * f / t2 / 1e9:6.1f} TF/s (2.5x fwd flops)")
