@@ -590,6 +590,111 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             tot[3] = tot[3] + (h4[2] + h4[3]) * 0.05
         return tuple(tot)
 
+    # ---- Stage 2: losses of a compositional-distillation iteration (ddpm.py:3714-3930, 4389-4551) ----------------------
+    MIX_LAYER_WEIGHTS = {7: 0.5, 8: 0.5, 12: 1., 16: 1., 17: 1., 18: 1., 19: 1., 20: 1., 21: 1., 22: 1., 23: 1., 24: 1.}
+    FEAT_SIZE2POOLER = {8: (4, 2), 16: (4, 2), 32: (8, 4), 64: (8, 4)}
+
+    def calc_prompt_mix_loss(self, ca_outfeats, ca_outfeat_lns, ca_attnscores, fg_indices_2b, BLOCK_SIZE):
+        """The batch is four blocks: (subject single, subject comp, mix single, mix comp).  What composing does to the
+        subject's features should be what it does to the class-mixed ("mix") features:
+          * feat_delta_align: per layer, the pooled output features, weighted down where the subject attends, subject minus
+            its projection on mix -- the comp delta against the single delta, orthogonal L2;
+          * subj_attn_delta_align: the same for the subject tokens' score maps (cosine, exponent 3);
+          * subj_attn_norm_distill: L1 between the mean subject scores of the subject and the mix instances.
+        Mix-side gradients are scaled by 0.1 (features) / 0.05 (scores).  -> the three sums over layers (normalised weights)."""
+        from ...stage2 import calc_delta_alignment_loss, convert_attn_to_spatial_weight, double_token_indices, ortho_l2loss
+        from ...util import gen_gradient_scaler, normalize_dict_values, normalized_sum, ortho_subtract
+        w_layers = normalize_dict_values(dict(LatentDiffusion.MIX_LAYER_WEIGHTS))
+        K_fg = len(fg_indices_2b[0]) // len(torch.unique(fg_indices_2b[0]))
+        fg_indices_4b = double_token_indices(fg_indices_2b, BLOCK_SIZE * 2)
+        feat_gs, attn_gs = gen_gradient_scaler(0.1), gen_gradient_scaler(0.05)
+        l_attn_delta, l_feat_delta, l_attn_norm = [], [], []
+        for li, ca_outfeat in ca_outfeats.items():
+            if li not in w_layers:
+                continue
+            w = w_layers[li]
+            if ca_outfeat_lns is not None:
+                ca_outfeat = ca_outfeat_lns[str(li)](ca_outfeat.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            score = ca_attnscores[li].permute(0, 3, 1, 2)                                   # [4B, 77, heads, N]
+            subj_attn_4b = score[fg_indices_4b].reshape(BLOCK_SIZE * 4, K_fg, *score.shape[2:]).sum(dim=1)
+            ss_attn, sc_attn, ms_attn, mc_attn = subj_attn_4b.chunk(4)
+            mc_attn_gs, ms_attn_gs = attn_gs(mc_attn), attn_gs(ms_attn)
+            d = calc_delta_alignment_loss(ss_attn, sc_attn, ms_attn, mc_attn, ref_grad_scale=0.05, feat_base_grad_scale=1,
+                                          use_cosine_loss=True, cosine_exponent=3, delta_types=["feat_to_ref"])
+            l_attn_delta.append(d["feat_to_ref"] * w)
+            l_attn_norm.append(((sc_attn.mean(dim=-1) - mc_attn_gs.mean(dim=-1)).abs().mean()
+                                + (ss_attn.mean(dim=-1) - ms_attn_gs.mean(dim=-1)).abs().mean()) * w)
+            hw = ca_outfeat.shape[2:]
+            sw_mix, _ = convert_attn_to_spatial_weight(mc_attn, BLOCK_SIZE, hw, reversed=True)
+            sw_subj, _ = convert_attn_to_spatial_weight(sc_attn, BLOCK_SIZE, hw, reversed=True)
+            feat = ca_outfeat * ((sw_mix + sw_subj) / 2)
+            k, st = LatentDiffusion.FEAT_SIZE2POOLER[feat.shape[-1]]
+            feat_2d = F.avg_pool2d(feat, k, stride=st).reshape(feat.shape[0], -1)
+            ss_f, sc_f, ms_f, mc_f = feat_2d.chunk(4)
+            comp_delta = ortho_subtract(sc_f, feat_gs(mc_f))
+            single_delta = ortho_subtract(ss_f, feat_gs(ms_f))
+            l_feat_delta.append(ortho_l2loss(comp_delta, single_delta, mean=True) * w)
+        return normalized_sum(l_feat_delta), normalized_sum(l_attn_delta), normalized_sum(l_attn_norm)
+
+    def calc_comp_fg_bg_preserve_loss(self, ca_outfeats, ca_outfeat_lns, ca_qs, ca_q_bns, ca_attnscores, fg_mask,
+                                      batch_have_fg_mask, subj_indices, BLOCK_SIZE):
+        """Elastic matching between the comp and the single instances (``stage2.calc_elastic_matching_loss`` on the pooled
+        queries / output features of every layer) + suppression of the subject tokens' scores on what the matching calls
+        background.  -> (comp_single_map_align, sc_ss_fg_match, mc_ms_fg_match (= 0, disabled in the reference),
+        sc_mc_bg_match, comp_subj_bg_attn_suppress, comp_mix_bg_attn_suppress)."""
+        from ...stage2 import calc_elastic_matching_loss
+        from ...util import gen_gradient_scaler, masked_mean, normalize_dict_values, normalized_sum, resize_mask_for_feat_or_attn
+        if fg_mask is None or batch_have_fg_mask.sum() == 0:
+            return 0, 0, 0, 0, 0, 0
+        w_layers = normalize_dict_values(dict(LatentDiffusion.MIX_LAYER_WEIGHTS))
+        fg_mask_4b = fg_mask * batch_have_fg_mask.view(-1, 1, 1, 1)
+        K_fg = len(subj_indices[0]) // len(torch.unique(subj_indices[0]))
+        ib1, it1 = subj_indices[0][:BLOCK_SIZE * K_fg], subj_indices[1][:BLOCK_SIZE * K_fg]
+        ind_B = torch.cat([ib1 + i * BLOCK_SIZE for i in range(4)], dim=0)
+        ind_N = it1.repeat(4)
+        mix_gs = gen_gradient_scaler(0.02)
+        l_map, l_scss, l_scmc, l_sbg, l_mbg = [], [], [], [], []
+        for li, ca_outfeat in ca_outfeats.items():
+            if li not in w_layers:
+                continue
+            w = w_layers[li]
+            q = ca_qs[li]                                                                    # [4B, heads, N, d]
+            qh = int(np.sqrt(q.shape[2] * ca_outfeat.shape[2] // ca_outfeat.shape[3]))
+            qw = q.shape[2] // qh
+            q = q.permute(0, 1, 3, 2).reshape(q.shape[0], -1, qh, qw)
+            if ca_q_bns is not None:
+                q = ca_q_bns[str(li)](q)
+            if ca_outfeat.shape[2:] != q.shape[2:]:
+                ca_outfeat = F.interpolate(ca_outfeat, size=q.shape[2:], mode="bilinear", align_corners=False)
+            if ca_outfeat_lns is not None:
+                ca_outfeat = ca_outfeat_lns[str(li)](ca_outfeat.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            pool = (lambda x: F.avg_pool2d(x, 4, stride=2)) if ca_outfeat.shape[-1] > 8 else (lambda x: x)
+            q_p = pool(q).reshape(*q.shape[:2], -1)
+            f_p = pool(ca_outfeat).reshape(*ca_outfeat.shape[:2], -1)
+            m4 = resize_mask_for_feat_or_attn(ca_outfeat, fg_mask_4b, "fg_mask_4b", num_spatial_dims=2, mode="nearest|bilinear")
+            m_p = pool(m4).chunk(4)[0]
+            m_p = m_p.reshape(*m_p.shape[:2], -1)
+            lm, lf, lb, sc_below, mc_below = calc_elastic_matching_loss(q_p, f_p, m_p, fg_bg_cutoff_prob=0.25,
+                                                                        single_q_grad_scale=0.1, single_feat_grad_scale=0.01,
+                                                                        mix_feat_grad_scale=0.05)
+            l_map.append(lm * w)
+            l_scss.append(lf * w)
+            l_scmc.append(lb * w)
+            if sc_below is None or mc_below is None:
+                continue
+            score = ca_attnscores[li].permute(0, 3, 1, 2)
+            subj_attn = score[ind_B, ind_N].reshape(BLOCK_SIZE * 4, K_fg, *score.shape[2:]).sum(dim=1)
+            H = int(np.sqrt(subj_attn.shape[-1]))
+            a_hw = subj_attn.reshape(*subj_attn.shape[:2], H, H)
+            if a_hw.shape[2:] != ca_outfeat.shape[2:]:
+                a_hw = F.interpolate(a_hw, size=ca_outfeat.shape[2:], mode="bilinear", align_corners=False)
+            a_p = pool(a_hw).reshape(*a_hw.shape[:2], -1)
+            _, sc_a, _, mc_a = a_p.chunk(4)
+            l_sbg.append(masked_mean(sc_a.clamp(min=0), sc_below) * w)
+            l_mbg.append(masked_mean(mix_gs(mc_a).clamp(min=0), mc_below) * w)
+        return (normalized_sum(l_map), normalized_sum(l_scss), 0, normalized_sum(l_scmc), normalized_sum(l_sbg),
+                normalized_sum(l_mbg))
+
     # ---- Arc2Face distillation: teacher rollout + multi-step student loss (ddpm.py:2950-3039) ------------------
     MAX_ACCUMU_BATCH_SIZE = 7
 

@@ -121,6 +121,27 @@ def shared_step_batch(B=4):
             "cls_prompt_single_bg": bgify(cs), "cls_prompt_comp_bg": bgify(cc)}
 
 
+# ---- stage-2 cases (shared with tests/test_stage2_golden.py) --------------------------------------------------------------
+STAGE2_LAYERS = {7: (16, 16), 12: (8, 8), 18: (16, 32), 21: (32, 64)}        # layer -> (attention side, outfeat side)
+
+
+def stage2_case(seed=300, C=8, heads=2, d=4):
+    """one instance x 4 blocks (subject single, subject comp, mix single, mix comp): captured outfeat / attnscore / q of
+    four layers (two of them with the output upsampled behind the transformer), subject token positions, foreground mask."""
+    outfeat = {li: seeded((4, C, so, so), seed + li) for li, (_, so) in STAGE2_LAYERS.items()}
+    score = {li: seeded((4, heads, sa * sa, 77), seed + 50 + li, 1.5) for li, (sa, _) in STAGE2_LAYERS.items()}
+    q = {li: seeded((4, heads, sa * sa, d), seed + 100 + li) for li, (sa, _) in STAGE2_LAYERS.items()}
+    subj_1b = (torch.zeros(9, dtype=torch.long), torch.arange(4, 13))
+    subj_2b = (torch.cat([torch.zeros(9, dtype=torch.long), torch.ones(9, dtype=torch.long)]), torch.arange(4, 13).repeat(2))
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 64), indexing="ij")
+    fg = ((xx / 0.55) ** 2 + (yy / 0.7) ** 2 <= 1.0).float()[None, None].repeat(4, 1, 1, 1)
+    return outfeat, score, q, subj_1b, subj_2b, fg
+
+
+def grad_norms(tensors):
+    return np.array([0.0 if t.grad is None else float(t.grad.double().norm()) for t in tensors])
+
+
 SHARED_STEP_CASES = [("recon", False, 11), ("recon", False, 12), ("distill", True, 21), ("distill", True, 22), ("distill", True, 23),
                      ("distill", True, 24), ("distill", True, 25), ("distill", True, 26)]
 
@@ -141,6 +162,11 @@ def flags_record(fl, x_start, captions, em_calls):
     out["a2f"] = None if fl.get("arc2face_prompt_emb") is None else list(fl["arc2face_prompt_emb"].shape)
     out["embman_names"] = [c for c in em_calls if c[0] == "set_curr_batch_subject_names"][-1][1:]
     return out
+
+
+def json_dumps(x):
+    import json
+    return json.dumps(x)
 
 
 def main():
@@ -241,6 +267,87 @@ def main():
         rec[f"rollout/{nd}/pred_last"] = preds[-1].numpy()
         rec[f"rollout/{nd}/x0_last"] = x0s[-1].numpy()
         rec[f"rollout/{nd}/noise_last"] = noises[-1].numpy()
+    # ---- H: stage 2 (compositional distillation): ldm/util.py functions and the two ddpm.py loss methods
+    import random as _random
+    import ldm.util as U
+    assert U.__file__.startswith(REF)
+    emb = seeded((2 * 2 * 16, 77, 12), 200, 0.3).requires_grad_(True)          # BS = 2: (subject half | class half)
+    for tag, kw in (("a", dict(training_percent=0.25, t_frac=torch.tensor([0.9, 0.85]), K=[1.0, 0.8], V=[1.0, 0.6])),
+                    ("b", dict(training_percent=0.8, t_frac=torch.tensor([0.55, 0.95]), K=[1.0, 1.0], V=[1.0, 0.7]))):
+        emb.grad = None
+        out, _, v_sc, _, k_sc = U.mix_static_vk_embeddings(emb, torch.arange(4, 13), kw["training_percent"], t_frac=kw["t_frac"],
+                                                           use_layerwise_embedding=True, N_CA_LAYERS=16,
+                                                           K_CLS_SCALE_LAYERWISE_RANGE=kw["K"], V_CLS_SCALE_LAYERWISE_RANGE=kw["V"])
+        (out * seeded(tuple(out.shape), 201)).sum().backward()
+        rec[f"s2/mixvk/{tag}/out"] = out.detach().numpy()
+        rec[f"s2/mixvk/{tag}/grad"] = emb.grad.numpy().copy()
+        rec[f"s2/mixvk/{tag}/scales"] = np.stack([v_sc.numpy(), k_sc.numpy()])
+    rec["s2/cfg_scales"] = U.gen_cfg_scales_for_stu_tea(6, 5, 2, "cpu").numpy()
+    rec["s2/dyn_scale"] = np.array([U.calc_dyn_loss_scale(torch.tensor(v), 0.2, 2, min_scale_base_ratio=1, max_scale_base_ratio=3)
+                                    for v in (0.05, 0.3, 0.9)])
+    # elastic matching on pooled maps
+    qe, fe = seeded((4, 10, 49), 210).requires_grad_(True), seeded((4, 14, 49), 211).requires_grad_(True)
+    me = (torch.rand(1, 1, 49, generator=torch.Generator().manual_seed(212)) > 0.55).float()
+    lm, lf, lb, scb, mcb = U.calc_elastic_matching_loss(qe, fe, me, fg_bg_cutoff_prob=0.25, single_q_grad_scale=0.1,
+                                                        single_feat_grad_scale=0.01, mix_feat_grad_scale=0.05)
+    (lm + lf + lb).backward()
+    rec["s2/elastic/losses"] = np.array([float(lm), float(lf), float(lb)])
+    rec["s2/elastic/below"] = np.stack([scb.detach().numpy(), mcb.detach().numpy()])
+    rec["s2/elastic/grad_q"], rec["s2/elastic/grad_f"] = qe.grad.numpy(), fe.grad.numpy()
+    # delta alignment, spatial weights
+    fb, fx, rb, rx = (seeded((1, 2, 64), 220 + i).requires_grad_(True) for i in range(4))
+    dl = U.calc_delta_alignment_loss(fb, fx, rb, rx, ref_grad_scale=0.05, feat_base_grad_scale=1, use_cosine_loss=True,
+                                     cosine_exponent=3, delta_types=["feat_to_ref"])["feat_to_ref"]
+    dl.backward()
+    rec["s2/delta/loss"] = np.float64(float(dl))
+    rec["s2/delta/gnorm"] = grad_norms([fb, fx, rb, rx])
+    sw, sa = U.convert_attn_to_spatial_weight(seeded((2, 2, 256), 230, 1.0) + 0.5, 1, torch.Size([32, 32]), reversed=True)
+    rec["s2/spatial_weight"], rec["s2/spatial_attn"] = sw.numpy(), sa.numpy()
+    # the compositional iteration's initial latent
+    for tag, pct in (("big", 0.6), ("small", 0.25)):
+        np.random.seed(77)
+        torch.manual_seed(77)
+        x0 = seeded((2, 4, 64, 64), 240)
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, 64), torch.linspace(-1, 1, 64), indexing="ij")
+        fgm = ((xx / pct) ** 2 + (yy / pct) ** 2 <= 1.0).float()[None, None].repeat(2, 1, 1, 1)
+        xi, m1, m2 = U.init_x_with_fg_from_training_image(x0, fgm, fgm.clone(), 0.4, base_scale_range=(0.7, 1.0),
+                                                          fg_noise_anneal_mean_range=(0.1, 0.4))
+        rec[f"s2/initx/{tag}/x"], rec[f"s2/initx/{tag}/fg"] = xi.numpy(), m1.numpy()
+        rec[f"s2/initx/{tag}/after"] = np.array([float(np.random.rand()), float(torch.rand(1))])
+    # the two loss methods of ddpm.py
+    outfeat, score, qq, subj_1b, subj_2b, fg4 = stage2_case()
+    leaves = {k: {li: v.clone().requires_grad_(True) for li, v in dct.items()} for k, dct in
+              (("outfeat", outfeat), ("score", score), ("q", qq))}
+    l_feat, l_attn_delta, l_attn_norm = D.LatentDiffusion.calc_prompt_mix_loss(m, leaves["outfeat"], None, leaves["score"], subj_2b, 1)
+    (l_feat + l_attn_delta + l_attn_norm).backward()
+    rec["s2/prompt_mix/losses"] = np.array([float(l_feat), float(l_attn_delta), float(l_attn_norm)])
+    rec["s2/prompt_mix/gnorm_outfeat"] = grad_norms([leaves["outfeat"][li] for li in STAGE2_LAYERS])
+    rec["s2/prompt_mix/gnorm_score"] = grad_norms([leaves["score"][li] for li in STAGE2_LAYERS])
+    leaves = {k: {li: v.clone().requires_grad_(True) for li, v in dct.items()} for k, dct in
+              (("outfeat", outfeat), ("score", score), ("q", qq))}
+    have = torch.ones(4)
+    ls = D.LatentDiffusion.calc_comp_fg_bg_preserve_loss(m, leaves["outfeat"], None, leaves["q"], None, leaves["score"], fg4, have,
+                                                         subj_1b, 1)
+    sum(l for l in ls if torch.is_tensor(l)).backward()
+    rec["s2/preserve/losses"] = np.array([float(l) for l in ls])
+    for k in ("outfeat", "score", "q"):
+        rec[f"s2/preserve/gnorm_{k}"] = grad_norms([leaves[k][li] for li in STAGE2_LAYERS])
+    ls0 = D.LatentDiffusion.calc_comp_fg_bg_preserve_loss(m, outfeat, None, qq, None, score, fg4, torch.zeros(4), subj_1b, 1)
+    rec["s2/preserve/no_mask"] = np.array([float(l) for l in ls0])
+    # teacher selection (calc_clip_losses, ddpm.py:3636-3679) with a scripted CLIP evaluator
+    sel = []
+    for losses in ([0.30, 0.27, 0.26, 0.20], [0.25, 0.26, 0.27, 0.29], [0.31, 0.30, 0.279, 0.2795]):
+        fake = types.SimpleNamespace(iter_flags={"do_teacher_filter": True, "reuse_init_conds": False}, num_candidate_teachers=2,
+                                     num_total_teacher_filter_iters=0, num_teachable_iters=0, num_total_reuse_filter_iters=0.001,   # ddpm.py:300-303
+                                     num_reuse_teachable_iters=0)
+        fake.decode_first_stage = lambda z: z
+        fake.clip_evaluator = types.SimpleNamespace(txt_to_img_similarity=lambda prompts, images, reduction, _l=losses: 0.5 - torch.tensor(_l))
+        try:
+            _imgs, teach, best, colors = D.LatentDiffusion.calc_clip_losses(fake, torch.zeros(4, 4, 8, 8), {"cls_comp_prompts": ["p"]}, {}, "train")
+        except ZeroDivisionError:            # (its reuse-iteration statistics divide by a counter that is still 0)
+            raise
+        sel.append([[bool(v) for v in teach.tolist()], int(best), [int(c) for c in colors.tolist()]])
+    rec["s2/select"] = np.array(json_dumps(sel))
     # ---- G: the front of shared_step (ddpm.py:1436-1938): iteration flags and the order random / np.random are consumed in
     import json
     import random
