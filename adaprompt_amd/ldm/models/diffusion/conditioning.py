@@ -15,7 +15,7 @@ import random
 import numpy as np
 import torch
 
-from ...util import (anneal_add_noise_to_embedding, distribute_embedding_to_M_tokens_by_dict, halve_token_indices,
+from ...util import (anneal_add_noise_to_embedding, anneal_value, distribute_embedding_to_M_tokens_by_dict, halve_token_indices,
                      join_dict_of_indices_with_key_filter, merge_cls_token_embeddings, repeat_selected_instances)
 
 # the prompt lists a batch carries (ldm/data/personalized.py:870-981), by (use_fp_trick, use_background_token)
@@ -268,6 +268,62 @@ class ConditioningMixin:
         self.embedding_manager.set_curr_batch_subject_names(self.batch_subject_names, embman_iter_type)
         return x_start, img_mask, fg_mask, captions
 
+    def prepare_compos_iteration(self, batch, x_start, img_mask, fg_mask, py_random=random):
+        """the front of ``shared_step`` for a compositional (prompt-mix distillation) iteration, ddpm.py:1450-1936: whether a
+        cached first-pass result of this subject is reused, the face-portrait prompt trick, the foreground-initialised
+        latent, the background token -- ``random`` consumed in the reference's order -- then the whole batch becomes BS
+        copies of its FIRST instance (one subject per compositional iteration) and the zero-shot features are averaged.
+        -> (x_start, img_mask, fg_mask, captions)."""
+        fl = self.iter_flags
+        assert fl["is_compos_iter"] and fl["do_mix_prompt_distillation"]
+        self.embedding_manager.training_percent = self.training_percent
+        have = batch["has_fg_mask"]
+        fl["fg_mask_avail_ratio"] = have.sum() / have.shape[0]
+        wds = batch.get("has_wds_comp")
+        fl["wds_comp_avail_ratio"] = 0 if wds is None else wds.sum() / wds.shape[0]
+        self.batch_1st_subject_name = batch["subject_name"][0]
+        in_mix_folder = bool(batch.get("is_in_mix_subj_folder", [False])[0])
+        p_reuse = 0.25 if in_mix_folder else 1
+        fl["reuse_init_conds"] = bool(self.batch_1st_subject_name in self.cached_inits and py_random.random() < p_reuse)
+        fl["do_teacher_filter"] = bool(self.do_clip_teacher_filtering and not fl["reuse_init_conds"])
+        fl["use_fp_trick"] = bool(self.use_fp_trick and "subj_prompt_single_fp" in batch and py_random.random() < 0.9)
+        if fl["wds_comp_avail_ratio"] == 1:
+            raise NotImplementedError("wds-overlay batches are out of scope (SURVEY.md section 2: data pipeline)")
+        fl["use_wds_comp"] = py_random.random() < 0
+        p_init_fg = 1 if self.do_zero_shot else anneal_value(self.training_percent, 0.5, (0.7, 0.9))
+        fl["comp_init_fg_from_training_image"] = bool(not fl["reuse_init_conds"] and fl["fg_mask_avail_ratio"] > 0
+                                                      and py_random.random() < p_init_fg)
+        fl["use_background_token"] = bool(self.use_background_token and py_random.random() < 0.5)
+        cap_key, k_ss, k_sc, k_cs, k_cc = _PROMPT_KEYS[(fl["use_fp_trick"], fl["use_background_token"])]
+        captions = batch[cap_key]
+        delta_prompts = (list(batch[k_ss]), [p.split("|")[0] for p in batch[k_sc]], list(batch[k_cs]),
+                         [p.split("|")[0] for p in batch[k_cc]])
+        BS = len(batch["subject_name"])
+        names, x_start, img_mask, fg_mask, have = repeat_selected_instances(
+            slice(0, 1), BS, list(batch["subject_name"]), x_start, img_mask, fg_mask, have)
+        fl["same_subject_in_batch"] = True
+        fl["gen_arc2face_rand_face"] = False
+        self.batch_subject_names = names
+        fl["is_face"] = [self.embedding_manager.subj_name_to_being_faces[n] for n in names]
+        zs_clip_features = zs_id_embs = None
+        if self.do_zero_shot:
+            first = {k: (v[:1].repeat(BS, *([1] * (v.dim() - 1))) if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == BS else v)
+                     for k, v in batch.items()}
+            zs_clip_features, zs_id_embs, faceless = self.zero_shot_features(first, fg_mask, is_face=fl["is_face"][0], calc_avg=True)
+            fl["add_noise_to_real_id_embs"] = py_random.random() < 0          # (the draw is made; p = 0 outside distillation)
+            fl["faceless_img_count"] = faceless
+            zs_id_embs = zs_id_embs.to(x_start.dtype)
+            fl["use_arc2face_as_target"] = False
+        fl.update(img_mask=img_mask, fg_mask=fg_mask, batch_have_fg_mask=have, delta_prompts=delta_prompts,
+                  zs_clip_features=zs_clip_features, zs_id_embs=zs_id_embs, arc2face_prompt_emb=None)
+        if fl["reuse_init_conds"]:
+            cached = self.cached_inits[self.batch_1st_subject_name]
+            for k in ("delta_prompts", "img_mask", "fg_mask", "batch_have_fg_mask", "filtered_fg_mask", "use_background_token",
+                      "use_wds_comp", "comp_init_fg_from_training_image", "zs_clip_features", "zs_id_embs", "arc2face_prompt_emb"):
+                fl[k] = cached[k]
+        self.embedding_manager.set_curr_batch_subject_names(self.batch_subject_names, "compos_distill_iter")
+        return x_start, img_mask, fg_mask, captions
+
     def zero_shot_features(self, batch, fg_mask, is_face=True, calc_avg=False):
         """``encode_zero_shot_image_features`` (ddpm.py:2322-2471) is CLIP-vision + insightface / DINO inference on
         third-party weights -- a boundary callee.  A batch that already carries ``zs_clip_features`` [B,514,D] and
@@ -275,8 +331,9 @@ class ConditioningMixin:
         ``zero_shot_encoder(images_u8_nchw, fg_mask, is_face=, calc_avg=)`` callable is asked."""
         if "zs_clip_features" in batch and "zs_id_embs" in batch:
             f, e = batch["zs_clip_features"], batch["zs_id_embs"]
-            if calc_avg:
-                f, e = f.mean(dim=0, keepdim=True), e.mean(dim=0, keepdim=True)
+            if calc_avg:                 # ddpm.py:2442-2465: mean over the instances, the id embedding re-normalised
+                f = f.mean(dim=0, keepdim=True)
+                e = torch.nn.functional.normalize(e.mean(dim=0, keepdim=True), p=2, dim=-1)
             return f, e, 0
         enc = getattr(self, "zero_shot_encoder", None)
         if enc is None:

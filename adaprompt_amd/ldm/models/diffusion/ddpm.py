@@ -223,6 +223,10 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         self.scale_factor = scale_factor
         self.bg_pixel_weight = bg_pixel_weight
         self.cond_fn = cond_fn
+        # CLIP text-image similarity of decoded images (evaluation/clip_eval.py:CLIPEvaluator.txt_to_img_similarity with
+        # reduction='diag' in the reference, ddpm.py:3624-3627): a callable behind the boundary, set by the trainer
+        self.clip_score_fn = None
+        self.empty_context_2b = self.empty_context_tea_filter = None
         self.batch_idx = 0
         self.is_dreambooth = False
         self.instantiate_first_stage(first_stage_config)
@@ -695,6 +699,177 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         return (normalized_sum(l_map), normalized_sum(l_scss), 0, normalized_sum(l_scmc), normalized_sum(l_sbg),
                 normalized_sum(l_mbg))
 
+    # ---- Stage 2: one compositional-distillation micro-batch (ddpm.py:2602-2839, 3041-3205, 3272-3445) --------------------
+    def compos_distill_step(self, x_start, noise, cond, fg_mask=None, batch_have_fg_mask=None, t=None, clip_score_fn=None,
+                            py_random=None, np_random=None, randn_like=None):
+        """``is_compos_iter`` with ``do_mix_prompt_distillation``.  ``cond`` is what the conditioning assembly returns in
+        'mix' mode: the four-way context (subject single, subject comp, class single, class comp) of ONE instance
+        [4 * 16, 77, D], the four prompt lists, ``extra_info`` with ``placeholder2indices_1b`` / ``_2b``.
+
+        Fresh iteration: t in the last fifth of the schedule; the latent is noise, or the training image's foreground
+        shrunk onto noise (``comp_init_fg_from_training_image``); ``num_candidate_teachers`` (initial condition) candidates
+        are denoised once WITHOUT grad under the subject-comp and under the mixed comp context (154-token split K/V,
+        ``stage2.mix_static_vk_embeddings``) with guidance 5 / 6 against the empty prompt, decoded and scored by
+        ``clip_score_fn(prompts, images) -> similarity`` (CLIP ViT-B/32 in the reference: a callable behind the boundary);
+        if a candidate's mixed version beats its subject version (``stage2.select_teacher``) that candidate's initial
+        condition is denoised again WITH grad under all four contexts, and the losses on the captured ``outfeat`` /
+        ``attnscore`` / ``q`` of the 12 distillation layers are formed; its x0 prediction is cached for a later
+        ``reuse_init_conds`` iteration of the same subject.  Reuse iteration: the cached x0 at a mid-schedule t, one pass.
+
+        ``randn_like``: replaces ``torch.randn_like`` for the fresh latent (parity tests: the same draws on two devices).
+        -> (loss or None when nothing was teachable, parts dict).  Backward: ``loss.backward()``."""
+        import random as _random
+        from ...stage2 import (calc_dyn_loss_scale, chunk_list, extend_indices_B_by_n_times, gen_cfg_scales_for_stu_tea,
+                               init_x_with_fg_from_training_image, mix_static_vk_embeddings, select_teacher)
+        from ...util import calc_prompt_emb_delta_loss, join_dict_of_indices_with_key_filter, repeat_selected_instances
+        py_random = py_random or _random
+        np_random = np_random or np.random
+        fl = self.iter_flags
+        assert fl["is_compos_iter"] and fl["do_mix_prompt_distillation"], "only the prompt-mix form of stage 2 is built"
+        c_static_emb, c_in, extra_info = cond
+        T, dev, BLOCK = self.num_timesteps, x_start.device, 1
+        em = self.embedding_manager
+        subj_keys = em.subject_string_dict if em is not None else extra_info.get("subject_strings", {"z": True})
+        subj_1b = join_dict_of_indices_with_key_filter(extra_info["placeholder2indices_1b"], subj_keys)
+        subj_2b = join_dict_of_indices_with_key_filter(extra_info["placeholder2indices_2b"], subj_keys)
+        init_fg = bool(fl.get("comp_init_fg_from_training_image"))
+        if self.do_zero_shot:
+            k_range, v_range = [1.0, 0.8], ([1.0, 0.7] if init_fg else [1.0, 0.6])
+        else:
+            k_range, v_range = [1.0, 1.0], ([1.0, 0.85] if init_fg else [1.0, 0.7])
+        have = batch_have_fg_mask if batch_have_fg_mask is not None else torch.zeros(x_start.shape[0], device=dev)
+        fg_avail = float(have.float().mean()) if fg_mask is not None else 0.0
+        img_mask, filtered_fg_mask = None, None
+        mix = partial(mix_static_vk_embeddings, training_percent=self.training_percent, use_layerwise_embedding=True,
+                      N_CA_LAYERS=self.N_CA_LAYERS, K_CLS_SCALE_LAYERWISE_RANGE=k_range, V_CLS_SCALE_LAYERWISE_RANGE=v_range)
+        name = getattr(self, "batch_1st_subject_name", "zs_default")
+        reuse = bool(fl.get("reuse_init_conds"))
+        do_filter = bool(self.do_clip_teacher_filtering and not reuse)
+        fl["do_teacher_filter"] = do_filter
+        if reuse:
+            cached = self.cached_inits.pop(name)
+            x_start, prev_t = cached["x_start"], cached["t"]
+            fg_mask, have, filtered_fg_mask = cached["fg_mask"], cached["batch_have_fg_mask"], cached["filtered_fg_mask"]
+            init_fg = bool(cached["comp_init_fg_from_training_image"])
+            if t is None:
+                t_mid = torch.randint(int(T * 0.4), int(T * 0.7), (x_start.shape[0],), device=dev)
+                t = torch.minimum(t_mid, prev_t - int(T * 0.15))
+        else:
+            if t is None:
+                t = torch.randint(int(T * 0.8), T, (x_start.shape[0],), device=dev)
+            if init_fg and fg_avail > 0:
+                filtered_fg_mask = fg_mask.to(x_start.dtype) * have.view(-1, 1, 1, 1).to(x_start.dtype)
+                x_start, fg_mask, filtered_fg_mask = init_x_with_fg_from_training_image(
+                    x_start, fg_mask, filtered_fg_mask, self.training_percent, base_scale_range=(0.7, 1.0),
+                    fg_noise_anneal_mean_range=(0.1, 0.4), np_random=np_random)
+            else:
+                x_start = (randn_like or torch.randn_like)(x_start)
+        cond_orig = cond
+        if do_filter:
+            NT = self.num_candidate_teachers * BLOCK
+            assert NT <= x_start.shape[0], f"num_candidate_teachers {NT} needs a batch of at least that size"
+            x_start, noise, t = x_start[:NT].repeat(2, 1, 1, 1), noise[:NT].repeat(2, 1, 1, 1), t[:NT].repeat(2)
+            _, subj_comp_emb, _, mix_comp_emb = c_static_emb.chunk(4)
+            c_static_emb2 = torch.cat([subj_comp_emb[:BLOCK * self.N_CA_LAYERS].repeat(self.num_candidate_teachers, 1, 1),
+                                       mix_comp_emb[:BLOCK * self.N_CA_LAYERS].repeat(self.num_candidate_teachers, 1, 1)], dim=0)
+            _, subj_comp_prompts, _, cls_comp_prompts = chunk_list(list(c_in), 4)
+            c_in2 = list(subj_comp_prompts) * self.num_candidate_teachers + list(cls_comp_prompts) * self.num_candidate_teachers
+            cond = (c_static_emb2, c_in2, extra_info)
+            fg_mask, filtered_fg_mask, have = repeat_selected_instances(slice(0, NT), 2, fg_mask, filtered_fg_mask, have)
+            cfg_scales = gen_cfg_scales_for_stu_tea(6, 5, NT, dev)
+            uncond = self.empty_context_tea_filter
+        else:
+            if not self.do_clip_teacher_filtering and not reuse:
+                x_start = x_start[:BLOCK].repeat(4, 1, 1, 1)
+            noise, t = noise[:BLOCK].repeat(4, 1, 1, 1), t[:BLOCK].repeat(4)
+            fg_mask, filtered_fg_mask, have = repeat_selected_instances(slice(0, BLOCK), 4, fg_mask, filtered_fg_mask, have)
+            cfg_scales = gen_cfg_scales_for_stu_tea(6, 5, BLOCK * 2, dev)
+            uncond = self.empty_context_2b
+        fg_avail = float(have.float().mean()) if fg_mask is not None else 0.0
+        c_vk = mix(cond[0], subj_1b[1], t_frac=t.chunk(2)[0] / T)[0]
+        ex = dict(extra_info)
+        ex.update(iter_type=self.prompt_mix_scheme, img_mask=None, capture_distill_attn=not do_filter)
+        model_output, x_recon = self.guided_denoise(x_start, noise, t, (c_vk, cond[1], ex), unet_has_grad=not do_filter,
+                                                    do_pixel_recon=True, cfg_info={"cfg_scales": cfg_scales, "uncond_context": uncond})
+        # ---- CLIP text-image score of the comp images: a metric to pick the teacher, never optimised (ddpm.py:3596-3712)
+        cls_comp = list(extra_info["cls_comp_prompts"])
+        if do_filter:
+            code, prompts = x_recon, cls_comp * self.num_candidate_teachers * 2
+        else:
+            _, sc, _, mc = x_recon.chunk(4)
+            code, prompts = torch.cat([sc, mc], dim=0), cls_comp * 2
+        parts = {}
+        with torch.no_grad():
+            images = self.decode_first_stage(code.detach())
+            losses_clip = 0.5 - clip_score_fn(prompts, images)
+        parts["loss_clip_subj_comp"], parts["loss_clip_cls_comp"] = (v.mean() for v in losses_clip.chunk(2))
+        if do_filter or reuse:
+            teachable, best = select_teacher(losses_clip)
+        else:
+            teachable, best = torch.ones_like(losses_clip.chunk(2)[0], dtype=torch.bool), 0
+        fl["is_teachable"] = bool(teachable.any())
+        parts["best_cand_idx"] = best
+        if do_filter and fl["is_teachable"]:
+            del model_output, x_recon
+            x_sel, noise_sel, t_sel = x_start[[best]].repeat(4, 1, 1, 1), noise[[best]].repeat(4, 1, 1, 1), t[best].repeat(4)
+            c_vk = mix(cond_orig[0], subj_1b[1], t_frac=t_sel.chunk(2)[0] / T)[0]
+            ex = dict(extra_info)
+            ex.update(iter_type=self.prompt_mix_scheme, img_mask=None, capture_distill_attn=True,
+                      placeholder2indices=extra_info["placeholder2indices_2b"])
+            cfg_info = {"cfg_scales": gen_cfg_scales_for_stu_tea(6, 5, BLOCK * 2, dev), "uncond_context": self.empty_context_2b}
+            model_output, x_recon = self.guided_denoise(x_sel, noise_sel, t_sel, (c_vk, cond_orig[1], ex), unet_has_grad=True,
+                                                        do_pixel_recon=True, cfg_info=cfg_info)
+            fg_mask, filtered_fg_mask, have = repeat_selected_instances([best], 4, fg_mask, filtered_fg_mask, have)
+            fg_avail = float(have.float().mean()) if fg_mask is not None else 0.0
+            self.cached_inits[name] = {
+                "x_start": x_recon.detach().chunk(2)[0].repeat(2, 1, 1, 1), "delta_prompts": extra_info.get("delta_prompts"),
+                "t": t_sel, "img_mask": None, "fg_mask": fg_mask, "batch_have_fg_mask": have, "filtered_fg_mask": filtered_fg_mask,
+                "use_background_token": fl.get("use_background_token", False), "use_wds_comp": fl.get("use_wds_comp", False),
+                "comp_init_fg_from_training_image": init_fg, "zs_clip_features": fl.get("zs_clip_features"),
+                "zs_id_embs": fl.get("zs_id_embs"), "arc2face_prompt_emb": fl.get("arc2face_prompt_emb")}
+            if len(self.cached_inits) > 100:
+                del self.cached_inits[py_random.choice(list(self.cached_inits.keys()))]
+        if not fl["is_teachable"]:
+            return None, parts
+        # ---- losses (ddpm.py:3207-3232, 3272-3445)
+        loss = 0
+        emb4 = ex.get("c_static_emb_4b")
+        if fl.get("do_static_prompt_delta_reg") and emb4 is not None and self.prompt_emb_delta_reg_weight > 0:
+            scale = (0.5 if self.optimizer_type == "Prodigy" else 1.0) / (5 if self.do_zero_shot else 1)
+            l_delta = calc_prompt_emb_delta_loss(emb4, ex.get("prompt_emb_mask"))
+            parts["static_prompt_delta"] = l_delta.detach()
+            loss = loss + l_delta * (self.prompt_emb_delta_reg_weight * scale)
+        acts = ex["ca_layers_activations"]
+        lns = bns = None
+        if self.normalize_ca_q_and_outfeat and em is not None and hasattr(em, "ca_q_bns"):
+            bns, lns = em.ca_q_bns, em.ca_outfeat_lns
+        l_preserve = 0
+        if init_fg and fg_avail > 0 and self.comp_fg_bg_preserve_loss_weight > 0:
+            l_map, l_ss, l_ms, l_bg, l_sbg, l_mbg = self.calc_comp_fg_bg_preserve_loss(
+                acts["outfeat"], lns, acts["q"], bns, acts["attnscore"], filtered_fg_mask, have, subj_1b, BLOCK)
+            bg_scale = calc_dyn_loss_scale(l_bg, 0.2, 2, min_scale_base_ratio=1, max_scale_base_ratio=3) if torch.is_tensor(l_bg) else 0
+            l_preserve = l_map + (l_ss + l_ms * 0.1 + l_bg * bg_scale) + (l_sbg + l_mbg) * 0.02
+            parts.update(comp_single_map_align=l_map, sc_ss_fg_match=l_ss, sc_mc_bg_match=l_bg, comp_subj_bg_attn_suppress=l_sbg,
+                         comp_mix_bg_attn_suppress=l_mbg, comp_fg_bg_preserve=l_preserve)
+        loss = loss + l_preserve * self.comp_fg_bg_preserve_loss_weight * (0.25 if reuse else 0.5)
+        feat_scale = 0.5 if self.do_zero_shot else 2
+        mix_lns = None
+        if self.normalize_ca_q_and_outfeat:
+            if py_random.random() < 0.5 and lns is not None:          # (the draw is made whether or not the norms exist)
+                mix_lns, feat_scale = lns, feat_scale * 5
+        l_feat, l_attn_delta, l_attn_norm = self.calc_prompt_mix_loss(acts["outfeat"], mix_lns, acts["attnscore"], subj_2b, BLOCK)
+        if self.do_zero_shot:
+            norm_scale = 1
+        else:
+            norm_scale = calc_dyn_loss_scale(l_attn_norm, 5., 0.2)
+        l_mix = l_attn_delta * 0.1 + l_attn_norm * norm_scale + l_feat * feat_scale
+        parts.update(feat_delta_align=l_feat, subj_attn_delta_align=l_attn_delta, subj_attn_norm_distill=l_attn_norm,
+                     mix_prompt_distill=l_mix)
+        preserve_on = torch.is_tensor(l_preserve) or l_preserve != 0
+        loss = loss + l_mix * (0.5 if preserve_on else 1) * self.mix_prompt_distill_weight
+        parts = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
+        return loss, parts
+
     # ---- Arc2Face distillation: teacher rollout + multi-step student loss (ddpm.py:2950-3039) ------------------
     MAX_ACCUMU_BATCH_SIZE = 7
 
@@ -813,6 +988,21 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             if self.embedding_manager is None:
                 raise RuntimeError("shared_step needs a context: pass cond=, set cond_fn, or construct the model with "
                                    "cond_stage_config + personalization_config")
+            if self.iter_flags.get("is_compos_iter"):
+                # stage 2: one subject, four prompt types, teacher filtering, losses on the captured activations
+                x_start, img_mask, fg_mask, captions = self.prepare_compos_iteration(batch, x_start, img_mask, fg_mask)
+                cond = self.assemble_conditioning(captions, x_start.shape[0])
+                if noise is None:
+                    noise = torch.randn_like(x_start)
+                self.ensure_empty_contexts()
+                loss, parts = self.compos_distill_step(x_start, noise, cond, fg_mask=self.iter_flags["fg_mask"],
+                                                       batch_have_fg_mask=self.iter_flags["batch_have_fg_mask"], t=t,
+                                                       clip_score_fn=self.clip_score_fn, **getattr(self, "_compos_test_hooks", {}))
+                aux = {"compos": True, "reg_parts": parts, "x_start": x_start}
+                if loss is None:                    # nothing teachable: no gradient this micro-batch (ddpm.py:3272)
+                    return torch.zeros((), device=x_start.device), None, None, aux
+                aux["reg_loss"] = loss
+                return loss.detach(), None, None, aux
             x_start, img_mask, fg_mask, captions = self.prepare_recon_iteration(batch, x_start, img_mask, fg_mask)
             fl = self.iter_flags
             cond = self.assemble_conditioning(captions, x_start.shape[0])
@@ -930,7 +1120,9 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         ``model_output`` (computed by the loss kernel, not by autograd) and the regularisers' scalar at its own root, in
         ONE pass over the tape, so the UNet's backward runs once and receives the attnscore gradients on the way."""
         roots, grads = [], []
-        if isinstance(model_output, (list, tuple)):
+        if model_output is None:                    # a compositional iteration: the whole loss is the auxiliary scalar
+            pass
+        elif isinstance(model_output, (list, tuple)):
             for o, g in zip(model_output, grad):
                 if o.requires_grad:
                     roots.append(o)
@@ -944,6 +1136,19 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             grads.append(torch.ones_like(reg))
         if roots:
             torch.autograd.backward(roots, grads)
+
+    def ensure_empty_contexts(self):
+        """ddpm.py:827-835 (``on_train_batch_start`` at global step 0): the empty prompt's context for the guidance passes of
+        a compositional iteration -- for 2 instances and for ``num_candidate_teachers`` instances."""
+        if getattr(self, "empty_context_2b", None) is None:
+            self.empty_context_2b = self.get_learned_conditioning([""] * 2, embman_iter_type="empty")
+        if getattr(self, "empty_context_tea_filter", None) is None:
+            self.empty_context_tea_filter = self.get_learned_conditioning([""] * self.num_candidate_teachers,
+                                                                          embman_iter_type="empty")
+
+    def on_train_batch_start(self, batch, batch_idx, dataloader_idx=0):
+        if self.embedding_manager is not None and self.cond_stage_model is not None:
+            self.ensure_empty_contexts()
 
     def make_prefetcher(self):
         return LatentPrefetcher(self)
@@ -1048,9 +1253,11 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             flags = self.draw_iteration_flags(gstep, cfg.get("composition_regs_iter_gap", 0),
                                               cfg.get("arc2face_distill_iter_prob", 0.0),
                                               cfg.get("mix_prompt_distill_weight", 0.0))
-            if flags["is_compos_iter"]:
-                raise NotImplementedError("compositional regularisation iterations (stage 2, composition_regs_iter_gap > 0) "
-                                          "are not built (DESIGN.md 7b)")
+            if flags["is_compos_iter"] and not (flags["do_mix_prompt_distillation"] and self.embedding_manager is not None
+                                                and getattr(self, "clip_score_fn", None) is not None):
+                raise NotImplementedError("a compositional iteration needs mix_prompt_distill_weight > 0, the reference's "
+                                          "conditioning side (cond_stage_config + personalization_config) and a clip_score_fn; "
+                                          "the ada-delta-only ablation form is not built")
             if flags["do_arc2face_distill"] and (self.cond_fn is not None or "cond" in step_kwargs):
                 # (with the reference's own conditioning side, shared_step's front decides use_arc2face_as_target / ND)
                 step_kwargs.update(use_arc2face_as_target=True, num_denoising_steps=self.draw_num_denoising_steps(

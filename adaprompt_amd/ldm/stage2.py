@@ -118,7 +118,7 @@ def gen_cfg_scales_for_stu_tea(tea_scale, stu_scale, num_teachers, device):
 def calc_dyn_loss_scale(loss, loss_base, loss_scale_base, min_scale_base_ratio=1, max_scale_base_ratio=2):
     if loss_base == 0:
         return 0
-    scale = float(loss) * loss_scale_base / loss_base
+    scale = float(loss.detach()) * loss_scale_base / loss_base
     return max(min(loss_scale_base * max_scale_base_ratio, scale), loss_scale_base * min_scale_base_ratio)
 
 

@@ -112,7 +112,7 @@ def shared_step_batch(B=4):
             "image_path": [f"/data/{i}.jpg" for i in range(B)], "has_fg_mask": torch.ones(B, dtype=torch.bool),
             "has_wds_comp": torch.zeros(B, dtype=torch.bool),
             "aug_mask": torch.ones(B, 16, 16), "fg_mask": (seeded((B, 16, 16), 5) > 0).float(),
-            "image_unnorm": torch.zeros(B, 16, 16, 3, dtype=torch.uint8),
+            "image_unnorm": torch.arange(B, dtype=torch.uint8).view(B, 1, 1, 1).repeat(1, 16, 16, 3),    # instance i: all pixels = i
             "zs_clip_features": seeded((B, 514, 8), 6), "zs_id_embs": seeded((B, 512), 7),
             "caption": list(ss), "caption_bg": bgify(ss),
             "subj_prompt_single": list(ss), "subj_prompt_comp": list(sc), "cls_prompt_single": list(cs),
@@ -142,7 +142,8 @@ def grad_norms(tensors):
     return np.array([0.0 if t.grad is None else float(t.grad.double().norm()) for t in tensors])
 
 
-SHARED_STEP_CASES = [("recon", False, 11), ("recon", False, 12), ("distill", True, 21), ("distill", True, 22), ("distill", True, 23),
+SHARED_STEP_CASES = [("compos", False, 31), ("compos", False, 32), ("compos_fp", False, 33), ("compos_fp", False, 34),
+                     ("recon", False, 11), ("recon", False, 12), ("distill", True, 21), ("distill", True, 22), ("distill", True, 23),
                      ("distill", True, 24), ("distill", True, 25), ("distill", True, 26)]
 
 
@@ -365,14 +366,30 @@ def main():
         fake.apply_arc2face_inverse_embs = False
         fake.embedding_manager = _EM(dim=8)
         batch = shared_step_batch(4)
+        if kind == "compos_fp":              # broad_class == 1 datasets also carry the face-portrait prompt variants
+            for k in list(batch.keys()):
+                if k.startswith(("subj_prompt", "cls_prompt")):
+                    base, bg = (k[:-3], "_bg") if k.endswith("_bg") else (k, "")
+                    batch[base + "_fp" + bg] = ["a face portrait of " + q for q in batch[k]]
         fake.get_input = lambda b, k: (seeded((len(b["subject_name"]), 4, 2, 2), 9), None)
-        fake.encode_zero_shot_image_features = lambda images, fg, image_paths=None, is_face=True, calc_avg=False: (
-            batch["zs_clip_features"], batch["zs_id_embs"], 0)
+        def fake_encoder(images, fg, image_paths=None, is_face=True, calc_avg=False, _b=batch):
+            # features are a function of the IMAGES handed over (instance i's pixels are all i): a repeated image gives
+            # repeated features; calc_avg as ddpm.py:2442-2465 (mean; the id embedding re-normalised)
+            idx = images[:, 0, 0, 0].long()
+            f, e = _b["zs_clip_features"][idx], _b["zs_id_embs"][idx]
+            if calc_avg:
+                f = f.mean(dim=0, keepdim=True)
+                e = torch.nn.functional.normalize(e.mean(dim=0, keepdim=True), p=2, dim=-1)
+            return f, e, 0
+        fake.encode_zero_shot_image_features = fake_encoder
         fake.arc2face = types.SimpleNamespace(gen_arc2face_prompt_embs=lambda n, pre_face_embs=None: (
             n, pre_face_embs if pre_face_embs is not None else seeded((n, 512), 8), seeded((n, 21, 8), 10)))
         fake.iter_flags = {}
         D.DDPM.init_iteration_flags(fake)
         fake.iter_flags["do_arc2face_distill"] = distill
+        if kind.startswith("compos"):        # what training_step sets for a prompt-mix iteration (ddpm.py:556-565)
+            fake.iter_flags.update(do_mix_prompt_distillation=True, do_ada_prompt_delta_reg=True, is_compos_iter=True,
+                                   calc_clip_loss=True, do_normal_recon=False)
         if distill:
             fake.iter_flags["do_static_prompt_delta_reg"] = False          # training_step switches it off (ddpm.py:572)
         random.seed(seed)

@@ -206,10 +206,20 @@ def test_shared_step_front_flags_and_rng_order():
         x0 = G.seeded((4, 4, 2, 2), 9)
         img_mask = torch.nn.functional.interpolate(batch["aug_mask"][:, None], size=(2, 2), mode="nearest")
         fg_mask = torch.nn.functional.interpolate(batch["fg_mask"][:, None], size=(2, 2), mode="nearest")
+        if kind == "compos_fp":
+            for k in list(batch.keys()):
+                if k.startswith(("subj_prompt", "cls_prompt")):
+                    base, bg = (k[:-3], "_bg") if k.endswith("_bg") else (k, "")
+                    batch[base + "_fp" + bg] = ["a face portrait of " + q for q in batch[k]]
+        if kind.startswith("compos"):
+            me.iter_flags.update(do_mix_prompt_distillation=True, do_ada_prompt_delta_reg=True, is_compos_iter=True,
+                                 calc_clip_loss=True, do_normal_recon=False)
+            me.use_fp_trick, me.do_clip_teacher_filtering, me.cached_inits = True, True, {}
         random.seed(seed)
         np.random.seed(seed)
         torch.manual_seed(seed)
-        x_start, im, fm, captions = ConditioningMixin.prepare_recon_iteration(me, batch, x0, img_mask, fg_mask)
+        prep = ConditioningMixin.prepare_compos_iteration if kind.startswith("compos") else ConditioningMixin.prepare_recon_iteration
+        x_start, im, fm, captions = prep(me, batch, x0, img_mask, fg_mask)
         got = G.flags_record(me.iter_flags, x_start, captions, me.embedding_manager.calls)
         got["after"] = [random.random(), float(np.random.rand())]
         for k, v in want.items():

@@ -1,0 +1,116 @@
+"""One compositional-distillation micro-batch (BASELINE config 4: bs = 3, 154-token split K/V context) on the
+MI355X against the same iteration with every device computation replaced by the CPU oracle: the no-grad teacher-filter pass
+with classifier-free guidance, VAE decode, teacher selection, the with-grad pass on the selected candidate under the four
+mixed contexts, the losses on the captured outfeat / attnscore / q of the distillation layers, and the gradient into the
+embedding manager's subject vectors (through the K/V prompt mixing, the UNet's attention side outputs and features).
+The host logic (iteration driver, stage-2 losses) is the product's own on both sides -- it is pinned separately by the
+reference-generated goldens (tests/test_stage2_golden.py, tests/test_ddpm_golden.py); what is compared here is HIP vs oracle."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from adaprompt_amd import synth          # noqa: E402
+from conftest import rel_err          # noqa: E402
+
+
+def _params(ucfg, vdd, dim):
+    return {"first_stage_config": {"target": "ldm.models.autoencoder.AutoencoderKL",
+                                   "params": {"ddconfig": vdd, "embed_dim": 4, "with_decoder": True}},
+            "cond_stage_config": {"target": "tests.stubs.StubTextEncoder", "params": {"dim": dim}},
+            "personalization_config": {"target": "tests.stubs.StubEmbeddingManager", "params": {"dim": dim, "num_vectors_per_subj_token": 9}},
+            "unet_config": {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
+            "scale_factor": 0.18215, "linear_start": 0.00085, "linear_end": 0.012, "conditioning_key": "crossattn",
+            "cond_stage_trainable": True, "use_layerwise_embedding": True, "do_zero_shot": True, "mix_prompt_distill_weight": 1e-4,
+            "comp_fg_bg_preserve_loss_weight": 1e-3, "prompt_emb_delta_reg_weight": 2e-4, "normalize_ca_q_and_outfeat": True,
+            "num_candidate_teachers": 2, "composition_regs_iter_gap": 3}
+
+
+def _batch(B, dev):
+    import make_golden_ddpm as G
+    b = G.shared_step_batch(4)
+    b = {k: (v[:B] if (torch.is_tensor(v) or isinstance(v, list)) else v) for k, v in b.items()}
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+    fg = ((xx / 0.6) ** 2 + (yy / 0.7) ** 2 <= 1.0).float()[None].repeat(B, 1, 1)
+    b.update(fg_mask=fg, aug_mask=torch.ones(B, 512, 512), zs_clip_features=G.seeded((B, 514, 8), 6), zs_id_embs=G.seeded((B, 512), 7))
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def _score_fn(prompts, images):
+    """scripted CLIP similarity: candidate 1's mixed image beats its subject image by the larger margin; a small image-dependent
+    term makes the score a function of the decoded pixels (so a wrong decode shows) without being able to flip the order."""
+    n = images.shape[0]
+    base = torch.tensor([0.30, 0.31, 0.25, 0.22][:n] if n == 4 else [0.30, 0.22], device=images.device)
+    stat = images.float()[:, :, ::8, ::8].mean(dim=(1, 2, 3))
+    return 0.5 - (base + 0.02 * torch.tanh(stat))
+
+
+@pytest.mark.gpu
+def test_compositional_micro_batch_vs_oracle():
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import ldm_oracle as O
+    dev = torch.device("cuda:0")
+    ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    vsd = synth.synthetic_vae_state_dict(vdd, decoder=True)
+    B = 3
+    x0 = synth.synthetic_input("s2.x0", (B, 4, 64, 64))
+    noise = synth.synthetic_input("s2.noise", (B, 4, 64, 64))
+    fresh = synth.synthetic_input("s2.fresh", (B, 4, 64, 64))
+    t = torch.tensor([931, 872, 990])
+
+    def run(device, oracle):
+        torch.manual_seed(0)
+        ld = LatentDiffusion(**_params(ucfg, vdd, 128))
+        missing, unexpected = ld.load_state_dict({**usd, **vsd}, strict=False)
+        assert not unexpected
+        ld = ld.to(device)
+        ld.embedding_manager.vectors["z"].data.mul_(0.2)
+        ld.embedding_manager.vectors["y"].data.mul_(0.2)
+        if oracle:
+            sched = O.make_schedule()
+            ld.q_sample = lambda x_start, t, noise=None: O.q_sample(sched, x_start, t, noise)
+            ld.apply_model = lambda x_noisy, tt, cond: O.unet_forward(usd, ucfg, x_noisy, tt, cond[0], cond[2])
+            ld.decode_first_stage = lambda z, **kw: O.decode_first_stage(vsd, vdd, z)
+        ld.clip_score_fn = _score_fn
+        ld.training_percent = 0.3
+        ld.init_iteration_flags()
+        ld.iter_flags.update(do_mix_prompt_distillation=True, do_ada_prompt_delta_reg=True, is_compos_iter=True, calc_clip_loss=True,
+                             do_normal_recon=False)
+        ld._compos_test_hooks = {"py_random": random.Random(5), "randn_like": lambda like: fresh[:like.shape[0]].to(like.device)}
+        random.seed(3)            # the front's draws: fresh iteration, no fp prompts in this batch, background token by chance
+        batch = _batch(B, device)
+        loss, grad, out, aux = ld.shared_step(batch, t=t.to(device), noise=noise.to(device), x_start=x0.to(device))
+        ld.manual_backward(out, grad, aux)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+        g = {k: v.grad.detach().cpu() for k, v in ld.embedding_manager.vectors.items() if v.grad is not None}
+        parts = {k: (float(v) if torch.is_tensor(v) else v) for k, v in aux["reg_parts"].items()}
+        return float(loss), parts, g, dict(ld.iter_flags), sorted(ld.cached_inits.keys()), ld.cached_inits
+
+    lh, ph, gh, fh, ch, cache_h = run(dev, oracle=False)
+    lo, po, go, fo, co, cache_o = run(torch.device("cpu"), oracle=True)
+    # same decisions
+    assert fh["is_teachable"] and fo["is_teachable"] and ph["best_cand_idx"] == po["best_cand_idx"] == 1
+    assert fh["do_teacher_filter"] and fh["use_background_token"] == fo["use_background_token"]
+    assert ch == co == ["alice"]
+    # the x0 prediction cached for the reuse iteration (guided denoise of the selected candidate, 4 contexts)
+    assert rel_err(cache_h["alice"]["x_start"].cpu(), cache_o["alice"]["x_start"]) < 2.5e-2
+    assert torch.equal(cache_h["alice"]["t"].cpu(), cache_o["alice"]["t"])
+    # losses: every term, then the total
+    for k in ("loss_clip_subj_comp", "loss_clip_cls_comp"):
+        assert abs(ph[k] - po[k]) < 2e-3, (k, ph[k], po[k])
+    for k in ("feat_delta_align", "subj_attn_delta_align", "subj_attn_norm_distill", "static_prompt_delta", "comp_single_map_align",
+              "sc_ss_fg_match", "sc_mc_bg_match", "comp_subj_bg_attn_suppress", "comp_mix_bg_attn_suppress", "comp_fg_bg_preserve",
+              "mix_prompt_distill"):
+        assert abs(ph[k] - po[k]) < 4e-2 * abs(po[k]) + 2e-6, (k, ph[k], po[k])
+    assert abs(lh - lo) < 3e-2 * abs(lo), (lh, lo)
+    # gradient into the subject vectors
+    assert float(go["z"].norm()) > 0
+    assert rel_err(gh["z"], go["z"]) < 8e-2, rel_err(gh["z"], go["z"])
