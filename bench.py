@@ -149,6 +149,7 @@ def main():
                          "would dominate a rocprofv3 --stats average of the dominant kernel)")
     ap.add_argument("--no-unfrozen", action="store_true",
                     help="skip the `unfreeze_model: True` leg (weight gradients + 4.5 GB optimiser / all-reduce payload)")
+    ap.add_argument("--no-compos", action="store_true", help="skip the config-4 leg (Stage-2 compositional micro-batches)")
     ap.add_argument("--no-distill-mix", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
     args = ap.parse_args()
@@ -499,6 +500,11 @@ def main():
         ld.set_arc2face_teacher(None)
         del teacher
 
+    # ---- extra leg: config 4 -- Stage-2 compositional distillation micro-batches at bs=3
+    compos = None
+    if world == 1 and not args.no_compos:
+        compos = compos_leg(device, gen)
+
     # ---- extra leg: config 5 -- 50 DDIM steps at bs=8 (UNet batch 16 under classifier-free guidance,
     # context [256,77,768]) and the VAE decode of the 8 latents
     ddim = None
@@ -631,6 +637,8 @@ def main():
             res["north_star_aggregates"] = aggregates
         if distill is not None:
             res["config2_distill_mix"] = distill
+        if compos is not None:
+            res["config4_compos"] = compos
         if ddim is not None:
             res["config5_ddim"] = ddim
         if unfrozen is not None:
@@ -638,6 +646,88 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def compos_leg(device, gen, micro_batches=8):
+    """BASELINE config 4 on one GPU: Stage-2 compositional (prompt-mix) distillation micro-batches, bs = 3, full SD-1.5 UNet
+    (frozen) + VAE encoder and decoder.  A fresh iteration is: the no-grad teacher-filter pass of 2 candidates x (subject comp,
+    mix comp) under classifier-free guidance (UNet batch 8, 154-token split K/V context), VAE decode of the 4 images, scoring,
+    then the with-grad pass of the selected candidate under the four contexts (UNet batch 4), the stage-2 losses on the
+    captured outfeat / attnscore / q of 12 layers and the backward through all of it into the embedding manager; a reuse
+    iteration starts from the cached prediction and skips the filter.  The text encoder, the embedding manager and the
+    CLIP scorer are third-party / boundary callees: stand-ins from tests/stubs.py and a scripted score."""
+    import random as _random
+    from adaprompt_amd import synth
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    B = 3
+    with torch.device(device):
+        ld = LatentDiffusion(
+            first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
+                                "params": {"ddconfig": dict(synth.SD15_VAE_DD), "embed_dim": 4, "with_decoder": True}},
+            cond_stage_config={"target": "tests.stubs.StubTextEncoder", "params": {"dim": 768}},
+            personalization_config={"target": "tests.stubs.StubEmbeddingManager", "params": {"dim": 768, "num_vectors_per_subj_token": 16}},
+            unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.SD15_UNET)},
+            scale_factor=0.18215, linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn", cond_stage_trainable=True,
+            use_layerwise_embedding=True, do_zero_shot=True, mix_prompt_distill_weight=1e-4, comp_fg_bg_preserve_loss_weight=1e-3,
+            prompt_emb_delta_reg_weight=2e-4, normalize_ca_q_and_outfeat=True, num_candidate_teachers=2, composition_regs_iter_gap=3)
+    ld = ld.to(device)
+    sd = device_state_dict(synth.unet_param_shapes(**synth.SD15_UNET), "model.diffusion_model.", device, 0)
+    sd.update(device_state_dict(synth.vae_encoder_param_shapes(**synth.SD15_VAE_DD), "first_stage_model.", device, 1))
+    sd.update(device_state_dict(synth.vae_decoder_param_shapes(**synth.SD15_VAE_DD), "first_stage_model.", device, 9))
+    missing, unexpected = ld.load_state_dict(sd, strict=False)
+    assert not unexpected
+    del sd
+    params = [p for p in ld.embedding_manager.parameters() if p.requires_grad]
+    for p in params:
+        p.data.mul_(0.05)
+
+    def score(prompts, images):          # scripted CLIP similarity: the mixed-prompt image always beats the subject one
+        n = images.shape[0]
+        base = torch.tensor([0.30, 0.31, 0.25, 0.22] if n == 4 else [0.30, 0.22], device=images.device)
+        return 0.5 - (base + 0.02 * torch.tanh(images.float()[:, :, ::8, ::8].mean(dim=(1, 2, 3))))
+
+    ld.clip_score_fn = score
+    ld.training_percent = 0.3
+    batch = synthetic_batch(B, device, 4321)
+    ss, sc = "a photo of z", "a photo of z dancing in a park"
+    cs, cc = "a photo of person", "a photo of person dancing in a park"
+    bg = " with background y"
+    batch.update(subject_name=["alice"] * B, is_in_mix_subj_folder=[False] * B, has_fg_mask=torch.ones(B, dtype=torch.bool, device=device),
+                 has_wds_comp=torch.zeros(B, dtype=torch.bool, device=device),
+                 zs_clip_features=torch.randn(B, 514, 768, device=device, generator=gen) * 0.1,
+                 caption=[ss] * B, caption_bg=[ss + bg] * B, subj_prompt_single=[ss] * B, subj_prompt_comp=[sc] * B,
+                 cls_prompt_single=[cs] * B, cls_prompt_comp=[cc] * B, subj_prompt_single_bg=[ss + bg] * B,
+                 subj_prompt_comp_bg=[sc + bg] * B, cls_prompt_single_bg=[cs + bg] * B, cls_prompt_comp_bg=[cc + bg] * B)
+    kinds = []
+
+    def cstep():
+        ld.init_iteration_flags()
+        ld.iter_flags.update(do_mix_prompt_distillation=True, do_ada_prompt_delta_reg=True, is_compos_iter=True, calc_clip_loss=True,
+                             do_normal_recon=False)
+        loss, grads, outs, aux = ld.shared_step(batch)
+        ld.manual_backward(outs, grads, aux)
+        kinds.append(("reuse" if ld.iter_flags["reuse_init_conds"] else "fresh") + ("" if ld.iter_flags["is_teachable"] else "-unteachable"))
+        for p in params:
+            p.grad = None
+        return loss
+
+    _random.seed(0)
+    for _ in range(2):                   # one fresh + one reuse iteration untimed
+        cstep()
+    torch.cuda.synchronize()
+    del kinds[:]
+    t0 = time.perf_counter()
+    for _ in range(micro_batches):
+        loss = cstep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "config 4: Stage-2 compositional distillation micro-batches, bs=3 (one subject x 4 prompt types; fresh "
+                        "iterations: no-grad teacher filter of 2 candidates under CFG at UNet batch 8 with the 154-token split K/V "
+                        "context + VAE decode of 4 images + scripted CLIP score, then the with-grad pass at UNet batch 4 + stage-2 "
+                        "losses on 12 layers' captured outfeat/attnscore/q + backward into the embedding manager; reuse iterations "
+                        "start from the cached prediction); text encoder / embedding manager / CLIP are stand-ins",
+            "micro_batches": micro_batches, "iteration_kinds": kinds, "ms_per_micro_batch": round(1e3 * dt / micro_batches, 2),
+            "images_per_sec": round(B * micro_batches / dt, 2), "final_loss": round(float(loss), 6)}
 
 
 def spawn_ranks(n):

@@ -20,7 +20,7 @@ def build(dev, seed):
     from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from adaprompt_amd.ldm.prodigy import Prodigy
-    ucfg = dict(synth.SD15_UNET, model_channels=32, context_dim=128)
+    ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)        # 8 heads x dim_head 8 (the kernels need a multiple of 8)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
     torch.manual_seed(seed)
     hook = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)

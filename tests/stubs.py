@@ -13,7 +13,7 @@ class StubTextEncoder(nn.Module):
     def __init__(self, dim=32, last_layers_skip_weights=(0.5, 0.5)):
         super().__init__()
         self.dim = dim
-        self.table = nn.Parameter(torch.randn(997, dim, generator=torch.Generator().manual_seed(5)), requires_grad=False)
+        self.table = nn.Parameter(torch.randn(997, dim, generator=torch.Generator(device="cpu").manual_seed(5), device="cpu"), requires_grad=False)
         self.sampled = 0
         self.device = torch.device("cpu")
 
@@ -46,7 +46,7 @@ class StubEmbeddingManager(nn.Module):
         self.background_string_dict = {s: True for s in background_strings}
         self.K = {**{s: num_vectors_per_subj_token for s in subject_strings},
                   **{s: num_vectors_per_bg_token for s in background_strings}}
-        self.vectors = nn.ParameterDict({s: nn.Parameter(torch.randn(16, k, dim, generator=torch.Generator().manual_seed(11 + i)))
+        self.vectors = nn.ParameterDict({s: nn.Parameter(torch.randn(16, k, dim, generator=torch.Generator(device="cpu").manual_seed(11 + i), device="cpu"))
                                          for i, (s, k) in enumerate(self.K.items())})
         self.use_conv_attn_kernel_size = -1
         self.placeholder2indices, self.prompt_emb_mask = {}, None
@@ -73,7 +73,8 @@ class StubEmbeddingManager(nn.Module):
         B = len(prompts)
         emb = emb.view(B, 16, 77, -1).clone()
         self.placeholder2indices = {}
-        mask = torch.full((B, 77, 1), 0.5)
+        mask = torch.full((B, 77, 1), 0.5, device=emb.device)
+        dev = emb.device
         for b, p in enumerate(prompts):
             words = p.split()
             mask[b, :len(words) + 2] = 1.0
@@ -84,8 +85,8 @@ class StubEmbeddingManager(nn.Module):
                     if getattr(self, "zs_id_embs", None) is not None and self.zs_id_embs.shape[0] > b % self.zs_id_embs.shape[0]:
                         vec = vec * (1 + self.zs_id_embs[b % self.zs_id_embs.shape[0]].mean())
                     emb[b, :, pos:pos + k] = vec
-                    ib, it = self.placeholder2indices.get(s, (torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)))
-                    self.placeholder2indices[s] = (torch.cat([ib, torch.full((k,), b)]), torch.cat([it, torch.arange(pos, pos + k)]))
+                    ib, it = self.placeholder2indices.get(s, (torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(0, dtype=torch.long, device=dev)))
+                    self.placeholder2indices[s] = (torch.cat([ib, torch.full((k,), b, device=dev)]), torch.cat([it, torch.arange(pos, pos + k, device=dev)]))
         self.prompt_emb_mask = mask
         return emb.view(B * 16, 77, -1)
 
