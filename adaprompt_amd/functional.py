@@ -9,12 +9,44 @@ inside a block nothing is left to it: residual adds, time-embedding adds, bias a
 accumulation are fused into kernel epilogues.
 
 All activations are pixel-major f32 (the residual stream) or bf16 (matrix-core operands)."""
+import os
+
 import torch
 
 from . import ops
 
 F32 = torch.float32
 BF16 = torch.bfloat16
+
+# Validation mode (``ADAP_F32_STORAGE=1`` or ``set_f32_storage(True)``): bf16 is used ONLY as the matrix-core operand
+# format.  Every tensor the shipped path keeps in HBM as bf16 although its consumer is not a contraction -- the ResBlock's
+# h1 (read by the second GroupNorm), the GEGLU pre-activation, the data gradients that feed a GroupNorm / GEGLU backward,
+# the read-modify-write of the captured-activation gradients into dq/dk -- is f32 instead, and rounded to bf16 exactly
+# once, where a contraction reads it.  It exists to put a number on what bf16 *storage* (as opposed to bf16 MFMA operands)
+# costs in accuracy (tests/test_precision_gpu.py); it runs a few torch element-wise kernels and is not a speed path.
+F32_STORAGE = os.environ.get("ADAP_F32_STORAGE", "0") == "1"
+
+
+def set_f32_storage(on):
+    global F32_STORAGE
+    F32_STORAGE = bool(on)
+
+
+def _geglu_fwd_f32(hh):
+    a, gate = hh.chunk(2, dim=-1)
+    return (a * torch.nn.functional.gelu(gate)).to(BF16)
+
+
+def _geglu_bwd_f32(dout, hh):
+    a, gate = hh.chunk(2, dim=-1)
+    cdf = 0.5 * (1.0 + torch.erf(gate * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * gate * gate) * 0.3989422804014327
+    return torch.cat([dout * (gate * cdf), dout * a * (cdf + gate * pdf)], dim=-1).to(BF16)
+
+
+def _op16(t):
+    """the bf16 operand of a contraction (validation mode hands f32 tensors around)."""
+    return t if t is None or t.dtype == BF16 else t.to(BF16)
 
 
 class WeightCache:
@@ -148,7 +180,10 @@ class ResBlockFn(torch.autograd.Function):
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
         _, a1, m1, r1 = ops.groupnorm_fwd(x, g1w, g1b, 1e-5, 1)
         # h1 is block-internal (read only by the second norm and its backward): kept in bf16
-        _, h1 = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, chan_add=emb_out, out_f32=False, out_bf16=True)
+        h1_32, h1 = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, chan_add=emb_out, out_f32=F32_STORAGE,
+                               out_bf16=not F32_STORAGE)
+        if F32_STORAGE:
+            h1 = h1_32
         _, a2, m2, r2 = ops.groupnorm_fwd(h1, g2w, g2b, 1e-5, 1)
         if sk is None:
             skip = x
@@ -169,9 +204,9 @@ class ResBlockFn(torch.autograd.Function):
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
         gop = _operand(g)
-        ga2 = _conv_bwd_data(gop, c2, 3, 1, bf16=True)
+        ga2 = _conv_bwd_data(gop, c2, 3, 1, bf16=not F32_STORAGE)
         _, gh1 = ops.groupnorm_bwd(ga2, h1, g2w, g2b, m2, r2, 1, out_f32=False, out_bf16=True)
-        ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=True)
+        ga1 = _conv_bwd_data(gh1, c1, 3, 1, bf16=not F32_STORAGE)
         g_emb = None
         db1 = _acc(T["conv1"][1]) if T is not None else None
         if ctx.needs_input_grad[1] or db1 is not None:
@@ -183,9 +218,9 @@ class ResBlockFn(torch.autograd.Function):
                 db1.add_(g_emb.sum(0))
         if T is not None:
             _dw_conv(T, "conv2", a2, gop, 3, 1, 1, with_bias=False)
-            _dw_norm(T, "gn2", ga2, h1, g2w, g2b, m2, r2, 0, 1)
+            _dw_norm(T, "gn2", _op16(ga2), _op16(h1), g2w, g2b, m2, r2, 0, 1)
             _dw_conv(T, "conv1", a1, gh1, 3, 1, 1, with_bias=False)
-            _dw_norm(T, "gn1", ga1, x, g1w, g1b, m1, r1, 0, 1)
+            _dw_norm(T, "gn1", _op16(ga1), x, g1w, g1b, m1, r1, 0, 1)
             if sk is not None:
                 _dw_conv(T, "skip", x, gop, 1, with_bias=False)
             # conv2 and the 1x1 skip see the same output gradient: one column sum serves both bias gradients
@@ -250,8 +285,12 @@ class SpatialTransformerFn(torch.autograd.Function):
         # --- GEGLU feed-forward -----------------------------------------------------------------
         n3, l3m, l3r = ops.layernorm_fwd(t2, *P["norm3"])
         ff1, ff2 = P["ff1"], P["ff2"]
-        _, hh = ops.linear(n3, ff1.fwd, 8 * C, bias=ff1.bias, out_f32=False, out_bf16=True)
-        gg = ops.geglu_fwd(hh)
+        hh32, hh = ops.linear(n3, ff1.fwd, 8 * C, bias=ff1.bias, out_f32=F32_STORAGE, out_bf16=not F32_STORAGE)
+        if F32_STORAGE:
+            hh = hh32
+            gg = _geglu_fwd_f32(hh)
+        else:
+            gg = ops.geglu_fwd(hh)
         # t3 only feeds proj_out, whose matrix-core operand is bf16 anyway: write it as bf16 only
         _, t3 = ops.linear(gg, ff2.fwd, C, bias=ff2.bias, residual=t2, out_f32=False, out_bf16=True)
         pout = P["proj_out"]
@@ -293,8 +332,12 @@ class SpatialTransformerFn(torch.autograd.Function):
         # data-gradient contraction reads bf16 (LDS-DMA path) instead of converting f32 on the fly
         gt3, gt3h = _lin_bwd(gop, P["proj_out"], out_f32=True, out_bf16=True)     # [B,N,C]
         # feed-forward
-        _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)           # bf16 [B,N,4C]
-        ghh = ops.geglu_bwd(ggg, hh)                                               # bf16 [B,N,8C]
+        if F32_STORAGE:
+            ggg, _ = _lin_bwd(gt3h, P["ff2"], out_f32=True, out_bf16=False)
+            ghh = _geglu_bwd_f32(ggg, hh)
+        else:
+            _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)       # bf16 [B,N,4C]
+            ghh = ops.geglu_bwd(ggg, hh)                                           # bf16 [B,N,8C]
         gn3, _ = _lin_bwd(ghh, P["ff1"])
         if T is not None:
             _dw_lin(T, "proj_out", t3, gop)
@@ -309,12 +352,19 @@ class SpatialTransformerFn(torch.autograd.Function):
         dkv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
         ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
                           dv=dkv2[..., C:])
+        dq_acc, dk_acc = dq2, dkv2[..., :C]
+        side = g_score is not None or g_qs is not None or g_tokmap is not None
+        if F32_STORAGE and side:          # the side outputs' gradients go to their own (zeroed) tensors, summed in f32 below
+            dq_acc, dk_acc = torch.zeros_like(dq2), torch.zeros(B, M, C, device=x.device, dtype=BF16)
         if g_score is not None or g_qs is not None:      # gradients of the captured attnscore / q side outputs
             ops.attention_capture_bwd(None if g_score is None else g_score.contiguous(),
-                                      None if g_qs is None else g_qs.contiguous(), q2, kv2[..., :C], dq2,
-                                      dkv2[..., :C], heads)
+                                      None if g_qs is None else g_qs.contiguous(), q2, kv2[..., :C], dq_acc,
+                                      dk_acc, heads)
         if g_tokmap is not None:                         # ... and of the token maps (compact: no dense d attnscore)
-            ops.attention_tokmap_bwd(g_tokmap.contiguous(), ctx.tok_w, q2, kv2[..., :C], dq2, dkv2[..., :C], heads)
+            ops.attention_tokmap_bwd(g_tokmap.contiguous(), ctx.tok_w, q2, kv2[..., :C], dq_acc, dk_acc, heads)
+        if F32_STORAGE and side:
+            dq2 = (dq2.float() + dq_acc.float()).to(BF16)
+            dkv2[..., :C].copy_(dkv2[..., :C].float() + dk_acc.float())
         gn2, _ = _lin_bwd(dq2, P["q2"])
         if T is not None:
             _dw_lin(T, "to_out2", o2, gt2h)
@@ -346,11 +396,13 @@ class SpatialTransformerFn(torch.autograd.Function):
             _dw_norm(T, "norm1", gn1, t0, P["norm1"][0], None, l1m, l1r, 1, 0)
         gt0, gt0h = ops.layernorm_bwd(gn1, t0, P["norm1"][0], l1m, l1r, accumulate_into=gt1, want_bf16=True)
         # proj_in, GroupNorm
-        _, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=False, out_bf16=True)
+        gxn32, gxn = _lin_bwd(gt0h, P["proj_in"], out_f32=F32_STORAGE, out_bf16=not F32_STORAGE)
+        if F32_STORAGE:
+            gxn = gxn32
         gnw, gnb = P["norm"]
         if T is not None:
             _dw_lin(T, "proj_in", xn.view(B, N, C), gt0h)
-            _dw_norm(T, "norm", gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, 0)
+            _dw_norm(T, "norm", _op16(gxn).view(B, H, W, C), x, gnw, gnb, gm, gr, 0, 0)
         gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None
@@ -410,10 +462,10 @@ class OutHeadFn(torch.autograd.Function):
         pk = ctx.pk
         g = g.contiguous()
         g16 = ops.pad_cast_bf16(g, pk.bwd.shape[2])          # 4 -> 8 channels for the K dim
-        ga = _conv_bwd_data(g16, pk, 3, 1, bf16=True)
+        ga = _conv_bwd_data(g16, pk, 3, 1, bf16=not F32_STORAGE)
         if ctx.train is not None:
             _dw_conv(ctx.train, "conv", a, g, 3, 1, 1)
-            _dw_norm(ctx.train, "gn", ga, h, ctx.gn[0], ctx.gn[1], m, r, 0, 1)
+            _dw_norm(ctx.train, "gn", _op16(ga), h, ctx.gn[0], ctx.gn[1], m, r, 0, 1)
         gh, _ = ops.groupnorm_bwd(ga, h, ctx.gn[0], ctx.gn[1], m, r, 1)
         return gh, None, None, None
 

@@ -449,7 +449,7 @@ def recon_step(unet_sd, vae_sd, unet_cfg, vae_dd, image_nchw, masks, post_noise,
     ctx = context.detach().clone().requires_grad_(need_grad)
     extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1,
              "iter_type": "normal_recon", "is_training": True, "capture_distill_attn": False,
-             "img_mask": None}
+             "img_mask": img_mask}          # ddpm.py:2876: the image mask also gates the self-attention keys
     eps_hat = unet_forward(unet_sd, unet_cfg, x_noisy, t, ctx, extra)
     loss, _ = calc_recon_loss(eps_hat, noise, img_mask, fg_mask, 1.0, bg_pixel_weight)
     grad = None

@@ -1,0 +1,135 @@
+"""What the bf16 path costs in accuracy, and where.
+
+(a) d loss / d context of the UNet against the reference-generated goldens, per context layer, in the shipped mode and in the
+    f32-storage validation mode (``functional.set_f32_storage``: bf16 only as the matrix-core operand format, every other
+    tensor f32 in HBM).  The two modes agree to a few 1e-4: the error of the shipped path is the error of bf16 MFMA operands,
+    not of bf16 storage.  Full size: 1.5e-2 (gate 2e-2).
+(b) a 20-optimizer-step training trajectory (clip 0.5, Prodigy + linear schedule) on the narrow
+    model, HIP vs the f32 oracle running the same loop: loss curve within 1 %, Prodigy's d within 5 % at every step."""
+import pytest
+import torch
+
+from adaprompt_amd import synth
+from conftest import load_golden, rel_err, ellipse_mask, border_mask
+
+pytestmark = pytest.mark.gpu
+
+NARROW = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _context_gradient(cfg, tag, gname, subs, f32_storage):
+    import test_model_gpu as T
+    from adaprompt_amd import functional as Fn
+    g = load_golden(gname)
+    B, M = g["B"], g["M"]
+    unet = T.build_unet(cfg)
+    x = synth.synthetic_input(f"unet.{tag}.x", (B, 4, 64, 64)).to(dev())
+    ctx = synth.synthetic_input(f"unet.{tag}.ctx", (16 * B, M, cfg["context_dim"])).to(dev()).requires_grad_(True)
+    w = synth.synthetic_input(f"unet.{tag}.gw", (B, 4, 64, 64)).to(dev())
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": g["iter_type"], "is_training": True,
+             "capture_distill_attn": bool(g["capture"]), "placeholder2indices": None, "img_mask": None}
+    Fn.set_f32_storage(f32_storage)
+    try:
+        eps = unet(x, g["t"].to(dev()), context=ctx, context_in=None, extra_info=extra)
+        (eps * w).sum().backward()
+    finally:
+        Fn.set_f32_storage(False)
+    gr = ctx.grad.cpu()
+    got = gr[:, ::4, ::8] if subs else gr
+    ref = g["grad_context"]
+    per_layer = [rel_err(got.view(B, 16, *got.shape[1:])[:, l], ref.view(B, 16, *ref.shape[1:])[:, l]) for l in range(16)]
+    return rel_err(eps.detach().cpu(), g["eps"]), rel_err(got, ref), per_layer
+
+
+@pytest.mark.parametrize("cfg,tag,gname,subs", [(NARROW, "narrow_recon", "unet_narrow_recon", False),
+                                                (dict(synth.SD15_UNET), "sd15_recon", "unet_sd15_recon", True)])
+def test_context_gradient_bf16_storage_vs_f32_storage(cfg, tag, gname, subs):
+    e0, g0, l0 = _context_gradient(cfg, tag, gname, subs, False)
+    e1, g1, l1 = _context_gradient(cfg, tag, gname, subs, True)
+    print(f"[{tag}] shipped     : eps {e0:.3e} grad_context {g0:.3e} per layer " + " ".join(f"{v:.3f}" for v in l0))
+    print(f"[{tag}] f32 storage : eps {e1:.3e} grad_context {g1:.3e} per layer " + " ".join(f"{v:.3f}" for v in l1))
+    assert g0 < 2e-2 and g1 < 2e-2                    # the gate on the shipped mode (measured 1.5e-2 full size, 1.7e-2 narrow)
+    assert max(l0) < 3e-2                             # no single layer's context gradient stands out
+    assert abs(g0 - g1) < 3e-3 and abs(e0 - e1) < 2e-3            # storage format is not where the error comes from
+
+
+def test_training_trajectory_20_optimizer_steps_vs_oracle():
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    from adaprompt_amd.ldm.util import prodigy_linear_schedule
+    from adaprompt_amd.parallel import GradReducer
+    from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
+    from oracle import ldm_oracle as O
+    from oracle.prodigy_oracle import ProdigyOracle, clip_grad_norm, linear_schedule_lrs
+    STEPS, ACC = 20, 1                # (accumulation over two micro-batches is covered by test_training_loop_prodigy_two_optimizer_steps_vs_oracle)
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    torch.manual_seed(3)
+    hook_ref = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
+    with torch.no_grad():
+        hook_ref.bases.mul_(20.0)
+    hook = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
+    hook.load_state_dict(hook_ref.state_dict())
+    hook = hook.to(dev())
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                                  {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
+                                  cond_fn=make_cond_fn(hook, capture=False))
+    usd = synth.synthetic_unet_state_dict(ucfg)
+    ld.load_state_dict(usd, strict=False)
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    ld.manual_accumulate_grad_batches = ACC
+    # d0 3e-4 instead of 1e-6: Prodigy's d then reaches the order of 0.1 inside 20 steps, so the parameters really move and a
+    # difference in the gradients would feed back into the trajectory
+    kw = dict(betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, weight_decay=0.0, d0=3e-4)
+    params = list(hook.parameters())
+    opt = Prodigy(params, lr=1.0, **kw)
+    red = GradReducer(params, flat=opt.grad_buffer)
+    sched = prodigy_linear_schedule(opt, max_steps=STEPS, warm_up_steps=4, scheduler_cycles=1)
+    B = 2
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+    sch = O.make_schedule()
+    ref_params = list(hook_ref.parameters())
+    orc = ProdigyOracle([p.data for p in ref_params], lr=1.0, **kw)
+    lrs = linear_schedule_lrs(1.0, max_steps=STEPS, warm_up_steps=4, scheduler_cycles=1, n=STEPS)
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": False, "img_mask": im64}
+    losses, ds = [], []
+    for mb in range(STEPS * ACC):
+        # the same 4 images come round again and again (a personalisation run sees its few subject images repeatedly):
+        # the loss on them must go down on both sides alike
+        k = mb % 4
+        x0 = synth.synthetic_input(f"traj.x0.{k}", (B, 4, 64, 64))
+        ids = synth.synthetic_input(f"traj.ids.{k}", (B, 32))
+        noise = synth.synthetic_input(f"traj.noise.{mb}", (B, 4, 64, 64))
+        t = torch.tensor([(137 * mb + 50) % 1000, (911 * mb + 400) % 1000])
+        batch = {"zs_id_embs": ids.to(dev()), "fg_mask": fg64[:, 0].to(dev()), "aug_mask": im64[:, 0].to(dev())}
+        loss, _aux = ld.training_step(batch, optimizer=opt, reducer=red, scheduler=sched, t=t.to(dev()),
+                                      noise=noise.to(dev()), x_start=x0.to(dev()))
+        ctx = hook_ref(ids)
+        eps = O.unet_forward(usd, ucfg, O.q_sample(sch, x0, t, noise), t, ctx, extra)
+        loss_ref, _ = O.calc_recon_loss(eps, noise, im64, fg64, 1.0, 0.1)
+        loss_ref.backward()
+        losses.append((float(loss), float(loss_ref.detach())))
+        if (mb + 1) % ACC == 0:
+            grads = [p.grad for p in ref_params]
+            clip_grad_norm(grads, 0.5)
+            orc.lr = lrs[(mb + 1) // ACC - 1]
+            orc.step(grads)
+            for p in ref_params:
+                p.grad = None
+            ds.append((opt.device_state()["d"], orc.d))
+            print(f"step {len(ds):2d}: loss hip {losses[-1][0]:.5f} oracle {losses[-1][1]:.5f}   d hip {ds[-1][0]:.4e} oracle {ds[-1][1]:.4e}", flush=True)
+    print("loss (hip, oracle) every 4th micro-batch:", [(round(a, 5), round(b, 5)) for a, b in losses[::4]])
+    print("d (hip, oracle) per optimizer step:", [(f"{a:.4e}", f"{b:.4e}") for a, b in ds])
+    worst_loss = max(abs(a - b) / b for a, b in losses)
+    worst_d = max(abs(a - b) / b for a, b in ds)
+    print(f"worst relative loss difference {worst_loss:.3e}, worst relative d difference {worst_d:.3e}")
+    assert opt.device_state()["k"] == orc.k == STEPS
+    assert worst_loss < 2e-3                                      # measured 2.4e-4 (the bar asked for: 1e-2)
+    assert worst_d < 2e-2                                         # measured 1.9e-3 (the bar asked for: 5e-2)
+    assert ds[-1][1] > ds[0][1]                                   # d did adapt over the run
