@@ -98,15 +98,28 @@ def build_model(device, seed=0):
     return ld, hook
 
 
-def cpu_baseline(threads):
-    """the oracle (a CPU port of the reference path, pinned by the reference's golden vectors) on the host cores:
-    ONE image of the same pure-recon step at full SD-1.5 size."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(threads, batch=1, timed=3):
+    """the oracle (a CPU port of the reference path, pinned by the reference's golden vectors) on the
+    host cores -- one pure-recon micro-batch (VAE encode -> q_sample -> UNet forward -> masked MSE -> backward to the
+    context) at full SD-1.5 size; 1 warm-up + ``timed`` timed iterations, median.  The default sample is bs=1 (about 25 s of CPU
+    work in all); ``--cpu-batch 4`` times the section's bs=4 unit."""
     from adaprompt_amd import synth
     from oracle import ldm_oracle as O
     torch.set_num_threads(threads)
     usd = synth.synthetic_unet_state_dict()
     vsd = synth.synthetic_vae_state_dict()
-    B = 1
+    B = batch
     g = torch.Generator().manual_seed(7)
     img = (torch.randn(B, 3, 512, 512, generator=g) * 0.5).clamp(-1, 1)
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
@@ -116,15 +129,24 @@ def cpu_baseline(threads):
     fg64 = torch.nn.functional.interpolate(fg, size=(64, 64), mode="nearest")
     im64 = torch.nn.functional.interpolate(aug, size=(64, 64), mode="nearest")
     ctx = torch.randn(16 * B, 77, 768, generator=g) * 0.05
-    t0 = time.time()
-    O.recon_step(usd, vsd, dict(synth.SD15_UNET), dict(synth.SD15_VAE_DD), img, {"fg_mask": fg, "aug_mask": aug},
-                 torch.randn(B, 4, 64, 64, generator=g), torch.tensor([500]), torch.randn(B, 4, 64, 64, generator=g), ctx,
-                 im64, fg64, 0.1, need_grad=True)
-    dt = time.time() - t0
+    times = []
+    for i in range(1 + timed):
+        pn, nz = torch.randn(B, 4, 64, 64, generator=g), torch.randn(B, 4, 64, 64, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        t0 = time.time()
+        O.recon_step(usd, vsd, dict(synth.SD15_UNET), dict(synth.SD15_VAE_DD), img, {"fg_mask": fg, "aug_mask": aug},
+                     pn, t, nz, ctx, im64, fg64, 0.1, need_grad=True)
+        if i > 0:
+            times.append(time.time() - t0)
+    times.sort()
+    dt = times[len(times) // 2]
     return {"value": round(B / dt, 5), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "1 image (bs=1, 1 step) of the same pure-recon step at full SD-1.5 size: VAE encode + UNet fwd + "
-                      "bwd-to-context, oracle/ldm_oracle.py (torch fp32) on the host CPU",
-            "seconds": round(dt, 2)}
+            "cpu_model": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"bs={B} pure-recon micro-batch at full SD-1.5 size (VAE encode + q_sample + UNet fwd + masked MSE + "
+                      f"bwd to the context; MSE only -- the GPU step additionally computes the iteration's auxiliary losses and "
+                      f"the optimiser step), oracle/ldm_oracle.py (torch fp32), 1 warm-up + {timed} timed, median",
+            "seconds_per_micro_batch": round(dt, 2), "timed_seconds": [round(x, 2) for x in times],
+            "achieved_gflops": round(GFLOP_PER_IMAGE * B / dt, 1)}
 
 
 def main():
@@ -142,6 +164,7 @@ def main():
                     help="replay the micro-batch as two hipGraphs (fwd, bwd) instead of launching eagerly; measured "
                          "45.1 vs 44.3 ms/step on MI355X -- the step is GPU-bound, not launch-bound, so eager is the default")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-batch", type=int, default=1, help="batch of the cpu_baseline sample (BASELINE.md section 3 unit: 4)")
     ap.add_argument("--no-ddim", action="store_true",
                     help="skip the extra leg that times config 5 (50-step DDIM at bs=8 with guidance + VAE decode)")
     ap.add_argument("--no-clock-probe", action="store_true",
@@ -608,7 +631,7 @@ def main():
         threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         del ld, hook, reducer, opt, sched
         torch.cuda.empty_cache()
-        cpu = cpu_baseline(threads)
+        cpu = cpu_baseline(threads, batch=args.cpu_batch)
 
     if rank == 0:
         imgs = world * B * args.steps
