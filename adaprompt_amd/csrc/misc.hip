@@ -39,6 +39,36 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MLP activation of the CLIP vision encoder (HF `ACT2FN`: "quick_gelu" x * sigmoid(1.702 x) for the OpenAI checkpoints,
+// "gelu" (erf) for the LAION ones): f32 [rows][cols] (the fc1 accumulator output) -> bf16 operand of fc2.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, long ldx, uint16_t* __restrict__ out, long ldo,
+                                                      long rows, int cols, int kind) {
+    const int ch_per_row = cols / 8;
+    const long total = rows * ch_per_row;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx / ch_per_row;
+        int ch = (int)(idx - r * ch_per_row);
+        const float4 a = *(const float4*)(x + r * ldx + ch * 8);
+        const float4 b = *(const float4*)(x + r * ldx + ch * 8 + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = kind == 0 ? v[e] / (1.0f + __expf(-1.702f * v[e])) : gelu_f(v[e]);
+        *(uint4*)(out + r * ldo + ch * 8) = pack_bf16x8(o);
+    }
+}
+
+extern "C" int adap_act_fwd(const float* x, long ldx, void* out, long ldo, long rows, int cols, int kind, void* stream) {
+    ADAP_REQUIRE(x && out, ADAP_ERR_SHAPE, "act_fwd: null pointer");
+    ADAP_REQUIRE(cols % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0 && ldx >= cols && ldo >= cols, ADAP_ERR_ALIGN, "act_fwd: alignment");
+    ADAP_REQUIRE(kind == 0 || kind == 1, ADAP_ERR_UNSUPPORTED, "act_fwd: kind %d (0 = quick_gelu, 1 = gelu)", kind);
+    if (rows == 0) return ADAP_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (uint16_t*)out, ldo, rows, cols, kind);
+    return adap_check_launch("act_fwd");
+}
+
 extern "C" int adap_geglu_fwd(const void* h, long ldh, void* out, long ldo, long rows, int inner, void* stream) {
     ADAP_REQUIRE(h && out, ADAP_ERR_SHAPE, "geglu_fwd: null pointer");
     ADAP_REQUIRE(inner % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0 && ldh >= 2 * inner, ADAP_ERR_ALIGN, "geglu_fwd: alignment");

@@ -340,8 +340,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None, want_bf16=Fals
 # attention
 # --------------------------------------------------------------------------------------------
 
-def attention_fwd(q, k, v, heads, key_mask=None):
-    """q [B,N,C], k/v [B,M,C] bf16 -> out [B,N,C] bf16, lse [B,H,N] f32."""
+def attention_fwd(q, k, v, heads, key_mask=None, scale=None):
+    """q [B,N,C], k/v [B,M,C] bf16 -> out [B,N,C] bf16, lse [B,H,N] f32.  ``scale``: the score scale (default d^-1/2)."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
@@ -352,8 +352,8 @@ def attention_fwd(q, k, v, heads, key_mask=None):
         assert key_mask.dtype == torch.uint8 and key_mask.shape == (B, M) and key_mask.is_contiguous()
     e0 = TIMER.start() if TIMER is not None else None
     _lib.call("adap_attention_fwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
-              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d, float(d) ** -0.5,
-              _stream())
+              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d,
+              float(d) ** -0.5 if scale is None else float(scale), _stream())
     if e0 is not None:
         TIMER.stop("attention_fwd", 4.0 * B * heads * N * M * d, e0, f"N={N} M={M} d={d}")      # QK^T + PV, SURVEY.md 8d
     return out, lse
@@ -444,6 +444,16 @@ def geglu_fwd(h):
     inner = h.shape[-1] // 2
     out = torch.empty(tuple(h.shape[:-1]) + (inner,), device=h.device, dtype=BF16)
     _lib.call("adap_geglu_fwd", h.data_ptr(), ldh, out.data_ptr(), inner, rows, inner, _stream())
+    return out
+
+
+def act_fwd(x, kind):
+    """x f32 [..., C] -> bf16: ``kind`` "quick_gelu" | "gelu" (the CLIP vision MLP's activation)."""
+    assert x.dtype == F32
+    rows, ldx = _rows_ld(x)
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _lib.call("adap_act_fwd", x.data_ptr(), ldx, out.data_ptr(), x.shape[-1], rows, x.shape[-1],
+              {"quick_gelu": 0, "gelu": 1}[kind], _stream())
     return out
 
 

@@ -250,3 +250,31 @@ def synthetic_vae_state_dict(ddconfig=None, embed_dim=4, seed=0, prefix="first_s
     if decoder:
         shapes = shapes + vae_decoder_param_shapes(embed_dim=embed_dim, **dd)
     return synthetic_like(shapes, seed, prefix)
+
+
+def clip_vision_param_shapes(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, image_size=224, patch_size=14,
+                             **_unused):
+    """(name, shape) of HF ``CLIPVisionModel`` (transformers modeling_clip.py: CLIPVisionEmbeddings / CLIPEncoderLayer),
+    with the ``vision_model.`` prefix transformers < 5 uses (the reference's checkpoints, ddpm.py:904-914)."""
+    H, I = hidden_size, intermediate_size
+    P = "vision_model."
+    out = [(P + "embeddings.class_embedding", (H,)), (P + "embeddings.patch_embedding.weight", (H, 3, patch_size, patch_size)),
+           (P + "embeddings.position_embedding.weight", ((image_size // patch_size) ** 2 + 1, H)),
+           (P + "pre_layrnorm.weight", (H,)), (P + "pre_layrnorm.bias", (H,))]
+    for i in range(num_hidden_layers):
+        L = f"{P}encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            out += [(L + f"self_attn.{n}.weight", (H, H)), (L + f"self_attn.{n}.bias", (H,))]
+        out += [(L + "layer_norm1.weight", (H,)), (L + "layer_norm1.bias", (H,)),
+                (L + "mlp.fc1.weight", (I, H)), (L + "mlp.fc1.bias", (I,)), (L + "mlp.fc2.weight", (H, I)), (L + "mlp.fc2.bias", (H,)),
+                (L + "layer_norm2.weight", (H,)), (L + "layer_norm2.bias", (H,))]
+    out += [(P + "post_layernorm.weight", (H,)), (P + "post_layernorm.bias", (H,))]
+    return out
+
+
+def synthetic_clip_vision_state_dict(cfg, seed=0):
+    sd = synthetic_like(clip_vision_param_shapes(**cfg), seed)
+    # the class token and the position table at the scale of the patch tokens (a 1-D "embedding" is not a bias)
+    sd["vision_model.embeddings.class_embedding"] = sd["vision_model.embeddings.class_embedding"] * 10.0
+    sd["vision_model.embeddings.position_embedding.weight"] = sd["vision_model.embeddings.position_embedding.weight"] * 10.0
+    return sd

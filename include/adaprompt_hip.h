@@ -179,6 +179,13 @@ int adap_geglu_fwd(const void* h, long ldh, void* out, long ldo, long rows, int 
 int adap_geglu_bwd(const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, long rows,
                    int inner, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MLP activation of the zero-shot front end's CLIP vision encoder (ddpm.py:904-914 loads HF `CLIPVisionModel`; its
+ * `CLIPMLP` applies ACT2FN[config.hidden_act] between fc1 and fc2): x f32 [rows][cols] -> bf16 [rows][cols].
+ * kind 0 = "quick_gelu" x * sigmoid(1.702 x) (openai/clip-vit-large-patch14), 1 = "gelu" (erf; the LAION checkpoints).
+ */
+int adap_act_fwd(const float* x, long ldx, void* out, long ldo, long rows, int cols, int kind, void* stream);
+
 /* time_embed MLP openaimodel.py:518-522 and ResBlock emb_layers :217-223 (R <= 8 rows, exact f32):
  * y[r][n] = post( bias[n] + sum_k pre(x[r][k]) w[n][k] ), pre/post = SiLU when the flag is set. */
 int adap_linear_small(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
