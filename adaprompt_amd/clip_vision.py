@@ -93,6 +93,11 @@ class CLIPVisionModelWithMask(nn.Module):
         self._packs = WeightCache()
         self.requires_grad_(False)
 
+    @property
+    def stop_before_last_layer(self):
+        """the ``layers_needed`` that makes ``hidden_states[-1]`` the full model's ``hidden_states[-2]``"""
+        return self.config.num_hidden_layers - 1
+
     @classmethod
     def from_config(cls, config):
         """``config``: a HF ``CLIPVisionConfig`` (or anything with its attribute names)."""

@@ -14,6 +14,7 @@ import random
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from ...util import (anneal_add_noise_to_embedding, anneal_value, distribute_embedding_to_M_tokens_by_dict, halve_token_indices,
                      join_dict_of_indices_with_key_filter, merge_cls_token_embeddings, repeat_selected_instances)
@@ -335,8 +336,112 @@ class ConditioningMixin:
                 f = f.mean(dim=0, keepdim=True)
                 e = torch.nn.functional.normalize(e.mean(dim=0, keepdim=True), p=2, dim=-1)
             return f, e, 0
+        images = batch["image_unnorm"].permute(0, 3, 1, 2)
+        masks = None if fg_mask is None else fg_mask.squeeze(1)
+        if getattr(self, "clip_image_encoder", None) is not None:                 # the reference's own front end, mirrored
+            return self.encode_zero_shot_image_features(images, masks, image_paths=batch.get("image_path"), is_face=is_face,
+                                                        calc_avg=calc_avg)
         enc = getattr(self, "zero_shot_encoder", None)
         if enc is None:
-            raise RuntimeError("the batch carries no zs_clip_features / zs_id_embs and no zero_shot_encoder is attached")
-        images = batch["image_unnorm"].permute(0, 3, 1, 2)
-        return enc(images, None if fg_mask is None else fg_mask.squeeze(1), is_face=is_face, calc_avg=calc_avg)
+            raise RuntimeError("the batch carries no zs_clip_features / zs_id_embs and no image encoders are attached "
+                               "(set_zero_shot_image_encoders) nor a zero_shot_encoder callable")
+        return enc(images, masks, is_face=is_face, calc_avg=calc_avg)
+
+    # ---- the zero-shot feature front end (ddpm.py:904-941, 2322-2471) -----------------------------------
+    def set_zero_shot_image_encoders(self, clip_image_encoder, clip_preprocessor, insightface_app=None, dino_encoder=None,
+                                     dino_preprocess=None):
+        """What ``instantiate_zero_shot_image_encoders`` (ddpm.py:904-941) builds from downloaded third-party weights, handed
+        over instead: ``clip_image_encoder(pixel_values, attn_mask=, output_hidden_states=True)`` with the reference's
+        ``CLIPVisionModelWithMask`` contract -- ``adaprompt_amd.clip_vision.CLIPVisionModelWithMask`` is that model on the
+        MI355X kernels; ``clip_preprocessor(images=, return_tensors="pt").pixel_values`` (HF ``CLIPImageProcessor``);
+        ``insightface_app.get(bgr_image)`` (ArcFace, ONNX) and the DINO pair for non-face subjects stay third-party."""
+        self.clip_image_encoder, self.clip_preprocessor = clip_image_encoder, clip_preprocessor
+        self.insightface_app, self.dino_encoder, self.dino_preprocess = insightface_app, dino_encoder, dino_preprocess
+        self.neg_image_features = None
+        self.zs_image_encoders_instantiated = True
+
+    def instantiate_zero_shot_image_encoders(self, clip_type="openai"):
+        raise RuntimeError("the zero-shot image encoders need third-party checkpoints (HF CLIP, insightface antelopev2, DINO): "
+                           "build them and hand them over with set_zero_shot_image_encoders(...)")
+
+    def encode_zero_shot_image_features(self, images, fg_masks, image_paths=None, is_face=True, size=(512, 512), calc_avg=False,
+                                        skip_non_faces=False, verbose=False):
+        """ddpm.py:2322-2471.  Per image: CLIP pixel values from the preprocessor; the identity embedding from insightface
+        (the largest detected face; a random vector when none is found, or the image is skipped) or DINO's class token for
+        non-faces.  Then the image encoder runs twice under no_grad -- foreground mask, background mask (1 - mask) -- and once,
+        cached, on an all-zero image; the features are the penultimate hidden states minus the zero image's, times the token
+        mask, concatenated along tokens: [BS, 514, D].  ``calc_avg``: mean over the batch, identity embedding re-normalised.
+        -> (clip_features, id_embs, faceless_img_count)."""
+        if not getattr(self, "zs_image_encoders_instantiated", False):
+            self.instantiate_zero_shot_image_encoders()
+        dev = self.device
+        pixel_values, all_id_embs, faceless = [], [], 0
+        for idx, image in enumerate(images):
+            pixel_values.append(self.clip_preprocessor(images=image, return_tensors="pt").pixel_values)
+            if is_face and self.insightface_app is not None:
+                if isinstance(image, torch.Tensor):
+                    image = image.cpu().numpy().transpose(1, 2, 0)
+                from PIL import Image
+                image = np.array(Image.fromarray(image).resize(size, Image.NEAREST))
+                faces = self.insightface_app.get(np.ascontiguousarray(image[..., ::-1]))           # RGB -> BGR
+                if len(faces) == 0 and not skip_non_faces:
+                    print(f"No face detected in {image_paths[idx]}. Use random face embedding.")
+                    id_emb = torch.randn(512, device=dev)
+                    faceless += 1
+                elif len(faces) > 0:
+                    # (the reference's key is (x2 - x1) * y2 - y1 -- precedence as written there, ddpm.py:2355)
+                    face = sorted(faces, key=lambda f: (f["bbox"][2] - f["bbox"][0]) * f["bbox"][3] - f["bbox"][1])[-1]
+                    id_emb = torch.from_numpy(face.normed_embedding).to(dev)
+                else:
+                    print(f"Skip image without face: {image_paths[idx]}")
+                    continue
+                all_id_embs.append(id_emb)
+            elif not is_face:
+                dino_input = self.dino_preprocess(images=image, return_tensors="pt").to(dev)
+                all_id_embs.append(self.dino_encoder(**dino_input).last_hidden_state[0, 0])
+        if verbose:
+            print(f"{len(all_id_embs)} face images identified, {faceless} faceless images.")
+        pixel_values = torch.cat(pixel_values, dim=0).to(dev)
+        all_id_embs = torch.stack(all_id_embs, dim=0) if self.insightface_app is not None else None
+        hw = pixel_values.shape[-2:]
+        if fg_masks is not None:
+            assert len(fg_masks) == len(images)
+            if isinstance(fg_masks, (list, tuple)):
+                m2 = [F.interpolate(torch.as_tensor(m, device=dev).float()[None, None], size=hw, mode="bilinear", align_corners=False)
+                      for m in fg_masks]
+                fg_masks2 = torch.cat(m2, dim=0).squeeze(1)
+            else:
+                fg_masks2 = F.interpolate(torch.as_tensor(fg_masks, device=dev).float().unsqueeze(1), size=hw, mode="bilinear",
+                                          align_corners=False).squeeze(1)
+        else:
+            fg_masks2 = torch.ones_like(pixel_values[:, 0])
+        enc = self.clip_image_encoder
+        # only the penultimate hidden states are read: an encoder that can stop there is asked to (the MI355X one can)
+        n_layers = getattr(enc, "stop_before_last_layer", None)
+        kw, pen = ({}, -2) if n_layers is None else ({"layers_needed": n_layers}, -1)
+        with torch.no_grad():
+            if self.neg_image_features is None:
+                self.neg_image_features = enc(torch.zeros_like(pixel_values[:1]).half(), attn_mask=None,
+                                              output_hidden_states=True, **kw).hidden_states[pen]
+            feats = []
+            if n_layers is not None:
+                # the MI355X encoder: foreground and background pass as ONE batch of 2 BS (samples are independent; twice
+                # the rows per contraction, half the launches)
+                pv2 = torch.cat([pixel_values.half(), pixel_values.half()], dim=0)
+                out = enc(pv2, attn_mask=torch.cat([fg_masks2.half(), 1 - fg_masks2.half()], dim=0), output_hidden_states=True, **kw)
+                f = (out.hidden_states[pen] - self.neg_image_features) * out.attn_mask
+                feats = list(f.chunk(2, dim=0))
+            else:
+                for mask in (fg_masks2.half(), 1 - fg_masks2.half()):
+                    out = enc(pixel_values.half(), attn_mask=mask, output_hidden_states=True, **kw)
+                    f = out.hidden_states[pen] - self.neg_image_features
+                    if out.attn_mask is not None:
+                        f = f * out.attn_mask
+                    feats.append(f)
+        clip_features = torch.cat(feats, dim=1).to(pixel_values.dtype)
+        if calc_avg:
+            clip_features = clip_features.mean(dim=0, keepdim=True)
+            id_embs = None if all_id_embs is None else F.normalize(all_id_embs.mean(dim=0, keepdim=True), p=2, dim=-1)
+        else:
+            id_embs = all_id_embs
+        return clip_features, id_embs, faceless

@@ -226,6 +226,10 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         # CLIP text-image similarity of decoded images (evaluation/clip_eval.py:CLIPEvaluator.txt_to_img_similarity with
         # reduction='diag' in the reference, ddpm.py:3624-3627): a callable behind the boundary, set by the trainer
         self.clip_score_fn = None
+        # the zero-shot feature front end's third-party encoders (conditioning.set_zero_shot_image_encoders)
+        self.clip_image_encoder = self.clip_preprocessor = self.insightface_app = None
+        self.dino_encoder = self.dino_preprocess = self.neg_image_features = None
+        self.zs_image_encoders_instantiated = False
         self.empty_context_2b = self.empty_context_tea_filter = None
         self.batch_idx = 0
         self.is_dreambooth = False

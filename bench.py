@@ -172,6 +172,7 @@ def main():
                          "would dominate a rocprofv3 --stats average of the dominant kernel)")
     ap.add_argument("--no-unfrozen", action="store_true",
                     help="skip the `unfreeze_model: True` leg (weight gradients + 4.5 GB optimiser / all-reduce payload)")
+    ap.add_argument("--no-zs-frontend", action="store_true", help="skip the zero-shot front end leg (CLIP ViT-L/14 image encoder)")
     ap.add_argument("--no-compos", action="store_true", help="skip the config-4 leg (Stage-2 compositional micro-batches)")
     ap.add_argument("--no-distill-mix", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
@@ -528,6 +529,11 @@ def main():
     if world == 1 and not args.no_compos:
         compos = compos_leg(device, gen)
 
+    # ---- extra leg: the zero-shot feature front end's image encoder, which runs in every zero-shot iteration
+    zs_front = None
+    if world == 1 and not args.no_zs_frontend:
+        zs_front = zs_frontend_leg(device, gen)
+
     # ---- extra leg: config 5 -- 50 DDIM steps at bs=8 (UNet batch 16 under classifier-free guidance,
     # context [256,77,768]) and the VAE decode of the 8 latents
     ddim = None
@@ -662,6 +668,8 @@ def main():
             res["config2_distill_mix"] = distill
         if compos is not None:
             res["config4_compos"] = compos
+        if zs_front is not None:
+            res["f4_zero_shot_frontend"] = zs_front
         if ddim is not None:
             res["config5_ddim"] = ddim
         if unfrozen is not None:
@@ -751,6 +759,42 @@ def compos_leg(device, gen, micro_batches=8):
                         "start from the cached prediction); text encoder / embedding manager / CLIP are stand-ins",
             "micro_batches": micro_batches, "iteration_kinds": kinds, "ms_per_micro_batch": round(1e3 * dt / micro_batches, 2),
             "images_per_sec": round(B * micro_batches / dt, 2), "final_loss": round(float(loss), 6)}
+
+
+def zs_frontend_leg(device, gen, iters=10):
+    """ddpm.py:2411-2431 for one bs=4 batch: the CLIP ViT-L/14 image encoder (openai/clip-vit-large-patch14 topology, random
+    init) twice under no_grad -- foreground mask, background mask -- up to the penultimate hidden states, [4,257,1024] each.
+    Algorithmic FLOPs per image and pass: 23 layers x (8 H^2 N + 4 N^2 H + 4 H I N) + the patch embedding."""
+    from adaprompt_amd import synth
+    from adaprompt_amd.clip_vision import CLIPVisionModelWithMask
+    cfg = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224, patch_size=14,
+               hidden_act="quick_gelu")
+    with torch.device(device):
+        enc = CLIPVisionModelWithMask(**cfg)
+    enc.load_hf_state_dict(device_state_dict(synth.clip_vision_param_shapes(**cfg), "", device, 31))
+    B, N, H, I = 4, 257, 1024, 4096
+    pv = torch.randn(B, 3, 224, 224, device=device, generator=gen).half()
+    mask = (torch.rand(B, 224, 224, device=device, generator=gen) > 0.5).half()
+    n = enc.stop_before_last_layer
+
+    def once():          # as conditioning.encode_zero_shot_image_features drives it: both passes as one batch of 8
+        h = enc(torch.cat([pv, pv]), attn_mask=torch.cat([mask, 1 - mask]), layers_needed=n).hidden_states[-1]
+        return h.chunk(2)
+
+    for _ in range(3):
+        a, b = once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        a, b = once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    flop = 2 * B * (n * (8 * H * H * N + 4 * N * N * H + 4 * H * I * N) + 2 * 256 * 588 * H)
+    return {"workload": "zero-shot front end: CLIP ViT-L/14 image encoder (24 layers, width 1024, 16 heads, 257 tokens), bs=4, the "
+                        "reference's two passes with its additive foreground-pair attention bias (mask, 1 - mask) run as one batch "
+                        "of 8, stopped before the last layer; preprocessing and ArcFace stay third-party",
+            "ms_per_batch": round(1e3 * dt, 3), "images_per_sec": round(B / dt, 1), "algorithmic_tflop": round(flop / 1e12, 3),
+            "achieved_tflops": round(flop / dt / 1e12, 1), "finite": bool(torch.isfinite(a).all() and torch.isfinite(b).all())}
 
 
 def spawn_ranks(n):

@@ -11,7 +11,7 @@ from test_bench_contract import check_bench_line
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-LEGS_OFF = ["--no-distill-mix", "--no-ddim", "--no-unfrozen", "--no-compos", "--no-clock-probe"]
+LEGS_OFF = ["--no-distill-mix", "--no-ddim", "--no-unfrozen", "--no-compos", "--no-zs-frontend", "--no-clock-probe"]
 
 
 def run_bench(*args, timeout=600):

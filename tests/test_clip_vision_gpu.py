@@ -75,3 +75,37 @@ def test_clip_vision_with_mask_vs_transformers_blocks(name):
     # the front end's short cut: stop before the last layer, hidden_states[-1] is then the reference's hidden_states[-2]
     out = m(x.to(DEV), attn_mask=mask.to(DEV), layers_needed=cfg["num_hidden_layers"] - 1)
     assert rel_err(G.sub(out.hidden_states[-1].cpu()), torch.from_numpy(g["masked.penultimate"])) < 1e-2
+
+
+def test_zero_shot_front_end_with_the_hip_encoder_vs_oracle_encoder():
+    """``encode_zero_shot_image_features`` end to end: preprocessor stand-in -> HIP image encoder (foreground pass, background
+    pass, cached zero-image pass, stopping before the last layer) -> [BS,514,D] features, against the same host code driving
+    the oracle encoder on the CPU."""
+    import types
+    import make_golden_zeroshot as Z
+    from adaprompt_amd.clip_vision import CLIPVisionModelWithMask
+    from adaprompt_amd.ldm.models.diffusion.conditioning import ConditioningMixin
+    from oracle import clip_vision_oracle as O
+    cfg = G.CASES["narrow_quick"]
+    sd = synth.synthetic_clip_vision_state_dict(cfg)
+    hip = CLIPVisionModelWithMask(**cfg)
+    hip.load_hf_state_dict(sd)
+    hip = hip.to(DEV)
+
+    def oracle_encoder(pixel_values, attn_mask=None, output_hidden_states=True):
+        out = O.clip_vision_forward(sd, cfg, pixel_values.float(), None if attn_mask is None else attn_mask.float())
+        return types.SimpleNamespace(hidden_states=out["hidden_states"], attn_mask=out["attn_mask"])
+
+    img, mask = Z.images_case(11, B=3, hw=96)
+    res = []
+    for dev, enc in ((DEV, hip), ("cpu", oracle_encoder)):
+        obj = types.SimpleNamespace(device=torch.device(dev), clip_preprocessor=Z.FakePreprocessor(), clip_image_encoder=enc,
+                                    insightface_app=Z.FakeInsightFace(), dino_encoder=None, dino_preprocess=None,
+                                    neg_image_features=None, zs_image_encoders_instantiated=True)
+        feats, ids, faceless = ConditioningMixin.encode_zero_shot_image_features(obj, img.to(dev), mask.to(dev),
+                                                                                 image_paths=["a", "b", "c"], calc_avg=True)
+        res.append((feats.cpu(), ids.cpu(), faceless))
+    (fh, ih, nh), (fo, io, no) = res
+    assert tuple(fh.shape) == (1, 514, cfg["hidden_size"]) and nh == no == 0
+    assert torch.allclose(ih, io, atol=1e-6)
+    assert rel_err(fh, fo) < 1e-2, rel_err(fh, fo)
