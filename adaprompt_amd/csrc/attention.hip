@@ -598,12 +598,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
         if (r >= 0 && (r >> 1) < ntiles) {
             const int t = r >> 1;
             if ((r & 1) == 0) {
-                __builtin_amdgcn_s_setprio(0);
+                if (p.qsplit == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
                 softmax(t);
+                __builtin_amdgcn_s_setprio(0);
             } else {
                 // the matrix phase issues first: its 28 MFMAs take 8 issue cycles each and keep the pipe busy for 32; left at equal
                 // priority the vector-phase partner (when it is the older wave) starves them (stamps: 2340 vs 1590 ticks)
-                __builtin_amdgcn_s_setprio(2);
+                if (p.qsplit == 1) __builtin_amdgcn_s_setprio(2);
                 mm_phase(t, true, t + 1 < ntiles);
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -1069,6 +1070,12 @@ static int launch_fwd_pp(const AttnParams& p, hipStream_t s) {
     dim3 grid((p.N + 511) / 512, p.B * p.H);
     AttnParams pp = p;
     pp.part = (float*)g_attn_stamps;          // diagnostic stamps (null in normal runs)
+    static int prio_mode = -1;                // which phase runs at raised priority: 1 = matrix (default), 2 = vector, 0 = neither
+    if (prio_mode < 0) {
+        const char* e = getenv("ADAP_ATTN_PP_PRIO");
+        prio_mode = e ? atoi(e) : 1;
+    }
+    pp.qsplit = prio_mode;                    // (qsplit is a backward-only field: reused to carry the mode)
     hipLaunchKernelGGL((attn_fwd_pp_kernel<KS, VT>), grid, dim3(512), lds, s, pp);
     g_attn_fwd_variant = 3;
     return adap_check_launch("attn_fwd (ping-pong)");

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""The 64x64 self-attention forward under sustained load (the clock the chip holds in the training step, not the first
+launches' boost clock): 400 warm-up launches, then 400 timed.  ADAP_ATTN_PP_PRIO / ADAP_ATTN_NO_PP select the variant."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from adaprompt_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+B, H, N, d = 4, 8, 4096, 40
+q, k, v = (torch.randn(B, N, H * d, device=dev).to(torch.bfloat16) for _ in range(3))
+for _ in range(400):
+    ops.attention_fwd(q, k, v, H)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(400):
+    ops.attention_fwd(q, k, v, H)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 400 * 1e3
+print(f"prio={os.environ.get('ADAP_ATTN_PP_PRIO', '1')} no_pp={os.environ.get('ADAP_ATTN_NO_PP', '0')} variant "
+      f"{_lib.call_long('adap_attention_fwd_last_variant')}: {us:.1f} us  {4.0 * B * H * N * N * d / us / 1e6:.1f} TF/s", flush=True)
