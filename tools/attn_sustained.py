@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The 64x64 self-attention forward under sustained load (the clock the chip holds in the training step, not the first
-launches' boost clock): 400 warm-up launches, then 400 timed.  ADAP_ATTN_PP_PRIO / ADAP_ATTN_NO_PP select the variant."""
+launches' boost clock): 400 warm-up launches, then 400 timed.  ADAP_ATTN_FORCE_PP=1 selects the ping-pong kernel, ADAP_ATTN_PP_PRIO its priority mode."""
 import os
 import sys
 
@@ -22,5 +22,5 @@ for _ in range(400):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 400 * 1e3
-print(f"prio={os.environ.get('ADAP_ATTN_PP_PRIO', '1')} no_pp={os.environ.get('ADAP_ATTN_NO_PP', '0')} variant "
+print(f"prio={os.environ.get('ADAP_ATTN_PP_PRIO', '1')} force_pp={os.environ.get('ADAP_ATTN_FORCE_PP', '0')} variant "
       f"{_lib.call_long('adap_attention_fwd_last_variant')}: {us:.1f} us  {4.0 * B * H * N * N * d / us / 1e6:.1f} TF/s", flush=True)
