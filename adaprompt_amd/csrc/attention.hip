@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
                     S[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][s], S[qb][t], 0, 0, 0);
             }
         }
-        const bool biased = sBias[64] != 0.f;           // wave-uniform: ragged / masked tile
+        // wave-uniform: ragged / masked tile (not even looked at when there is no key mask and the tile is not the ragged last one)
+        const bool biased = (p.kmask != nullptr || (!more && (p.M & 63) != 0)) && sBias[64] != 0.f;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             if (biased) {
