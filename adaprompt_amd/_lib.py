@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "adaprompt_hip.h")
 LIB_PATH = os.path.join(HERE, "libadaprompt_hip.so")
 
-ABI_VERSION = 2        # bumped whenever an entry point's argument list changes (capi.hip returns the same number)
+ABI_VERSION = 3        # bumped whenever an entry point's argument list changes (capi.hip returns the same number)
 
 _SCALARS = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 

@@ -56,6 +56,7 @@ struct AttnParams {
     const uint16_t* k; long ldk;
     const uint16_t* v; long ldv;
     const uint8_t* kmask;       // [B][M] (1 = keep) or null
+    const int* mcount;          // [B] or null: sample b attends to its first mcount[b] keys only (compacted keys, rows >= count unused)
     uint16_t* o; long ldo;      // fwd out (bf16)
     float* lse;                 // [B][H][N]
     // backward
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
-    const int ntiles = (p.M + 63) / 64;
+    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count
+    const int ntiles = (Mb + 63) / 64;
     TileRegs<G::NCH> rK, rV;
     TileMap<G::NCH> mapK, mapV;
     mapK.init(p.ldk, KSTRIDE, d, tid);
@@ -215,15 +217,15 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
         if (tid < 64) {
             int key = key0 + tid;
             float bias = 0.f;
-            if (key >= p.M) bias = -INFINITY;
+            if (key >= Mb) bias = -INFINITY;
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
             unsigned long long any = __ballot(bias != 0.f);
             if (tid == 0) sBias[64] = any ? 1.f : 0.f;
         }
     };
-    tile_load(rK, mapK, kb, min(64, p.M));
-    tile_load(rV, mapV, vb, min(64, p.M));
+    tile_load(rK, mapK, kb, min(64, Mb));
+    tile_load(rV, mapV, vb, min(64, Mb));
     tile_store(rK, mapK, sKV);
     tile_store(rV, mapV, sKV + 64 * KSTRIDE);
     key_bias(0, sBiasAll);
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
         const float* sBias = sBiasAll + (kt & 1) * 68;
         if (more) {
             const int key1 = (kt + 1) * 64;
-            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, p.M - key1));
-            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, p.M - key1));
+            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, Mb - key1));
+            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, Mb - key1));
         }
         f32x16 S[QB][2];
 #pragma unroll
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
             }
         }
         // wave-uniform: ragged / masked tile (not even looked at when there is no key mask and the tile is not the ragged last one)
-        const bool biased = (p.kmask != nullptr || (!more && (p.M & 63) != 0)) && sBias[64] != 0.f;
+        const bool biased = (p.kmask != nullptr || (!more && (Mb & 63) != 0)) && sBias[64] != 0.f;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             if (biased) {
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
-    const int ntiles = (p.M + 63) / 64;
+    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count
+    const int ntiles = (Mb + 63) / 64;
     // staging map: thread -> chunk (row, 16-byte column) of a 64-row tile
     const int srow = tid / NCH, sch = tid - srow * NCH;
     const bool sin = tid < 64 * NCH && sch * 8 < d;       // chunk holds data (else zero padding)
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
     const bool sone = slive && ones_col && sch == (d >> 3);
     uint4 rK = make_uint4(0, 0, 0, 0), rV = make_uint4(0, 0, 0, 0);
     auto stage_load = [&](int s) {
-        const int key0 = s * 64, nvalid = min(64, p.M - key0);
+        const int key0 = s * 64, nvalid = min(64, Mb - key0);
         rK = make_uint4(0, 0, 0, 0);
         rV = make_uint4(0, 0, 0, 0);
         if (sin && srow < nvalid) {
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
             float* sBias = sBiasAll + (s % 3) * 68;
             const int key = s * 64 + tid;
             float bias = 0.f;
-            if (key >= p.M) bias = -INFINITY;
+            if (key >= Mb) bias = -INFINITY;
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
             unsigned long long any = __ballot(bias != 0.f);
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
     auto softmax = [&](int t) {                             // S -> P (bf16 fragments), running max with a threshold
         const float* sBias = sBiasAll + (t % 3) * 68;
         // wave-uniform: ragged / masked tile (the flag sits in LDS; not even looked at when neither can be the case)
-        const bool biased = (p.kmask != nullptr || ((p.M & 63) != 0 && t == ntiles - 1)) && sBias[64] != 0.f;
+        const bool biased = (p.kmask != nullptr || ((Mb & 63) != 0 && t == ntiles - 1)) && sBias[64] != 0.f;
         if (biased) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
@@ -744,7 +747,8 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
-    const int ntiles = (p.M + 63) / 64;
+    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count
+    const int ntiles = (Mb + 63) / 64;
     TileRegs<G::NCH> rK, rV;
     TileMap<G::NCH> mapK, mapV;
     mapK.init(p.ldk, KSTRIDE, d, tid);
@@ -753,15 +757,15 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         if (tid < 64) {
             int key = key0 + tid;
             float bias = 0.f;
-            if (key >= p.M) bias = -INFINITY;
+            if (key >= Mb) bias = -INFINITY;
             else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
             sBias[tid] = bias;
             unsigned long long any = __ballot(bias != 0.f);
             if (tid == 0) sBias[64] = any ? 1.f : 0.f;
         }
     };
-    tile_load(rK, mapK, kb, min(64, p.M));
-    tile_load(rV, mapV, vb, min(64, p.M));
+    tile_load(rK, mapK, kb, min(64, Mb));
+    tile_load(rV, mapV, vb, min(64, Mb));
     tile_store(rK, mapK, sK);
     tile_store(rV, mapV, sV);
     key_bias(0);
@@ -770,8 +774,8 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         const bool more = kt + 1 < ntiles;
         if (more) {
             const int key1 = (kt + 1) * 64;
-            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, p.M - key1));
-            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, p.M - key1));
+            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, Mb - key1));
+            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, Mb - key1));
         }
         const bool biased = sBias[64] != 0.f;           // wave-uniform
 #pragma unroll
@@ -854,6 +858,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int key = blockIdx.x * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
+    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count (rows beyond it get zeros)
 
     // this wave's 32 keys as B operands
     bf16x8 kf[KS], vf[KS];
@@ -861,7 +866,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     for (int s = 0; s < KS; ++s) {
         int ch = 2 * s + h;
         uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
-        if (key < p.M && ch * 8 < d) {
+        if (key < Mb && ch * 8 < d) {
             a = *(const uint4*)(p.k + ((size_t)b * p.M + key) * p.ldk + head * d + ch * 8);
             g = *(const uint4*)(p.v + ((size_t)b * p.M + key) * p.ldv + head * d + ch * 8);
         }
@@ -869,7 +874,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
         vf[s] = __builtin_bit_cast(bf16x8, g);
     }
     float bias = 0.f;
-    if (key >= p.M) bias = -INFINITY;
+    if (key >= Mb) bias = -INFINITY;
     else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
     const bool biased = __any(bias != 0.f);              // wave-uniform
 
@@ -898,7 +903,9 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     };
     // this workgroup's slice of the query tiles (the whole range unless the grid was too small to fill the chip)
     const int split = blockIdx.z;
-    const int qt0 = (int)((long)split * ntiles / p.qsplit), qt1 = (int)((long)(split + 1) * ntiles / p.qsplit);
+    const int qt0 = (int)((long)split * ntiles / p.qsplit);
+    // a workgroup whose 128 keys all lie beyond the sample's count has nothing to accumulate: it only writes its zeros
+    const int qt1 = (int)blockIdx.x * 128 >= Mb ? qt0 : (int)((long)(split + 1) * ntiles / p.qsplit);
     tile_load(rQ, mapQ, qb + (size_t)qt0 * 64 * p.ldq, min(64, p.N - qt0 * 64));
     tile_load(rDO, mapDO, dob + (size_t)qt0 * 64 * p.lddo, min(64, p.N - qt0 * 64));
     row_stats_load(qt0 * 64);
@@ -1146,7 +1153,7 @@ static int attn_common_checks(const char* who, int B, int H, int N, int M, int d
 }
 
 extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                                  const uint8_t* key_mask, void* out, long ldo, float* lse,
+                                  const uint8_t* key_mask, const int* key_count, void* out, long ldo, float* lse,
                                   int B, int H, int N, int M, int d, float scale, void* stream) {
     ADAP_REQUIRE(q && k && v && out, ADAP_ERR_SHAPE, "attention_fwd: null pointer");
     int rc = attn_common_checks("attention_fwd", B, H, N, M, d, ldq, ldk, ldv);
@@ -1154,7 +1161,7 @@ extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long l
     ADAP_REQUIRE(ldo % 4 == 0 && ldo >= H * d, ADAP_ERR_ALIGN, "attention_fwd: ldo");
     AttnParams p = {};
     p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
-    p.kmask = key_mask; p.o = (uint16_t*)out; p.ldo = ldo; p.lse = lse;
+    p.kmask = key_mask; p.mcount = key_count; p.o = (uint16_t*)out; p.ldo = ldo; p.lse = lse;
     p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
     ATTN_DISPATCH(launch_fwd, p, (hipStream_t)stream);
 }
@@ -1168,8 +1175,8 @@ extern "C" long adap_attention_bwd_workspace_floats(int B, int H, int N, int M, 
 }
 
 extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                                  const uint8_t* key_mask, const void* out, long ldo, const void* dout, long lddo,
-                                  const float* lse, float* workspace,
+                                  const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
+                                  long lddo, const float* lse, float* workspace,
                                   float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
                                   float* dv32, void* dv16, long lddv,
                                   int B, int H, int N, int M, int d, float scale, void* stream) {
@@ -1187,7 +1194,8 @@ extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long l
                        (const uint16_t*)dout, lddo, delta_ws, B, H, N, d);
     AttnParams p = {};
     p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
-    p.kmask = key_mask; p.lse = (float*)lse; p.dout = (const uint16_t*)dout; p.lddo = lddo; p.delta = delta_ws;
+    p.kmask = key_mask; p.mcount = key_count; p.lse = (float*)lse; p.dout = (const uint16_t*)dout; p.lddo = lddo;
+    p.delta = delta_ws;
     p.dq32 = dq32; p.dq16 = (uint16_t*)dq16; p.lddq = lddq;
     p.dk32 = dk32; p.dk16 = (uint16_t*)dk16; p.lddk = lddk;
     p.dv32 = dv32; p.dv16 = (uint16_t*)dv16; p.lddv = lddv;

@@ -22,7 +22,7 @@ int adap_check_launch(const char* what) {
 
 extern "C" const char* adap_last_error(void) { return g_err; }
 
-extern "C" int adap_abi_version(void) { return 2; }
+extern "C" int adap_abi_version(void) { return 3; }
 
 // 0 on success; fills name (<= 255 chars + NUL), CU count and gcn arch string of the current device
 extern "C" int adap_device_info(char* name, int name_cap, int* num_cus, char* arch, int arch_cap) {

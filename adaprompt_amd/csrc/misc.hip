@@ -69,6 +69,34 @@ extern "C" int adap_act_fwd(const float* x, long ldx, void* out, long ldo, long 
     return adap_check_launch("act_fwd");
 }
 
+// ---------------------------------------------------------------------------------------------
+// row gather of bf16 rows: dst[b][i] = src[b][idx[b][i]] (16 bytes per thread)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint16_t* __restrict__ src, long lds, const int* __restrict__ idx,
+                                                          uint16_t* __restrict__ dst, long ldd, int rows_src, int rows_dst,
+                                                          int cols, long total) {
+    const int cpr = cols / 8;
+    for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long row = t / cpr;
+        const int ch = (int)(t - row * cpr);
+        const long b = row / rows_dst;
+        const int r = idx[row];
+        *(uint4*)(dst + row * ldd + ch * 8) = *(const uint4*)(src + (b * rows_src + r) * lds + ch * 8);
+    }
+}
+
+extern "C" int adap_gather_rows_bf16(const void* src, long lds, const int* idx, void* dst, long ldd, int B, int rows_src,
+                                     int rows_dst, int cols, void* stream) {
+    ADAP_REQUIRE(src && idx && dst, ADAP_ERR_SHAPE, "gather_rows: null pointer");
+    ADAP_REQUIRE(cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && lds >= cols && ldd >= cols, ADAP_ERR_ALIGN, "gather_rows: alignment");
+    ADAP_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ADAP_ERR_ALIGN, "gather_rows: 16-byte base alignment");
+    const long total = (long)B * rows_dst * (cols / 8);
+    if (total == 0) return ADAP_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, lds,
+                       idx, (uint16_t*)dst, ldd, rows_src, rows_dst, cols, total);
+    return adap_check_launch("gather_rows");
+}
+
 extern "C" int adap_geglu_fwd(const void* h, long ldh, void* out, long ldo, long rows, int inner, void* stream) {
     ADAP_REQUIRE(h && out, ADAP_ERR_SHAPE, "geglu_fwd: null pointer");
     ADAP_REQUIRE(inner % 8 == 0 && ldh % 8 == 0 && ldo % 8 == 0 && ldh >= 2 * inner, ADAP_ERR_ALIGN, "geglu_fwd: alignment");

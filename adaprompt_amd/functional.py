@@ -49,6 +49,19 @@ def _op16(t):
     return t if t is None or t.dtype == BF16 else t.to(BF16)
 
 
+class KeyCompaction:
+    """a self-attention key mask [B,N] uint8 with its compaction: ``perm`` / ``inv_perm`` [B,N] int32, ``count`` [B] int32
+    (attention.KeyMasks.compaction)."""
+
+    def __init__(self, mask, perm, inv_perm, count):
+        self.mask, self.perm, self.inv_perm, self.count = mask, perm, inv_perm, count
+
+
+# self-attention with a key mask at N >= this many tokens gathers the kept keys to the front and runs on them alone (two row
+# gathers per layer against ~1/4 of the key tiles at the training masks' border widths); ADAP_COMPACT_KEYS=0 switches it off
+COMPACT_KEYS_MIN_N = 1024 if os.environ.get("ADAP_COMPACT_KEYS", "1") != "0" else 1 << 30
+
+
 class WeightCache:
     """bf16 packs of a module's parameters, rebuilt when a parameter changes (``_version``)."""
 
@@ -260,7 +273,13 @@ class SpatialTransformerFn(torch.autograd.Function):
         qkv = P["qkv1"]
         _, qkv1 = ops.linear(n1, qkv.fwd, 3 * C, out_f32=False, out_bf16=True)
         q1, k1, v1 = qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:]
-        o1, lse1 = ops.attention_fwd(q1, k1, v1, heads, key_mask)
+        kc, kv1c = None, None
+        if isinstance(key_mask, KeyCompaction):
+            kc, key_mask = key_mask, key_mask.mask
+            kv1c = ops.gather_rows_bf16(qkv1[..., C:], kc.perm)                   # kept keys first: [B,N,2C]
+            o1, lse1 = ops.attention_fwd(q1, kv1c[..., :C], kv1c[..., C:], heads, None, key_count=kc.count)
+        else:
+            o1, lse1 = ops.attention_fwd(q1, k1, v1, heads, key_mask)
         to1 = P["to_out1"]
         t1, _ = ops.linear(o1, to1.fwd, C, bias=to1.bias, residual=t0)
         # --- attn2 (cross) ----------------------------------------------------------------------
@@ -296,7 +315,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         pout = P["proj_out"]
         out, _ = ops.linear(t3, pout.fwd, C, bias=pout.bias, residual=x.view(B, N, C))
         ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
-        ctx.key_mask = key_mask
+        ctx.key_mask, ctx.key_compaction, ctx.kv1c = key_mask, kc, kv1c
         ctx.tok_w = tok_w if capture else None
         tr = P.get("train") is not None      # weight gradients also need each contraction's input operand
         ctx.save_for_backward(x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh,
@@ -385,8 +404,16 @@ class SpatialTransformerFn(torch.autograd.Function):
         # self attention
         _, go1 = _lin_bwd(gt1h, P["to_out1"], out_f32=False, out_bf16=True)
         dqkv1 = torch.empty(B, N, 3 * C, device=x.device, dtype=BF16)
-        ops.attention_bwd(qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:], o1, go1, lse1, heads, ctx.key_mask,
-                          dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:])
+        kc = ctx.key_compaction
+        if kc is not None:
+            kv1c, ctx.kv1c = ctx.kv1c, None
+            dkvc = torch.empty(B, N, 2 * C, device=x.device, dtype=BF16)
+            ops.attention_bwd(qkv1[..., :C], kv1c[..., :C], kv1c[..., C:], o1, go1, lse1, heads, None,
+                              dq=dqkv1[..., :C], dk=dkvc[..., :C], dv=dkvc[..., C:], key_count=kc.count)
+            ops.gather_rows_bf16(dkvc, kc.inv_perm, out=dqkv1[..., C:])          # back to pixel order (masked keys: zeros)
+        else:
+            ops.attention_bwd(qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:], o1, go1, lse1, heads, ctx.key_mask,
+                              dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:])
         gn1, _ = _lin_bwd(dqkv1, P["qkv1"])
         if T is not None:
             _dw_lin(T, "to_out1", o1, gt1h)

@@ -82,6 +82,21 @@ class KeyMasks:
             m = self._by_res[(H, W)] = (m2.reshape(m2.shape[0], H * W) != 0).to(torch.uint8).contiguous()
         return m
 
+    def compaction(self, H, W):
+        """(perm, inv_perm, count) of a level, all on the device (no host sync): ``perm`` [B,N] int32 lists a sample's kept
+        keys first (in order), then the masked ones; ``inv_perm`` undoes it; ``count`` [B] int32 = kept keys.  A masked key's
+        softmax weight is exactly 0 (attention.py:223-232 fills its score with -finfo.max), so self-attention over the first
+        ``count`` rows of the permuted K / V is the same arithmetic on fewer key tiles (functional.SpatialTransformerFn)."""
+        c = self._by_res.get((H, W, "compaction"))
+        if c is None:
+            m = self.at(H, W)
+            perm = torch.argsort(m, dim=1, descending=True, stable=True)
+            inv = torch.argsort(perm, dim=1)
+            c = self._by_res[(H, W, "compaction")] = HF.KeyCompaction(m, perm.to(torch.int32).contiguous(),
+                                                                      inv.to(torch.int32).contiguous(),
+                                                                      m.sum(dim=1, dtype=torch.int32).contiguous())
+        return c
+
 
 class SpatialTransformer(nn.Module):
     """forward(x, context, mask): x pixel-major [B,H,W,C] f32; ``context`` is a tensor, a
@@ -153,7 +168,9 @@ class SpatialTransformer(nn.Module):
         key_mask = None
         if mask is not None:
             # UNetModel.forward hands over a per-resolution cache (KeyMasks): the 16 transformers run at 4 resolutions
-            key_mask = mask.at(H, W) if hasattr(mask, "at") else KeyMasks(mask).at(H, W)
+            km = mask if hasattr(mask, "at") else KeyMasks(mask)
+            # long sequences: the kept keys are moved to the front and the masked ones left out (HF.COMPACT_KEYS_MIN_N)
+            key_mask = km.compaction(H, W) if H * W >= HF.COMPACT_KEYS_MIN_N else km.at(H, W)
         capture = bool(blk.attn2.save_attn_vars)
         # token weights [B, 77, G] set by UNetModel.forward when the conditioning side names the subject / background
         # token positions: the capture then also returns the per-head token maps (functional / ops.attention_capture)

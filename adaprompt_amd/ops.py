@@ -340,8 +340,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None, want_bf16=Fals
 # attention
 # --------------------------------------------------------------------------------------------
 
-def attention_fwd(q, k, v, heads, key_mask=None, scale=None):
-    """q [B,N,C], k/v [B,M,C] bf16 -> out [B,N,C] bf16, lse [B,H,N] f32.  ``scale``: the score scale (default d^-1/2)."""
+def gather_rows_bf16(src, idx, out=None):
+    """src [B, R, C] bf16 (rows may be strided), idx [B, n] int32 -> [B, n, C]: out[b, i] = src[b, idx[b, i]]."""
+    B, R, C = src.shape
+    n = idx.shape[1]
+    assert src.dtype == BF16 and idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape[0] == B
+    if out is None:
+        out = torch.empty(B, n, C, device=src.device, dtype=BF16)
+    assert out.dtype == BF16 and tuple(out.shape) == (B, n, C)
+    _lib.call("adap_gather_rows_bf16", src.data_ptr(), _rows_ld(src)[1], idx.data_ptr(), out.data_ptr(), _rows_ld(out)[1], B, R, n, C,
+              _stream())
+    return out
+
+
+def attention_fwd(q, k, v, heads, key_mask=None, scale=None, key_count=None):
+    """q [B,N,C], k/v [B,M,C] bf16 -> out [B,N,C] bf16, lse [B,H,N] f32.  ``scale``: the score scale (default d^-1/2).
+    ``key_count`` [B] int32: sample b attends to its first key_count[b] keys only (compacted keys)."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
@@ -351,15 +365,17 @@ def attention_fwd(q, k, v, heads, key_mask=None, scale=None):
     if key_mask is not None:
         assert key_mask.dtype == torch.uint8 and key_mask.shape == (B, M) and key_mask.is_contiguous()
     e0 = TIMER.start() if TIMER is not None else None
+    if key_count is not None:
+        assert key_count.dtype == torch.int32 and key_count.shape == (B,) and key_count.is_contiguous()
     _lib.call("adap_attention_fwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
-              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d,
+              _rows_ld(v)[1], _ptr(key_mask), _ptr(key_count), out.data_ptr(), C, lse.data_ptr(), B, heads, N, M, d,
               float(d) ** -0.5 if scale is None else float(scale), _stream())
     if e0 is not None:
         TIMER.stop("attention_fwd", 4.0 * B * heads * N * M * d, e0, f"N={N} M={M} d={d}")      # QK^T + PV, SURVEY.md 8d
     return out, lse
 
 
-def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=None, dv=None, out_dtype=BF16):
+def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=None, dv=None, out_dtype=BF16, key_count=None):
     """dq/dk/dv may be caller-provided pixel-major views (e.g. slices of one fused [B,N,3C] buffer);
     otherwise fresh tensors of ``out_dtype`` are allocated."""
     B, N, C = q.shape
@@ -376,8 +392,8 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=Non
         return (0, t.data_ptr()) if t.dtype == BF16 else (t.data_ptr(), 0)
     (dq32, dq16), (dk32, dk16), (dv32, dv16) = pp(dq), pp(dk), pp(dv)
     _lib.call("adap_attention_bwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
-              _rows_ld(v)[1], _ptr(key_mask), out.data_ptr(), _rows_ld(out)[1], dout.data_ptr(), _rows_ld(dout)[1],
-              lse.data_ptr(), delta.data_ptr(),
+              _rows_ld(v)[1], _ptr(key_mask), _ptr(key_count), out.data_ptr(), _rows_ld(out)[1], dout.data_ptr(),
+              _rows_ld(dout)[1], lse.data_ptr(), delta.data_ptr(),
               dq32, dq16, _rows_ld(dq)[1], dk32, dk16, _rows_ld(dk)[1], dv32, dv16, _rows_ld(dv)[1],
               B, heads, N, M, d, float(d) ** -0.5, _stream())
     return dq, dk, dv

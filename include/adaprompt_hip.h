@@ -127,9 +127,13 @@ int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, con
  * CrossAttention core, attention.py:195-243: softmax((q k^T) * scale [+ key mask]) v, fused.
  * q [B][N][H*d], k/v [B][M][H*d] bf16; key_mask [B][M] bytes (0 = masked with -finfo.max, :223-232)
  * or NULL; out bf16 [B][N][H*d]; lse f32 [B][H][N].  d % 8 == 0, d <= 160.
+ * key_count [B] int32 (device) or NULL: sample b attends to its FIRST key_count[b] keys only -- the form a key mask takes after
+ * the kept keys have been compacted to the front (adap_gather_rows_bf16): masked keys contribute exactly 0 to the softmax
+ * (attention.py:223-232 fills them with -finfo.max), so leaving them out is the same arithmetic on fewer tiles.  The
+ * backward writes zeros into dk / dv rows >= key_count[b].
  */
 int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                       const uint8_t* key_mask, void* out, long ldo, float* lse,
+                       const uint8_t* key_mask, const int* key_count, void* out, long ldo, float* lse,
                        int B, int H, int N, int M, int d, float scale, void* stream);
 /* which forward kernel the last adap_attention_fwd dispatched to: 1 / 2 = query-stationary kernel with 1 / 2 query blocks per
  * wave, 3 = the ping-pong kernel (512-query workgroups, SIMD partners half a tile apart; N >= 512 keys, d <= 64) */
@@ -142,8 +146,8 @@ int adap_attention_set_stamp_buffer(void* buf);
  * query-split dK/dV pass, summed in a fixed order). */
 long adap_attention_bwd_workspace_floats(int B, int H, int N, int M, int d);
 int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                       const uint8_t* key_mask, const void* out, long ldo, const void* dout, long lddo,
-                       const float* lse, float* workspace,
+                       const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
+                       long lddo, const float* lse, float* workspace,
                        float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
                        float* dv32, void* dv16, long lddv,
                        int B, int H, int N, int M, int d, float scale, void* stream);
@@ -185,6 +189,11 @@ int adap_geglu_bwd(const void* dout, long lddo, const void* h, long ldh, void* d
  * kind 0 = "quick_gelu" x * sigmoid(1.702 x) (openai/clip-vit-large-patch14), 1 = "gelu" (erf; the LAION checkpoints).
  */
 int adap_act_fwd(const float* x, long ldx, void* out, long ldo, long rows, int cols, int kind, void* stream);
+
+/* dst[b][i][0..cols) = src[b][idx[b][i]][0..cols): row gather of bf16 rows (cols % 8 == 0, 16-byte aligned rows) with leading
+ * dimensions on both sides -- moves the keys a mask keeps to the front (and dk / dv back) for adap_attention_*'s key_count. */
+int adap_gather_rows_bf16(const void* src, long lds, const int* idx, void* dst, long ldd, int B, int rows_src, int rows_dst,
+                          int cols, void* stream);
 
 /* time_embed MLP openaimodel.py:518-522 and ResBlock emb_layers :217-223 (R <= 8 rows, exact f32):
  * y[r][n] = post( bias[n] + sum_k pre(x[r][k]) w[n][k] ), pre/post = SiLU when the flag is set. */

@@ -28,7 +28,7 @@ def test_bad_arguments_return_status_not_crash():
                               1, 0, 0, 0, 0, 0)
     assert rc == -2 and b"Cin" in lib.adap_last_error()
     with pytest.raises(_lib.HipError):
-        _lib.call("adap_attention_fwd", 16, 40, 16, 40, 16, 40, 0, 16, 40, 0, 1, 8, 16, 16, 5, 0.1, 0)   # d = 5
+        _lib.call("adap_attention_fwd", 16, 40, 16, 40, 16, 40, 0, 0, 16, 40, 0, 1, 8, 16, 16, 5, 0.1, 0)   # d = 5
 
 
 def test_product_package_does_not_import_oracle():

@@ -719,3 +719,39 @@ def test_integration_md_ctypes_stub_runs_verbatim():
         os.chdir(cwd)
     ref = F.silu(gn(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
     assert rel(y.float(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("B,H,N,d", [(3, 8, 4096, 40), (2, 8, 1024, 80), (2, 4, 200, 40)])
+def test_attention_with_compacted_keys_equals_masked_attention(B, H, N, d):
+    """key_count: the kept keys gathered to the front and the masked ones left out -- forward and backward against the same
+    kernels run with the byte mask (the two differ only in the order of summation), and against torch."""
+    C = H * d
+    g = torch.Generator().manual_seed(3)
+    q, k, v, do = (bf(torch.randn(B, N, C, generator=g)).to(dev()) for _ in range(4))
+    mask = (torch.rand(B, N, generator=g) > 0.3)
+    mask[0, :] = True                                      # one sample keeps everything
+    mask[-1, N // 2:] = False                              # one loses a whole half (whole tiles of masked keys)
+    mask = mask.to(dev())
+    km = mask.to(torch.uint8).contiguous()
+    qb, kb, vb, dob = (t.to(torch.bfloat16) for t in (q, k, v, do))
+    perm = torch.argsort(km, dim=1, descending=True, stable=True)
+    inv = torch.argsort(perm, dim=1).to(torch.int32).contiguous()
+    perm = perm.to(torch.int32).contiguous()
+    count = km.sum(dim=1, dtype=torch.int32).contiguous()
+    kv = torch.cat([kb, vb], dim=-1)
+    kvc = ops.gather_rows_bf16(kv, perm)
+    assert torch.equal(kvc[0], kv[0]) and torch.equal(kvc[1, 0], kv[1, int(perm[1, 0])])
+    o_c, lse_c = ops.attention_fwd(qb, kvc[..., :C], kvc[..., C:], H, None, key_count=count)
+    o_m, lse_m = ops.attention_fwd(qb, kb, vb, H, km)
+    assert rel(o_c.float(), o_m.float()) < 3e-3 and rel(lse_c, lse_m) < 2e-4          # (tile boundaries differ: other rounding)
+    ref, sim, _ = ref_attention(q, k, v, H, mask)
+    assert rel(o_c.float(), ref) < 6e-3
+    dq_m, dk_m, dv_m = ops.attention_bwd(qb, kb, vb, o_m, dob, lse_m, H, km)
+    dkvc = torch.empty(B, N, 2 * C, device=dev(), dtype=torch.bfloat16)
+    dq_c, _, _ = ops.attention_bwd(qb, kvc[..., :C], kvc[..., C:], o_c, dob, lse_c, H, None, dk=dkvc[..., :C], dv=dkvc[..., C:],
+                                   key_count=count)
+    dkv = ops.gather_rows_bf16(dkvc, inv)
+    assert rel(dq_c.float(), dq_m.float()) < 6e-3
+    assert rel(dkv[..., :C].float(), dk_m.float()) < 6e-3 and rel(dkv[..., C:].float(), dv_m.float()) < 6e-3
+    # masked keys receive exactly zero gradient
+    assert float(dkv[~mask].abs().max()) == 0.0
