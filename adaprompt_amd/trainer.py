@@ -50,6 +50,10 @@ class Trainer:
         return self.logged
 
     def save_checkpoint(self, model):
+        from . import ops
+        if ops.gn_sync_poisoned():          # (one device -> host read per checkpoint; never set in any run so far)
+            raise RuntimeError("a single-launch GroupNorm's in-launch exchange timed out since the last checkpoint: the "
+                               "parameters may be wrong; rerun with ADAP_GN_TWO_PASS=1")
         ckpt = {"state_dict": {}, "global_step": model.global_step}
         d = self.checkpoint_callback.dirpath
         if d is not None:

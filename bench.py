@@ -632,6 +632,10 @@ def main():
         opt = reducer = sched = None
 
     cpu = None
+    # a single-launch GroupNorm that ever gave up waiting for its sample's other workgroups would have produced garbage: every
+    # rank checks its device's flag, and a set flag fails the run instead of reporting a number
+    if ops.gn_sync_poisoned():
+        raise SystemExit(f"rank {rank}: the single-launch GroupNorm's exchange timed out (ops.gn_sync_poisoned): results invalid")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
         threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
