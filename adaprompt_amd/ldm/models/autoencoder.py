@@ -48,6 +48,82 @@ class AutoencoderKL(nn.Module):
         m, _ = ops.linear(h.view(B, H * W, C), qc.fwd, qc.O4, bias=qc.bias)
         return m.view(B, H, W, -1)
 
+    # ---- the same encode through the single C entry adap_vae_encode (vae_encode(x, masks, weights*, noise, z))
+    def _c_abi_table(self):
+        """(cfg ints, device-pointer table, the tensors kept alive) in the order include/adaprompt_hip.h documents."""
+        import ctypes
+        enc = self.encoder
+        keep, ptrs = [], []
+
+        def conv(mod_wc, key, m, fused=None):
+            pk = mod_wc.get(key, m.weight, m.bias) if fused is None else mod_wc.get(key, *fused)
+            keep.extend([pk.fwd, pk.bias])
+            ptrs.extend([pk.fwd.data_ptr(), pk.bias.data_ptr()])
+
+        def norm(m):
+            keep.extend([m.weight, m.bias])
+            ptrs.extend([m.weight.data_ptr(), m.bias.data_ptr()])
+
+        def res(b):
+            norm(b.norm1)
+            conv(b._wc, "conv1", b.conv1)
+            norm(b.norm2)
+            conv(b._wc, "conv2", b.conv2)
+            if b.in_channels != b.out_channels:
+                conv(b._wc, "nin", b.nin_shortcut)
+
+        conv(enc._wc, "conv_in", enc.conv_in)
+        for i, lvl in enumerate(enc.down):
+            for b in lvl.block:
+                res(b)
+            if i != enc.num_resolutions - 1:
+                conv(lvl.downsample._wc, "conv", lvl.downsample.conv)
+        res(enc.mid.block_1)
+        at = enc.mid.attn_1
+        norm(at.norm)
+        conv(at._wc, "qkv", None, fused=([at.q.weight, at.k.weight, at.v.weight], [at.q.bias, at.k.bias, at.v.bias]))
+        conv(at._wc, "proj_out", at.proj_out)
+        res(enc.mid.block_2)
+        norm(enc.norm_out)
+        conv(enc._wc, "conv_out", enc.conv_out)
+        conv(self._wc, "quant_conv", self.quant_conv)
+        dd = self.ddconfig
+        cfg = [dd["ch"], len(dd["ch_mult"]), dd["num_res_blocks"], enc.conv_out.out_channels, self.quant_conv.out_channels] + \
+            [int(m) for m in dd["ch_mult"]]
+        return (ctypes.c_int * len(cfg))(*cfg), (ctypes.c_void_p * len(ptrs))(*ptrs), len(ptrs), keep
+
+    @torch.no_grad()
+    def encode_c_abi(self, x_hwc, mask=None, noise=None, scale=1.0):
+        """``adap_vae_encode``: x [B,H,W,3] f32 -> (moments [B,h,w,2z], z [B,h,w,z] or None) in ONE C-ABI call -- the same
+        launches ``encode_moments_nhwc`` + ``ops.posterior_sample`` issue from Python, issued by the library."""
+        import ctypes
+        from ... import _lib
+        from ...ops import _stream, gn_sync_buffer
+        from ..modules.diffusionmodules.model import AttnBlock
+        if not x_hwc.is_cuda:
+            raise RuntimeError("adaprompt_amd AutoencoderKL.encode runs on the MI355X HIP kernels only; got a CPU tensor")
+        x = x_hwc.contiguous().float()
+        B, H, W, _ = x.shape
+        cfg, table, n, keep = self._c_abi_table()
+        f = 2 ** (self.encoder.num_resolutions - 1)
+        h, w = H // f, W // f
+        cls = AttnBlock.pixel_classes(mask, (h, w), x)
+        e2 = self.quant_conv.out_channels
+        moments = torch.empty(B, h, w, e2, device=x.device)
+        z = None
+        if noise is not None:
+            noise = noise.contiguous().float()
+            assert tuple(noise.shape) == (B, h, w, e2 // 2), noise.shape
+            z = torch.empty_like(noise)
+        nbytes = _lib.call_long("adap_vae_encode_workspace_bytes", ctypes.addressof(cfg), B, H, W)
+        ws = torch.empty(nbytes + 256, device=x.device, dtype=torch.uint8)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        _lib.call("adap_vae_encode", ctypes.addressof(cfg), ctypes.addressof(table), n, x.data_ptr(),
+                  0 if cls is None else cls.data_ptr(), 0 if noise is None else noise.data_ptr(), float(scale), moments.data_ptr(),
+                  0 if z is None else z.data_ptr(), base, nbytes, gn_sync_buffer(x.device), B, H, W, _stream())
+        del keep
+        return moments, z
+
     def encode(self, x, mask=None):
         """reference signature: x NCHW -> posterior over NCHW moments."""
         moments = self.encode_moments_nhwc(x.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)

@@ -37,6 +37,48 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+class CAbiComm:
+    """An RCCL communicator owned by libadaprompt_hip.so (``adap_comm_*`` / ``adap_allreduce_bucket``, include/adaprompt_hip.h)."""
+
+    def __init__(self, unique_id, nranks, rank):
+        import ctypes
+        from . import _lib
+        self._lib, self.nranks, self.rank = _lib, nranks, rank
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), len(unique_id))
+        _lib.call("adap_comm_init", ctypes.byref(h), ctypes.addressof(buf), nranks, rank)
+        self.handle = h
+
+    @staticmethod
+    def new_unique_id():
+        import ctypes
+        from . import _lib
+        n = _lib.call_long("adap_comm_unique_id_bytes")
+        buf = ctypes.create_string_buffer(n)
+        _lib.call("adap_comm_unique_id", ctypes.addressof(buf))
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """rank 0 draws the id, ``torch.distributed`` (any backend) carries its 128 bytes to the others, once."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], world, rank)
+
+    def allreduce_(self, t, average=True):
+        """in place on the current stream; f32 or bf16, contiguous."""
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        self._lib.call("adap_allreduce_bucket", self.handle, t.data_ptr(), t.numel(), 0 if t.dtype == torch.float32 else 1,
+                       1 if average else 0, self._lib.current_stream())
+        return t
+
+    def destroy(self):
+        if self.handle:
+            self._lib.call("adap_comm_destroy", self.handle)
+            self.handle = None
+
+
 class GradReducer:
     """Flat-buffer gradient all-reduce (mean over ranks), asynchronous.
 
@@ -44,12 +86,20 @@ class GradReducer:
     wait()    -- make the current stream wait for them (call before the next backward / the step)
     """
 
-    def __init__(self, params, process_group=None, bucket_bytes=256 << 20, flat=None):
+    def __init__(self, params, process_group=None, bucket_bytes=256 << 20, flat=None, backend=None):
         """``flat``: an existing flat gradient buffer that every ``p.grad`` already views (e.g.
-        ``adaprompt_amd.ldm.prodigy.Prodigy.grad_buffer``) -- the exchange then runs on the optimiser's own buffer."""
+        ``adaprompt_amd.ldm.prodigy.Prodigy.grad_buffer``) -- the exchange then runs on the optimiser's own buffer.
+        ``backend="c_abi"`` (or ``ADAP_REDUCER_BACKEND=c_abi``): the collectives go through the library's own
+        ``adap_allreduce_bucket`` on an RCCL communicator it creates (``CAbiComm``) instead of ``torch.distributed``'s; the
+        process group is then only used once, to hand the communicator's unique id to the other ranks."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._cabi = None
+        if (backend or os.environ.get("ADAP_REDUCER_BACKEND")) == "c_abi" and self.world > 1:
+            self._cabi = CAbiComm.from_process_group(process_group)
+            self._side = torch.cuda.Stream()           # the exchange's own stream (RCCL kernels run under the next forward)
+            self._done = None
         dev = self.params[0].device if self.params else torch.device("cpu")
         if flat is not None:
             lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
@@ -80,6 +130,14 @@ class GradReducer:
         if self.world == 1:
             return
         self.wait()
+        if self._cabi is not None:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                for c in self.chunks:
+                    self._cabi.allreduce_(c, average=True)
+                self._done = torch.cuda.Event()
+                self._done.record()
+            return
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
         for c in self.chunks:
             self._works.append(dist.all_reduce(c, op=op, group=self.group, async_op=True))
@@ -88,6 +146,9 @@ class GradReducer:
     def wait(self):
         """the current stream waits for the outstanding collectives.  MUST run before anything writes the gradient
         buffer again (the next ``manual_backward``) and before the optimiser reads it."""
+        if self._cabi is not None and self._done is not None:
+            torch.cuda.current_stream().wait_event(self._done)
+            self._done = None
         for w in self._works:
             w.wait()
         self._works = []
@@ -97,7 +158,7 @@ class GradReducer:
 
     @property
     def pending(self):
-        return bool(self._works)
+        return bool(self._works) or (self._cabi is not None and self._done is not None)
 
     def zero(self):
         self.wait()

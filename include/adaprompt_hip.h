@@ -195,6 +195,42 @@ int adap_act_fwd(const float* x, long ldx, void* out, long ldo, long rows, int c
 int adap_gather_rows_bf16(const void* src, long lds, const int* idx, void* dst, long ldd, int B, int rows_src, int rows_dst,
                           int cols, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The first stage's encode as ONE call: image -> moments [-> z] (encode_first_stage / get_first_stage_encoding, ddpm.py:1381-1419,
+ * 955-962; AutoencoderKL.encode autoencoder.py:324-328; Encoder.forward model.py:408-499).  Host code that issues the library's
+ * own launches (conv / GroupNorm / the mid AttnBlock's two batched products and softmax / quant_conv / posterior sample) on
+ * `stream` in Encoder.forward's order -- the same launches the Python mirror issues, hence the same bits.
+ *   cfg (host ints): ch, num_levels, num_res_blocks, 2*z_channels, 2*embed_dim, ch_mult[num_levels]
+ *   tensors (host array of DEVICE pointers; adap_vae_encode_tensor_count(cfg) of them), in this order:
+ *     conv_in {w, b}; per level: per ResnetBlock {norm1 g, b; conv1 w, b; norm2 g, b; conv2 w, b; [nin_shortcut w, b when the
+ *     block changes the channel count]}; {downsample w, b} for all but the last level; mid.block_1 (8); mid.attn_1 {norm g, b;
+ *     q|k|v fused w, b; proj_out w, b}; mid.block_2 (8); norm_out {g, b}; conv_out {w, b}; quant_conv {w, b}
+ *     -- every w is the bf16 forward pack of adap_pack_conv_weight ([taps][O4][I8]), every b / g f32.
+ *   x_hwc [B][H][W][3] f32 in [-1,1] (the dataloader's layout); pixel_class [B][(H/8)*(W/8)] bytes (0 outside the aug mask,
+ *   1 foreground, 2 background: the mid attention's hetero-pair zero fill, model.py:196-232) or NULL;
+ *   moments f32 [B][h][w][2*embed_dim] out; z f32 [B][h][w][embed_dim] out or NULL, = scale * (mean + std * noise) with
+ *   noise [B][h][w][embed_dim]; workspace: adap_vae_encode_workspace_bytes(cfg, B, H, W) bytes, 256-byte aligned;
+ *   gn_sync as in adap_groupnorm_fwd (NULL = two-pass GroupNorm kernels). */
+int adap_vae_encode_tensor_count(const int* cfg);
+long adap_vae_encode_workspace_bytes(const int* cfg, int B, int H, int W);
+int adap_vae_encode(const int* cfg, const void* const* tensors, int n_tensors, const float* x_hwc,
+                    const uint8_t* pixel_class, const float* noise, float scale, float* moments, float* z,
+                    void* workspace, long workspace_bytes, void* gn_sync, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The data-parallel gradient exchange as C entries (main.py:829 strategy="ddp": the mean of the trainable gradients after every
+ * micro-batch backward).  RCCL (librccl.so.1, resolved with dlopen at the first call) on a communicator of the library's own:
+ * rank 0 draws a unique id (adap_comm_unique_id_bytes() bytes), the host passes it to the other processes by any means, every
+ * process calls adap_comm_init(&comm, id, nranks, rank) with its GPU current, then adap_allreduce_bucket(comm, buf, count,
+ * dtype (0 = f32, 1 = bf16), average (0 = sum, 1 = mean), stream) in place on slices of its flat gradient buffer -- asynchronous
+ * on `stream`, like every other entry.  (adaprompt_amd/parallel.py::GradReducer drives the same exchange through
+ * torch.distributed by default and through these entries with backend="c_abi".) */
+int adap_comm_unique_id_bytes(void);
+int adap_comm_unique_id(void* id_out);
+int adap_comm_init(void** comm_out, const void* id, int nranks, int rank);
+int adap_allreduce_bucket(void* comm, void* buf, long count, int dtype, int average, void* stream);
+int adap_comm_destroy(void* comm);
+
 /* time_embed MLP openaimodel.py:518-522 and ResBlock emb_layers :217-223 (R <= 8 rows, exact f32):
  * y[r][n] = post( bias[n] + sum_k pre(x[r][k]) w[n][k] ), pre/post = SiLU when the flag is set. */
 int adap_linear_small(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,

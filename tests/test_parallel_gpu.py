@@ -37,3 +37,31 @@ def test_training_step_two_ranks_matches_hand_averaged_step():
         assert r["replicas_identical"] and r["grad_buffer_zeroed"] and r["moved"] > 0
         # same gradients, summed in a different order (ranks in parallel vs one after the other): f32 round-off only
         assert r["rel_err_vs_hand_averaged"] < 1e-4, r
+
+
+@pytest.mark.gpu
+def test_allreduce_bucket_c_entry_single_rank():
+    """``adap_allreduce_bucket`` on a communicator the library creates itself (unique id -> ncclCommInitRank -> ncclAllReduce,
+    RCCL resolved with dlopen): with one rank the mean and the sum of a buffer are the buffer, f32 and bf16, on a side stream.
+    (More ranks need more GPUs than a test box has: the N > 1 path of this entry is exercised by the driver's scaling run
+    only when ADAP_REDUCER_BACKEND=c_abi is set; the default exchange goes through torch.distributed.)"""
+    import torch
+    from adaprompt_amd.parallel import CAbiComm
+    uid = CAbiComm.new_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = CAbiComm(uid, 1, 0)
+    x = torch.randn(1 << 20, device="cuda")
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.allreduce_(x, average=True)
+        comm.allreduce_(x, average=False)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    y = torch.randn(4096, device="cuda").to(torch.bfloat16)
+    ry = y.clone()
+    comm.allreduce_(y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ry)
+    comm.destroy()
