@@ -16,6 +16,7 @@ runs on the same kernels (``Arc2FaceWrapper``).  ``cond_fn(batch) -> (c_static_e
 [16*B, 77, 768], prompts, extra_info)`` is the embedding hook: whatever produced the context (the
 reference's ``get_learned_conditioning``) is called as-is and only its output enters the path.
 """
+import os
 from functools import partial
 
 import numpy as np
@@ -384,9 +385,20 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if fg is not None or aug is not None:
             mask = {"fg_mask": None if fg is None else fg[:, None].float(),
                     "aug_mask": None if aug is None else aug[:, None].float()}
-        moments = self.encode_first_stage_moments(img, mask)              # pixel-major [B,h,w,8]
         if post_noise is not None:
             post_noise = post_noise.permute(0, 2, 3, 1).contiguous()
+        fs = self.first_stage_model
+        if ops.TIMER is None and hasattr(fs, "encode_c_abi") and not os.environ.get("ADAP_VAE_PY"):
+            # one C-ABI call (adap_vae_encode): the library issues the encoder's launches itself -- the same launches, the
+            # same bits as the Python sequencing below, ~60 ctypes round trips less on the host (the per-kernel timers of
+            # bench.py's roofline pass hook the Python wrappers, so that pass keeps the sequencing)
+            if post_noise is None:
+                f = 2 ** (fs.encoder.num_resolutions - 1)
+                post_noise = torch.randn(img.shape[0], img.shape[1] // f, img.shape[2] // f, fs.quant_conv.out_channels // 2,
+                                         device=img.device)
+            _moments, z = fs.encode_c_abi(img, mask, post_noise, self.scale_factor)
+            return z.permute(0, 3, 1, 2), mask
+        moments = self.encode_first_stage_moments(img, mask)              # pixel-major [B,h,w,8]
         z = self.sample_latent_nhwc(moments, post_noise)                  # pixel-major [B,h,w,4]
         return z.permute(0, 3, 1, 2), mask
 
