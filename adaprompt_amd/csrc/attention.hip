@@ -1045,6 +1045,10 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnParams p) {
 static int dkv_qsplit(int B, int H, int N, int M, int d) {
     const long blocks = (long)((M + 127) / 128) * B * H;
     const int ntiles = (N + 63) / 64;
+    if (const char* e = getenv("ADAP_ATTN_DKV_QSPLIT")) {          // tuning override (tools/attn_bwd_count_probe.py)
+        int q = atoi(e);
+        if (q >= 1 && q <= 16 && q <= ntiles) return q;
+    }
     if (blocks >= 256 || ntiles < 2) return 1;
     long want = (512 + blocks - 1) / blocks;
     if (want > 16) want = 16;
