@@ -855,7 +855,11 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-    const int key = blockIdx.x * 128 + wave * 32 + c;
+    // Which 128 keys: rotated by the (batch, head) row.  With a key count the workgroups of the LAST key blocks have nothing to
+    // do; workgroups are placed round-robin over the CUs in launch order, and with 32 key blocks per row an unrotated map puts
+    // all the idle ones on the same CUs (256 = 8 x 32: measured -- no gain at all from 28 % fewer keys).
+    const int kblk = (int)((blockIdx.x + (unsigned)bh) % gridDim.x);
+    const int key = kblk * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
     const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count (rows beyond it get zeros)
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int split = blockIdx.z;
     const int qt0 = (int)((long)split * ntiles / p.qsplit);
     // a workgroup whose 128 keys all lie beyond the sample's count has nothing to accumulate: it only writes its zeros
-    const int qt1 = (int)blockIdx.x * 128 >= Mb ? qt0 : (int)((long)(split + 1) * ntiles / p.qsplit);
+    const int qt1 = kblk * 128 >= Mb ? qt0 : (int)((long)(split + 1) * ntiles / p.qsplit);
     tile_load(rQ, mapQ, qb + (size_t)qt0 * 64 * p.ldq, min(64, p.N - qt0 * 64));
     tile_load(rDO, mapDO, dob + (size_t)qt0 * 64 * p.lddo, min(64, p.N - qt0 * 64));
     row_stats_load(qt0 * 64);
