@@ -558,8 +558,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ r,
                                                           long ldr, const float* __restrict__ gl, float* __restrict__ loss,
                                                           float* __restrict__ dx, long lddx, float* __restrict__ dr, long lddr,
-                                                          int D, int demean, int align, float ref_grad_scale) {
+                                                          int D, int demean, int align, float ref_grad_scale, int expo) {
     __shared__ float red[4];
+    // the reference's sign-preserving power r |r|^(e-1) and its derivative e |r|^(e-1), e in {1, 2, 3}
+    auto spow = [expo](float v) { return expo == 1 ? v : (expo == 2 ? v * fabsf(v) : v * v * v); };
+    auto dspow = [expo](float v) { return expo == 1 ? 1.0f : (expo == 2 ? 2.0f * fabsf(v) : 3.0f * v * v); };
     const long row = blockIdx.x;
     const float* xr = x + row * ldx;
     const float* rr = r + row * ldr;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restric
     }
     float P = 0.f, A = 0.f, Bq = 0.f;
     for (int i = t; i < D; i += 256) {
-        const float xt = xr[i] - sx, rt = rr[i] - sr, tt = rt * fabsf(rt);
+        const float xt = xr[i] - sx, rt = rr[i] - sr, tt = spow(rt);
         P += xt * tt; A += xt * xt; Bq += tt * tt;
     }
     P = block_sum_256(P, red);
@@ -588,29 +591,30 @@ __global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restric
     float mx = 0.f, mr = 0.f;
     if (demean) {
         for (int i = t; i < D; i += 256) {
-            const float xt = xr[i] - sx, rt = rr[i] - sr, tt = rt * fabsf(rt);
+            const float xt = xr[i] - sx, rt = rr[i] - sr, tt = spow(rt);
             mx += (tt - (P / A) * xt) * inv;
-            mr += (xt - (P / Bq) * tt) * inv * 2.0f * fabsf(rt);
+            mr += (xt - (P / Bq) * tt) * inv * dspow(rt);
         }
         mx = block_sum_256(mx, red) / D;
         mr = block_sum_256(mr, red) / D;
     }
     for (int i = t; i < D; i += 256) {
-        const float xt = xr[i] - sx, rt = rr[i] - sr, tt = rt * fabsf(rt);
+        const float xt = xr[i] - sx, rt = rr[i] - sr, tt = spow(rt);
         if (dx) dx[row * lddx + i] = gc * ((tt - (P / A) * xt) * inv - mx);
-        if (dr) dr[row * lddr + i] = gc * ref_grad_scale * ((xt - (P / Bq) * tt) * inv * 2.0f * fabsf(rt) - mr);
+        if (dr) dr[row * lddr + i] = gc * ref_grad_scale * ((xt - (P / Bq) * tt) * inv * dspow(rt) - mr);
     }
 }
 
 // loss != NULL: forward (gl, dx, dr NULL).  dx / dr != NULL: backward for the rows' loss gradients gl [R].
 extern "C" int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const float* gl, float* loss, float* dx,
                                 long lddx, float* dr, long lddr, long R, int D, int demean, int align, float ref_grad_scale,
-                                void* stream) {
+                                int exponent, void* stream) {
     ADAP_REQUIRE(x && r && (loss || ((dx || dr) && gl)), ADAP_ERR_SHAPE, "cosine_rows: null pointer");
+    ADAP_REQUIRE(exponent >= 1 && exponent <= 3, ADAP_ERR_UNSUPPORTED, "cosine_rows: exponent %d (1, 2 or 3)", exponent);
     ADAP_REQUIRE(R >= 0 && D >= 1 && ldx >= D && ldr >= D, ADAP_ERR_SHAPE, "cosine_rows: shape");
     if (R == 0) return ADAP_OK;
     hipLaunchKernelGGL(cosine_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, x, ldx, r, ldr, gl, loss, dx,
-                       lddx, dr, lddr, D, demean, align, ref_grad_scale);
+                       lddx, dr, lddr, D, demean, align, ref_grad_scale, exponent);
     return adap_check_launch("cosine_rows");
 }
 

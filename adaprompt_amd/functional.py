@@ -553,25 +553,25 @@ class SkipFn(torch.autograd.Function):
 
 
 class CosineRowsFn(torch.autograd.Function):
-    """per-row demeaned cosine loss against a sign-preserving squared reference (ldm/util.py:437-535, exponent 2), one
+    """per-row demeaned cosine loss against a sign-preserving squared reference (ldm/util.py:437-535, exponent 1 / 2 / 3), one
     HIP launch forward and one backward instead of ~25 element-wise torch launches each way."""
 
     @staticmethod
-    def forward(ctx, x, r, demean, align, ref_grad_scale):
+    def forward(ctx, x, r, demean, align, ref_grad_scale, exponent=2):
         x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
         r2 = r.reshape(-1, r.shape[-1]).float().contiguous()
         ctx.save_for_backward(x2, r2)
-        ctx.cfg = (bool(demean), bool(align), float(ref_grad_scale), x.shape, r.shape)
-        return ops.cosine_rows(x2, r2, demean, align).reshape(x.shape[:-1])
+        ctx.cfg = (bool(demean), bool(align), float(ref_grad_scale), x.shape, r.shape, int(exponent))
+        return ops.cosine_rows(x2, r2, demean, align, exponent=exponent).reshape(x.shape[:-1])
 
     @staticmethod
     def backward(ctx, g):
         x2, r2 = ctx.saved_tensors
-        demean, align, rgs, xs, rs = ctx.cfg
+        demean, align, rgs, xs, rs, expo = ctx.cfg
         want_dr = ctx.needs_input_grad[1] and rgs != 0
         dx, dr = ops.cosine_rows(x2, r2, demean, align, rgs, gl=g.reshape(-1).float().contiguous(),
-                                 want_dx=ctx.needs_input_grad[0], want_dr=want_dr)
-        return (None if dx is None else dx.reshape(xs)), (None if dr is None else dr.reshape(rs)), None, None, None
+                                 want_dx=ctx.needs_input_grad[0], want_dr=want_dr, exponent=expo)
+        return (None if dx is None else dx.reshape(xs)), (None if dr is None else dr.reshape(rs)), None, None, None, None
 
 
 class MaskHingesFn(torch.autograd.Function):

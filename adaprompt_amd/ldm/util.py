@@ -171,9 +171,9 @@ def gen_gradient_scaler(alpha, debug=False):
 def cosine_loss_rows(rows, ref_rows, exponent=2, do_demean_first=False, ref_grad_scale=0, aim_to_align=True):
     """[..., D] x [..., D] -> [...]: 1 - cos(row, ref^exponent) (or max(0, cos) when not aligning), ref^exponent sign
     preserving, both optionally demeaned over D, the reference's gradient scaled by ``ref_grad_scale``."""
-    if rows.is_cuda and exponent == 2 and rows.dtype == torch.float32 and ref_rows.dtype == torch.float32:
+    if rows.is_cuda and exponent in (1, 2, 3) and rows.dtype == torch.float32 and ref_rows.dtype == torch.float32:
         from .. import functional as HF            # the fused HIP kernel (forward + analytic backward)
-        return HF.CosineRowsFn.apply(rows, ref_rows.expand_as(rows), do_demean_first, aim_to_align, ref_grad_scale)
+        return HF.CosineRowsFn.apply(rows, ref_rows.expand_as(rows), do_demean_first, aim_to_align, ref_grad_scale, exponent)
     if do_demean_first:
         rows, ref_rows = demean(rows), demean(ref_rows)
     ref_rows = gen_gradient_scaler(ref_grad_scale)(ref_rows)

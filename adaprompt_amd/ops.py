@@ -674,21 +674,21 @@ def norm_affine_bwd(dy, x, gamma, beta, mean, rstd, kind, act, dgamma, dbeta, ac
               rows, HW, C, _stream())
 
 
-def cosine_rows(x, r, demean, align, ref_grad_scale=1.0, gl=None, want_dx=True, want_dr=True):
-    """x, r f32 [R, D] (rows contiguous).  gl None: -> loss [R] (ldm/util.py:437-535 per-row term, exponent 2).
+def cosine_rows(x, r, demean, align, ref_grad_scale=1.0, gl=None, want_dx=True, want_dr=True, exponent=2):
+    """x, r f32 [R, D] (rows contiguous).  gl None: -> loss [R] (ldm/util.py:437-535 per-row term, exponent 1 / 2 / 3).
     gl f32 [R]: -> (dx, dr), the gradients of sum(gl * loss)."""
     assert x.dtype == F32 and r.dtype == F32 and x.dim() == 2 and x.shape == r.shape and x.stride(1) == 1 and r.stride(1) == 1
     R, D = x.shape
     if gl is None:
         loss = torch.empty(R, device=x.device, dtype=F32)
         _lib.call("adap_cosine_rows", x.data_ptr(), x.stride(0), r.data_ptr(), r.stride(0), 0, loss.data_ptr(), 0, 0, 0, 0, R, D,
-                  int(bool(demean)), int(bool(align)), float(ref_grad_scale), _stream())
+                  int(bool(demean)), int(bool(align)), float(ref_grad_scale), int(exponent), _stream())
         return loss
     assert gl.dtype == F32 and gl.numel() == R and gl.is_contiguous()
     dx = torch.empty(R, D, device=x.device, dtype=F32) if want_dx else None
     dr = torch.empty(R, D, device=x.device, dtype=F32) if want_dr else None
     _lib.call("adap_cosine_rows", x.data_ptr(), x.stride(0), r.data_ptr(), r.stride(0), gl.data_ptr(), 0, _ptr(dx), D, _ptr(dr), D,
-              R, D, int(bool(demean)), int(bool(align)), float(ref_grad_scale), _stream())
+              R, D, int(bool(demean)), int(bool(align)), float(ref_grad_scale), int(exponent), _stream())
     return dx, dr
 
 

@@ -338,14 +338,14 @@ int adap_norm_affine_bwd(const void* dy, int dy_dtype, long lddy, const void* x,
                          int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Row-wise demeaned cosine loss against a sign-preserving squared reference (ldm/util.py:437-535 calc_ref_cosine_loss,
- * exponent 2; F.cosine_embedding_loss with margin 0): per row of x, r f32 [R][D]
- *   loss = 1 - cos(x - mean x, t)  (align) or max(0, cos) (align == 0),  t = (r - mean r) * |r - mean r|.
+ * Row-wise demeaned cosine loss against a sign-preserving power of the reference (ldm/util.py:437-535 calc_ref_cosine_loss,
+ * exponent 1, 2 or 3; F.cosine_embedding_loss with margin 0): per row of x, r f32 [R][D]
+ *   loss = 1 - cos(x - mean x, t)  (align) or max(0, cos) (align == 0),  t = (r - mean r) * |r - mean r|^(exponent - 1).
  * Forward: loss != NULL.  Backward: dx and / or dr != NULL receive gl[row] * d loss / d x (d r scaled by
  * ref_grad_scale, the reference's ScaleGrad). */
 int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const float* gl, float* loss, float* dx,
                      long lddx, float* dr, long lddr, long R, int D, int demean, int align, float ref_grad_scale,
-                     void* stream);
+                     int exponent, void* stream);
 
 /* The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for L same-resolution layers:
  * S / G f32 [L][B][H][N] = per-head score maps of the subject / background tokens (element stride `estride`: they

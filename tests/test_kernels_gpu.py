@@ -619,9 +619,10 @@ def test_attention_token_maps_fwd_bwd(B, N, M, d, G):
     assert torch.equal(dq_b, dq) and torch.equal(dk_b, dk)
 
 
+@pytest.mark.parametrize("expo", [2, 3, 1])
 @pytest.mark.parametrize("R,D,demean,align,rgs", [(8, 4096, True, True, 1.0), (5, 64, True, True, 0.05), (3, 1024, False, False, 1.0),
                                                   (700, 768, True, True, 0.05), (4, 256, True, True, 0.0)])
-def test_cosine_rows_fwd_bwd(R, D, demean, align, rgs):
+def test_cosine_rows_fwd_bwd(R, D, demean, align, rgs, expo):
     """adap_cosine_rows against the torch chain of ldm/util.py:499-517 (demean, ScaleGrad, sign-preserving square,
     F.cosine_embedding_loss) and its autograd, in fp64."""
     from adaprompt_amd import functional as HF
@@ -631,12 +632,12 @@ def test_cosine_rows_fwd_bwd(R, D, demean, align, rgs):
     gl = torch.randn(R, generator=g)
     xd, rd = x.double().requires_grad_(True), r.double().requires_grad_(True)
     xt, rt = (xd - xd.mean(-1, keepdim=True), rd - rd.mean(-1, keepdim=True)) if demean else (xd, rd)
-    tgt = rt * rt.abs()
+    tgt = rt * rt.abs().pow(expo - 1)
     ref = F.cosine_embedding_loss(xt, tgt, torch.full((R,), 1.0 if align else -1.0, dtype=torch.float64), reduction="none")
     (ref * gl.double()).sum().backward()
     dev = torch.device("cuda:0")
     xh, rh = x.to(dev).requires_grad_(True), r.to(dev).requires_grad_(True)
-    out = HF.CosineRowsFn.apply(xh, rh, demean, align, rgs)
+    out = HF.CosineRowsFn.apply(xh, rh, demean, align, rgs, expo)
     (out * gl.to(dev)).sum().backward()
     assert rel(out.cpu(), ref.detach().float()) < 1e-5
     assert rel(xh.grad.cpu(), xd.grad.float()) < 2e-5
