@@ -1117,7 +1117,7 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
             return launch_fwd_pp<KS, VT>(p, s);
     }
     // two query blocks per wave when that still leaves >= 2 workgroups per CU's worth of work (the 64x64 level)
-    if (KS <= 4 && (long)((p.N + 255) / 256) * p.B * p.H >= 512) return launch_fwd_q<KS, VT, 2>(p, s);
+    if (KS <= 4 && (long)((p.N + 255) / 256) * p.B * p.H >= 512 && !getenv("ADAP_ATTN_QB1")) return launch_fwd_q<KS, VT, 2>(p, s);
     return launch_fwd_q<KS, VT, 1>(p, s);
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the context-gradient error of the bf16 path come from?  (GPU only; diagnostic behind tests/test_precision_gpu.py)
+"""Where does the context-gradient error of the bf16 path come from?  (GPU only; diagnostic behind tests/test_precision_gpu.py; it calls the oracle, hence its place under tests/)
 
 For the narrow smoke case and the UNet-only golden cases: relative L2 error of d loss / d context against the f32 oracle,
 per context layer, in the shipped mode and in the f32-storage validation mode (functional.set_f32_storage), and -- for the
