@@ -33,9 +33,18 @@ def test_bad_arguments_return_status_not_crash():
 
 def test_product_package_does_not_import_oracle():
     import re
-    root = os.path.dirname(os.path.abspath(build.__file__))
-    for dp, _, files in os.walk(root):
-        for f in files:
-            if f.endswith(".py"):
-                src = open(os.path.join(dp, f)).read()
-                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+    pkg = os.path.dirname(os.path.abspath(build.__file__))
+    repo = os.path.dirname(pkg)
+    # the product package, the `ldm` alias package and the tuning tools: none may touch oracle/ (only tests/, smoke() and the
+    # bench's cpu_baseline leg do)
+    for root in (pkg, os.path.join(repo, "ldm"), os.path.join(repo, "tools")):
+        for dp, _, files in os.walk(root):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+    bench_src = open(os.path.join(repo, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"^\s*(from|import)\s+oracle\b", bench_src, re.M)]
+    start = bench_src.index("def cpu_baseline(")
+    end = bench_src.index("\ndef ", start + 1)
+    assert len(uses) == 1 and start < uses[0] < end, "bench.py may use the oracle inside cpu_baseline() only"
