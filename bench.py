@@ -819,6 +819,9 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if ndev < n:
             env.setdefault("ADAP_DIST_BACKEND", "gloo")
+            # two processes on one device: the single-launch GroupNorm needs ALL of its workgroups resident at once, which two
+            # such grids from two processes cannot both have -- the rehearsal runs the two-pass kernels
+            env.setdefault("ADAP_GN_TWO_PASS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     if ndev < n:
         print(f"warning: --gpus {n} on a box with {ndev} GPU(s): ranks share devices, gradient exchange over gloo",

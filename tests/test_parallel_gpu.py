@@ -25,6 +25,8 @@ def test_training_step_two_ranks_matches_hand_averaged_step():
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                    ADAP_DIST_BACKEND="nccl" if ndev >= 2 else "gloo")
+        if ndev < 2:          # two processes on one device: two-pass GroupNorm (two single-launch grids cannot both be resident)
+            env["ADAP_GN_TWO_PASS"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
