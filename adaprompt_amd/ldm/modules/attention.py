@@ -92,9 +92,13 @@ class KeyMasks:
             m = self.at(H, W)
             perm = torch.argsort(m, dim=1, descending=True, stable=True)
             inv = torch.argsort(perm, dim=1)
+            count = m.sum(dim=1, dtype=torch.int32)
+            # (a sample whose mask keeps NO key -- an image with an empty aug mask, which the data pipeline does not produce --
+            # would divide by an empty softmax sum: it attends to all keys instead; the reference's masked_fill gives it the
+            # plain average of V)
+            count = torch.where(count == 0, torch.full_like(count, H * W), count).contiguous()
             c = self._by_res[(H, W, "compaction")] = HF.KeyCompaction(m, perm.to(torch.int32).contiguous(),
-                                                                      inv.to(torch.int32).contiguous(),
-                                                                      m.sum(dim=1, dtype=torch.int32).contiguous())
+                                                                      inv.to(torch.int32).contiguous(), count)
         return c
 
 
