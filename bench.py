@@ -386,8 +386,8 @@ def main():
     # HBM fraction is structurally tiny (DESIGN.md section 3 / SURVEY 7 "roofline honesty").
     aggregates = None
     if rank == 0 and not args.no_roofline:
-        def timed(fn, n=20):
-            for _ in range(3):
+        def timed(fn, n=50):
+            for _ in range(20):          # past the first launches' clock ramp: the rate the kernel holds inside the step
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -420,10 +420,38 @@ def main():
         rb_flops = 2.0 * 2 * B * 64 * 64 * C * C * 9
         # the HBM-bound part of that block, where the north star's HBM target applies: GroupNorm32 + SiLU (f32 in -> bf16 out)
         gw, gb_ = torch.ones(C, device=device), torch.zeros(C, device=device)
-        t_gn = timed(lambda: ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1))
+        def graph_timed(fn, n=20):
+            """GPU time per call of a ~10 us kernel: ``n`` calls captured into one hipGraph and replayed (issued eagerly from
+            Python the loop measures the host -- torch.empty x 5 + ctypes is ~15 us per call; inside the training step these
+            launches are queued well ahead of the GPU).  The capture stream is made the owner of the single-launch path for the
+            measurement and the default stream gets it back afterwards."""
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            ops.set_gn_single_launch_stream(device, side.cuda_stream)
+            try:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        for _ in range(n):
+                            fn()
+                    for _ in range(5):
+                        g.replay()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        g.replay()
+                    e1.record()
+                torch.cuda.synchronize()
+            finally:
+                ops.set_gn_single_launch_stream(device, torch.cuda.default_stream(device).cuda_stream)
+            return e0.elapsed_time(e1) / (5 * n) * 1e-3
+        t_gn = graph_timed(lambda: ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1))
         dy16 = go.to(torch.bfloat16)
         _, _, gm_, gr_ = ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1)
-        t_gnb = timed(lambda: ops.groupnorm_bwd(dy16, xr, gw, gb_, gm_, gr_, 1, out_f32=False, out_bf16=True))
+        t_gnb = graph_timed(lambda: ops.groupnorm_bwd(dy16, xr, gw, gb_, gm_, gr_, 1, out_f32=False, out_bf16=True))
         gn_bytes_f, gn_bytes_b = xr.numel() * (4 + 2), xr.numel() * (4 + 2 + 2)       # algorithmic: x once + y / x, dy once + dx
         aggregates = {
             "attention_self_64x64": {"shape": f"B{B} h8 N{N} d40", "fwd_us": round(t_f * 1e6, 1), "bwd_us": round(t_b * 1e6, 1),
