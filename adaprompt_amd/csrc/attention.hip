@@ -71,6 +71,8 @@ struct AttnParams {
     float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
 };
 
+#define MAX_SLACK 5.0f          // see attn_fwd_kernel's running reference point
+
 // max over the two lanes l and l ^ 32 -- the two halves of a score column in the 32x32 accumulator layout -- without the LDS
 // round trip of __shfl_xor (ds_bpermute + lgkmcnt wait, queued behind the partner wave's fragment reads): gfx950's
 // v_permlane32_swap exchanges one register's upper 32 lanes with the other's lower 32 in the vector pipe.
@@ -275,9 +277,14 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][t][r]);
             mx = xor32_max(mx);
-            const float mnew = fmaxf(m[qb], mx * cs);   // running max in the exp2 domain (cs > 0)
-            if (__any(mnew != m[qb])) {                 // wave-uniform: skip the O rescale while no row's max moves
-                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);
+            // running reference point in the exp2 domain (cs > 0): raised only when a row's max outgrows it by more than
+            // 2^MAX_SLACK (or it is still -inf) -- p <= 2^MAX_SLACK keeps its full f32 / bf16 relative precision, and the O
+            // rescale below (64 multiplies) then runs on a handful of tiles instead of on every second one
+            const float mcand = mx * cs;
+            const bool grow = mcand > m[qb] + MAX_SLACK;
+            if (__any(grow)) {                          // wave-uniform
+                const float mnew = grow ? mcand : m[qb];
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);      // 1 for the rows that keep their reference
 #pragma unroll
                 for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
