@@ -718,7 +718,7 @@ def compos_leg(device, gen, micro_batches=8):
     then the with-grad pass of the selected candidate under the four contexts (UNet batch 4), the stage-2 losses on the
     captured outfeat / attnscore / q of 12 layers and the backward through all of it into the embedding manager; a reuse
     iteration starts from the cached prediction and skips the filter.  The text encoder, the embedding manager and the
-    CLIP scorer are third-party / boundary callees: stand-ins from tests/stubs.py and a scripted score."""
+    CLIP scorer are third-party / boundary callees: stand-ins from adaprompt_amd/standins.py and a scripted score."""
     import random as _random
     from adaprompt_amd import synth
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
@@ -727,8 +727,8 @@ def compos_leg(device, gen, micro_batches=8):
         ld = LatentDiffusion(
             first_stage_config={"target": "ldm.models.autoencoder.AutoencoderKL",
                                 "params": {"ddconfig": dict(synth.SD15_VAE_DD), "embed_dim": 4, "with_decoder": True}},
-            cond_stage_config={"target": "tests.stubs.StubTextEncoder", "params": {"dim": 768}},
-            personalization_config={"target": "tests.stubs.StubEmbeddingManager", "params": {"dim": 768, "num_vectors_per_subj_token": 16}},
+            cond_stage_config={"target": "adaprompt_amd.standins.StubTextEncoder", "params": {"dim": 768}},
+            personalization_config={"target": "adaprompt_amd.standins.StubEmbeddingManager", "params": {"dim": 768, "num_vectors_per_subj_token": 16}},
             unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": dict(synth.SD15_UNET)},
             scale_factor=0.18215, linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn", cond_stage_trainable=True,
             use_layerwise_embedding=True, do_zero_shot=True, mix_prompt_distill_weight=1e-4, comp_fg_bg_preserve_loss_weight=1e-3,
