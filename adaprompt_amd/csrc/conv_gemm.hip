@@ -66,6 +66,126 @@ struct ConvParams {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// ---------------------------------------------------------------------------------------------
+// The fused epilogue shared by every contraction kernel: y = alpha * acc + bias[c] + chan_add[b][c] + residual[m][c], as
+// f32 and / or bf16.  acc[i][j] is the accumulator quad of channel tile i and pixel fragment j; `geo` maps (i, j) to the
+// output pixel / image / channel of this lane.
+// All addend loads of the tile are ISSUED BEFORE the first store.  Written as one load-add-store per quad, the compiler
+// must keep program order between a quad's stores and the next quad's loads (y32 may alias residual: the transformer's
+// residual adds run in place), so every quad paid a full memory round trip: 0.6 us x 20 quads = 13 us of a 21 us
+// launch on the 128 x 160 tile (in-kernel stamps, tools/gemm_timeline.py).  Each lane only ever re-reads addresses it
+// writes itself, so hoisting the loads is safe under that aliasing.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int PT, class Geo, int JB = (MT * PT > 16 ? PT / 2 : PT)>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo, float* y32,
+                                              uint16_t* y16) {
+    static_assert(PT % JB == 0, "pixel fragments are processed in batches of JB");
+    // 32-bit byte offsets against wave-uniform bases (global_load/store saddr form): twenty 64-bit addresses per tensor
+    // would otherwise be live across the batch (the host checks that every tensor spans < 4 GiB)
+    unsigned cc[MT];
+    bool cok[MT];
+    float4 bq[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        cc[i] = (unsigned)geo.chan(i);
+        cok[i] = (int)cc[i] < p.Cout;
+        bq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && cok[i]) bq[i] = *(const float4*)((const char*)p.bias + cc[i] * 4u);
+    }
+    const bool has_res = p.residual != nullptr, has_ca = p.chan_add != nullptr;
+    const unsigned ldr = (unsigned)p.ldr, ldca = (unsigned)p.ld_ca, ld32 = (unsigned)p.ldy32, ld16 = (unsigned)p.ldy16;
+#pragma unroll
+    for (int j0 = 0; j0 < PT; j0 += JB) {
+        unsigned mm[JB], bb[JB];
+        bool mok[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            int m, b;
+            mok[j] = geo.pixel(j0 + j, m, b);
+            mm[j] = (unsigned)m;
+            bb[j] = (unsigned)b;
+        }
+        float4 rq[MT][JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) rq[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    if (mok[j] && cok[i]) rq[i][j] = *(const float4*)((const char*)p.residual + (mm[j] * ldr + cc[i]) * 4u);
+        }
+        if (has_ca) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    if (mok[j] && cok[i]) {
+                        const float4 t = *(const float4*)((const char*)p.chan_add + (bb[j] * ldca + cc[i]) * 4u);
+                        rq[i][j].x += t.x; rq[i][j].y += t.y; rq[i][j].z += t.z; rq[i][j].w += t.w;
+                    }
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (!(mok[j] && cok[i])) continue;
+                const f32x4 a = acc[i][j0 + j];
+                const float v0 = a[0] * p.alpha + bq[i].x + rq[i][j].x, v1 = a[1] * p.alpha + bq[i].y + rq[i][j].y;
+                const float v2 = a[2] * p.alpha + bq[i].z + rq[i][j].z, v3 = a[3] * p.alpha + bq[i].w + rq[i][j].w;
+                if (y32) *(float4*)((char*)y32 + (mm[j] * ld32 + cc[i]) * 4u) = make_float4(v0, v1, v2, v3);
+                if (y16) {
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
+                    *(uint2*)((char*)y16 + (mm[j] * ld16 + cc[i]) * 2u) = o;
+                }
+            }
+    }
+}
+
+// split-K: this split's raw accumulators to its slab (no epilogue; splitk_reduce_kernel sums the slabs in a fixed order)
+template <int MT, int PT, class Geo>
+__device__ __forceinline__ void conv_store_slab(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo, float* slab) {
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        int m, b;
+        if (!geo.pixel(j, m, b)) continue;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int c0 = geo.chan(i);
+            if (c0 < p.Cout)
+                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// lane -> (pixel, image, channel) of the plain implicit-GEMM tiling: pixel fragments of 16 consecutive output pixels
+struct GemmGeo {
+    int mbase, cbase, M, HWo, frow, fchunk;
+    __device__ __forceinline__ bool pixel(int j, int& m, int& b) const {
+        m = mbase + j * 16 + frow;
+        b = m / HWo;
+        return m < M;
+    }
+    __device__ __forceinline__ int chan(int i) const { return cbase + i * 16 + fchunk * 4; }
+};
+
+// ... of the stencil-window kernels: an 8 x 32 (WIDE) or 16 x 16 patch of one image
+template <bool WIDE>
+struct PatchGeo {
+    int bimg, y0, x0, cbase, Hin, Win, wq, frow, fchunk;       // wq: the wave's pixel quarter
+    __device__ __forceinline__ bool pixel(int j, int& m, int& b) const {
+        const int yy = y0 + (WIDE ? 2 * wq + (j >> 1) : 4 * wq + j), xx = x0 + (WIDE ? (j & 1) * 16 : 0) + frow;
+        m = (bimg * Hin + yy) * Win + xx;
+        b = bimg;
+        return true;
+    }
+    __device__ __forceinline__ int chan(int i) const { return cbase + i * 16 + fchunk * 4; }
+};
+
 template <int BN, bool A_F32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     constexpr int WN = BN / 2;        // output channels per wave
@@ -359,44 +479,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     // acc[i][j][r] = C[cout = n0 + wn*WN + i*16 + (lane>>4)*4 + r][pixel = m0 + wm*64 + j*16 + (lane&15)]
     float* y32 = p.y32 ? p.y32 + (size_t)bz * p.batch_stride_y32 : nullptr;
     uint16_t* y16 = p.y16 ? p.y16 + (size_t)bz * p.batch_stride_y16 : nullptr;
-    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + frow;
-        if (m >= M) continue;
-        const int b = m / HWo;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
-            if (c0 >= p.Cout) continue;
-            if (slab) {
-                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                continue;
-            }
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            if (p.bias) {
-                float4 t = *(const float4*)(p.bias + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.chan_add) {
-                float4 t = *(const float4*)(p.chan_add + (size_t)b * p.ld_ca + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.residual) {
-                float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (y32) *(float4*)(y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-            if (y16) {
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(y16 + (size_t)m * p.ldy16 + c0) = o;
-            }
-        }
-    }
+    const GemmGeo geo{m0 + wm * 64, n0 + wn * WN, M, HWo, frow, fchunk};
+    if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+    else conv_epilogue<MT, PT, GemmGeo, 1>(p, acc, geo, y32, y16);      // (batches of one pixel fragment: this kernel lives on 2-3 workgroups per CU)
 }
 
 // split-K second pass: fixed-order sum of the slabs + the fused epilogue
@@ -638,6 +723,10 @@ __device__ __forceinline__ void ring_body(const ConvParams& p) {
 
     const int ntl = kt_end - kt_begin;
     const int L = 4 + nB;                               // DMA instructions this wave issues per stage
+    // diagnostic timeline (tools/gemm_timeline.py; p.clk NULL in production): 100 MHz real-time stamps of this workgroup's
+    // start, first operand tile landed, K loop done, epilogue stores issued
+    unsigned long long* stamps = p.clk ? p.clk + 4 * ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.z) : nullptr;
+    if (stamps && tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
         if (i < ntl) stage(i, kt_begin + i);
@@ -650,6 +739,7 @@ __device__ __forceinline__ void ring_body(const ConvParams& p) {
         wait_vmcnt(ahead * L);
         __builtin_amdgcn_s_barrier();          // X: tile t visible to every wave; every wave has read tile t-1
         asm volatile("" ::: "memory");
+        if (stamps && t == 0 && tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
         auto issue = [&]() {
             if (t + NST - 1 < ntl) {
                 int nb = buf + NST - 1;
@@ -684,44 +774,16 @@ __device__ __forceinline__ void ring_body(const ConvParams& p) {
         if (++buf == NST) buf = 0;
     }
     if (ROLE == 2 && pending) mfmas();         // the late half's last step (no barrier: the early half is done)
+    if (stamps && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
 
-    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + frow;
-        if (m >= M) continue;
-        const int b = m / HWo;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int c0 = n0 + wn * WN + i * 16 + fchunk * 4;
-            if (c0 >= p.Cout) continue;
-            if (slab) {
-                *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                continue;
-            }
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            if (p.bias) {
-                float4 t = *(const float4*)(p.bias + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.chan_add) {
-                float4 t = *(const float4*)(p.chan_add + (size_t)b * p.ld_ca + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.residual) {
-                float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.y16) {
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
-            }
-        }
+    {
+        const GemmGeo geo{m0 + wm * 64, n0 + wn * WN, M, HWo, frow, fchunk};
+        if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+        else conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16);
+    }
+    if (stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -926,47 +988,10 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
     }
 
     const int M = p.B * p.Hin * p.Win;
-    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
     auto epilogue = [&](int c_bimg, int c_y0, int c_x0, int c_n0) {
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int yy = c_y0 + (WIDE ? 2 * wm + (j >> 1) : 4 * wm + j), xx = c_x0 + (WIDE ? (j & 1) * 16 : 0) + frow;
-            const int m = (c_bimg * p.Hin + yy) * p.Win + xx;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int c0 = c_n0 + wn * WN + i * 16 + fchunk * 4;
-                if (c0 < p.Cout) {
-                    if (slab) {
-                        *(float4*)(slab + (size_t)m * p.Cout + c0) =
-                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                    } else {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-                        if (p.bias) {
-                            float4 t = *(const float4*)(p.bias + c0);
-                            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                        }
-                        if (p.chan_add) {
-                            float4 t = *(const float4*)(p.chan_add + (size_t)c_bimg * p.ld_ca + c0);
-                            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                        }
-                        if (p.residual) {
-                            float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
-                            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                        }
-                        if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-                        if (p.y16) {
-                            uint2 o;
-                            o.x = pack_bf16x2(v[0], v[1]);
-                            o.y = pack_bf16x2(v[2], v[3]);
-                            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
-                        }
-                    }
-                }
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
+        const PatchGeo<WIDE> geo{c_bimg, c_y0, c_x0, c_n0 + wn * WN, p.Hin, p.Win, wm, frow, fchunk};
+        if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+        else conv_epilogue<MT, PT>(p, acc, geo, p.y32, p.y16);
     };
 
     // ---- the step stream.  A step = (chunk, tap); the nine taps of a chunk are unrolled (ring slot = tap % 3 because
@@ -1257,45 +1282,9 @@ __device__ __forceinline__ void win32_body(const ConvParams& p) {
 
     if (p.dbg & 4) return;
     const int M = p.B * p.Hin * p.Win;
-    float* slab = p.ksplit > 1 ? p.ws + (size_t)blockIdx.z * M * p.Cout : nullptr;
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        const int yy = y0 + (WIDE ? 2 * wv + (j >> 1) : 4 * wv + j), xx = x0 + (WIDE ? (j & 1) * 16 : 0) + frow;
-        const int m = (bimg * p.Hin + yy) * p.Win + xx;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int c0 = n0 + i * 16 + fchunk * 4;
-            if (c0 < p.Cout) {
-                if (slab) {
-                    *(float4*)(slab + (size_t)m * p.Cout + c0) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                } else {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-                    if (p.bias) {
-                        float4 t = *(const float4*)(p.bias + c0);
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                    }
-                    if (p.chan_add) {
-                        float4 t = *(const float4*)(p.chan_add + (size_t)bimg * p.ld_ca + c0);
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                    }
-                    if (p.residual) {
-                        float4 t = *(const float4*)(p.residual + (size_t)m * p.ldr + c0);
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                    }
-                    if (p.y32) *(float4*)(p.y32 + (size_t)m * p.ldy32 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (p.y16) {
-                        uint2 o;
-                        o.x = pack_bf16x2(v[0], v[1]);
-                        o.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2*)(p.y16 + (size_t)m * p.ldy16 + c0) = o;
-                    }
-                }
-            }
-        }
-    }
+    const PatchGeo<WIDE> geo{bimg, y0, x0, n0, p.Hin, p.Win, wv, frow, fchunk};
+    if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+    else conv_epilogue<MT, PT, PatchGeo<WIDE>, 1>(p, acc, geo, p.y32, p.y16);
 }
 
 template <int BN, bool WIDE>
@@ -1454,6 +1443,15 @@ extern "C" int adap_conv2d_set_clock_probe(void* buf) {
 static thread_local int g_last_variant = -1;
 extern "C" int adap_conv2d_last_variant(void) { return g_last_variant; }
 
+static thread_local int g_force_kind = 0, g_force_bn = 0;
+extern "C" int adap_conv2d_debug_force(int kind, int bn) {
+    ADAP_REQUIRE(kind >= 0 && kind <= 3 && (bn == 0 || bn == 64 || bn == 128 || bn == 160), ADAP_ERR_UNSUPPORTED,
+                 "conv2d_debug_force: kind %d bn %d", kind, bn);
+    g_force_kind = kind;
+    g_force_bn = bn;
+    return ADAP_OK;
+}
+
 extern "C" int adap_conv2d_nhwc(
     const void* x, int x_dtype, long ldx,
     const void* w_packed,
@@ -1547,6 +1545,28 @@ extern "C" int adap_conv2d_nhwc(
             p.ntiles_m = (int)((M + BM - 1) / BM);
         }
         if (!use_big && ((M + BM - 1) / BM) * t160 < 200 && ((M + BM - 1) / BM) * t64 > ((M + BM - 1) / BM) * t160) bn = 64;
+    }
+    if (!halo && g_force_kind != 0 && nbatch == 1 && up == 0 && x_dtype == 1) {      // diagnostic override (tools/gemm_probe.py)
+        if (g_force_bn) bn = g_force_bn;
+        if (g_force_kind == 2 && bn == 64) bn = 128;          // no 256 x 64 ring variant
+        use_big = g_force_kind == 2;
+        p.ntiles_m = (int)((M + (use_big ? BMB : BM) - 1) / (use_big ? BMB : BM));
+        p.ntiles_n = (Cout + bn - 1) / bn;
+        if (g_force_kind == 2) {
+            g_last_variant = 2000 + bn;
+            if (bn == 160) return launch_ring<256, 160, 3>(p, s);
+            return launch_ring<256, 128, 3>(p, s);
+        } else if (g_force_kind == 3) {
+            g_last_variant = 3000 + bn;
+            if (bn == 160) return launch_ring<128, 160, 4>(p, s);
+            if (bn == 128) return launch_ring<128, 128, 4>(p, s);
+            return launch_ring<128, 64, 4>(p, s);
+        } else {
+            g_last_variant = 1000 + bn;
+            if (bn == 160) return launch<160, false>(p, nbatch, s);
+            if (bn == 128) return launch<128, false>(p, nbatch, s);
+            return launch<64, false>(p, nbatch, s);
+        }
     }
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (halo) {

@@ -601,6 +601,7 @@ __device__ __forceinline__ double gn_sweep(int* sync, int first_wg, int nslab, i
     for (int c0 = w; c0 < nslab; c0 += 64) {
         float v[8];
         unsigned spins = 0;
+        bool gave_up = false;
         for (;;) {
             bool ok = true;
 #pragma unroll
@@ -617,12 +618,16 @@ __device__ __forceinline__ double gn_sweep(int* sync, int first_wg, int nslab, i
             if (__all(ok)) break;
             if (++spins > GN_SPIN_LIMIT) {
                 if (e == 0) __hip_atomic_store(sync + GN_SYNC_POISON, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += (double)v[j];
+        // a timed-out exchange must never look like a result: the statistics become NaN, and with them this workgroup's
+        // outputs, mean / rstd, the loss and every gradient downstream (the host also polls the poison word, ops.py)
+        if (gave_up) acc = __builtin_nan("");
     }
     lds8x64[w * 64 + e] = acc;
     __syncthreads();

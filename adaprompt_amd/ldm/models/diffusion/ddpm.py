@@ -30,6 +30,15 @@ from ...modules.distributions.distributions import DiagonalGaussianDistribution
 from ...util import default, instantiate_from_config
 from .conditioning import ConditioningMixin
 
+# the recon iteration's attention regularisers as one call of the HIP library (LatentDiffusion.fused_token_map_losses);
+# ADAP_FUSED_REG=0 runs the host expressions instead (the checker of the fused form in tests/)
+FUSED_REG_LOSSES = os.environ.get("ADAP_FUSED_REG", "1") != "0"
+
+
+def set_fused_reg_losses(on):
+    global FUSED_REG_LOSSES
+    FUSED_REG_LOSSES = bool(on)
+
 
 class DiffusionWrapper(nn.Module):
     """reference ddpm.py:5505-5544 for conditioning_key='crossattn' with the AdaFace cond triple."""
@@ -1075,6 +1084,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if reg is not None:
             aux["reg_loss"], aux["reg_parts"] = reg, parts
             loss = loss + reg.detach()
+        if "reg_tokmap_grads" in extra_info:
+            aux["reg_tokmap_grads"] = extra_info.pop("reg_tokmap_grads")
         return loss, grad, model_output, aux
 
     def recon_regularizers(self, extra_info, block_size, do_static_prompt_delta_reg=True, fg_mask=None,
@@ -1107,6 +1118,18 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         tm = None
         if acts is not None and acts.get("attnscore_tokmap") and extra_info.get("ca_tokmap_weights") is not None:
             tm = (acts["attnscore_tokmap"], extra_info["ca_tokmap_weights"])
+        extra_info.pop("reg_tokmap_grads", None)
+        if tm is not None and subj is not None and FUSED_REG_LOSSES:
+            # both attention regularisers, values and gradients, as one call of the HIP library (csrc/regloss.hip): the host
+            # expressions below -- the readable form, and what runs on CPU tensors -- cost ~400 small launches per micro-batch
+            fused = self.fused_token_map_losses(acts, tm, subj, extra_info.get("bg_indices"), block_size, fg_mask, instance_mask,
+                                                do_complementary)
+            if fused is not None:
+                f_total, f_parts, roots, grads = fused
+                parts.update(f_parts)
+                extra_info["reg_tokmap_grads"] = (roots, grads)          # manual_backward hands them to autograd as roots
+                total = f_total if total is None else total + f_total
+                return total, parts
         if do_complementary and subj is not None and acts is not None and acts.get("attnscore") \
                 and self.fg_bg_complementary_loss_weight > 0:
             l_c, l_smb, l_bmf, l_con = self.calc_fg_bg_complementary_loss(
@@ -1130,6 +1153,73 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             total = None
         return total, parts
 
+    def fused_token_map_losses(self, acts, token_maps, subj_indices, bg_indices, block_size, fg_mask, instance_mask,
+                               do_complementary):
+        """``calc_fg_bg_complementary_loss`` + ``calc_fg_bg_xlayer_consist_loss`` with the weighting of ``recon_regularizers``
+        on the capture kernel's token maps through ``ops.reg_losses`` -> (total, {name: value}, token maps, their gradients),
+        or None when the fused form does not apply (then the host expressions run)."""
+        from ...util import normalize_dict_values, token_weight_matrix
+        maps, w_tok = token_maps
+        scores = acts["attnscore"]
+        layers = [li for li in scores if li in maps]
+        if not layers or len(layers) > 16:
+            return None
+        first = maps[layers[0]]
+        if not (first.is_cuda and first.dtype == torch.float32):
+            return None
+        have_bg = bg_indices is not None
+        idx_groups = [subj_indices] + ([bg_indices] if have_bg else [])
+        if token_weight_matrix(idx_groups, first.shape[0], scores[layers[0]].shape[-1]) is not w_tok or first.shape[-1] != len(idx_groups):
+            return None
+        w_c = self.fg_bg_complementary_loss_weight if do_complementary else 0
+        w_x = self.fg_bg_xlayer_consist_loss_weight
+        use_mask = w_c > 0 and fg_mask is not None and (instance_mask is None or bool(instance_mask.sum() > 0))
+        if w_c > 0 and not have_bg and not use_mask:
+            w_c = 0
+        if not (w_c > 0 or w_x > 0):
+            return None
+        N = {li: maps[li].shape[2] for li in layers}
+        pos = {li: i for i, li in enumerate(layers)}
+        pairs = []
+        if w_x > 0:
+            xw, below = normalize_dict_values(dict(LatentDiffusion.XLAYER_WEIGHTS)), LatentDiffusion.XLAYER_BELOW
+            for li in layers:
+                if li not in xw:
+                    continue
+                fine, coarse = li, below[li]
+                if coarse not in pos:
+                    return None
+                if N[coarse] > N[fine]:
+                    fine, coarse = coarse, fine
+                if N[fine] not in (N[coarse], 4 * N[coarse]):
+                    return None
+                pairs.append((pos[fine], pos[coarse], xw[li]))
+        cw = [0.0] * len(layers)
+        if w_c > 0:
+            lw = normalize_dict_values(dict(LatentDiffusion.COMPLEM_WEIGHTS))
+            cw = [lw.get(li, 0.0) for li in layers]
+        k_fg = float(subj_indices[0].numel()) / first.shape[0]
+        k_bg = float(bg_indices[0].numel()) / first.shape[0] if have_bg else 1.0
+        fg = None
+        if use_mask:
+            fg = fg_mask[:, 0] if fg_mask.dim() == 4 else fg_mask
+            fg = fg.float().contiguous()
+            if fg.shape[1] != fg.shape[2] or any(fg.shape[1] % int(np.sqrt(n)) for n in N.values()):
+                return None
+        iw = None if (instance_mask is None or not use_mask) else instance_mask[:block_size].float().contiguous()
+        fg_scale, bg_scale = (0.2, 0.06) if self.do_zero_shot else (1.0, 0.3)
+        coefs = (fg_scale * w_x, bg_scale * w_x if have_bg else 0.0, (0.2 if self.do_zero_shot else 1.0) * w_c if have_bg else 0.0,
+                 w_c if use_mask else 0.0, w_c if (use_mask and have_bg) else 0.0, w_c if (use_mask and have_bg) else 0.0)
+        roots = [maps[li] for li in layers]
+        p8, grads = ops.reg_losses(roots, cw, tuple(pairs), fg, iw, block_size, have_bg and w_c > 0, 0.4, 0.4 * k_fg / k_bg, 0.1,
+                                   coefs)
+        parts = {}
+        if w_c > 0:
+            parts.update(fg_bg_complem=p8[2], subj_mb_suppress=p8[3], bg_mf_suppress=p8[4], fg_bg_mask_contrast=p8[5])
+        if w_x > 0:
+            parts.update(fg_xlayer_consist=p8[0], bg_xlayer_consist=p8[1])
+        return p8[6], parts, roots, grads
+
     @staticmethod
     def manual_backward(model_output, grad, aux=None):
         """``manual_backward(loss)`` (ddpm.py:595) for the pair shared_step returns: the masked-MSE gradient enters at
@@ -1150,6 +1240,12 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if reg is not None and reg.requires_grad:
             roots.append(reg)
             grads.append(torch.ones_like(reg))
+        tg = None if aux is None else aux.get("reg_tokmap_grads")
+        if tg is not None:                          # the fused regularisers' gradients enter at the captured token maps
+            for o, g in zip(*tg):
+                if o.requires_grad:
+                    roots.append(o)
+                    grads.append(g)
         if roots:
             torch.autograd.backward(roots, grads)
 

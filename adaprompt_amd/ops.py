@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory and the stream; every function c
 passes raw pointers to the C ABI (include/adaprompt_hip.h) on torch's current stream and returns
 torch tensors.  Activations are pixel-major: [B, H, W, C] / [B, N, C] with the channel dim
 contiguous and an arbitrary leading dimension (stride of dim -2)."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -259,6 +261,35 @@ def gn_sync_buffer(device):
 def gn_sync_poisoned():
     """True if a single-launch GroupNorm ever gave up waiting for its sample's other workgroups (tests assert it is False)."""
     return any(int(b[1]) != 0 for b in _GN_SYNC.values())          # word 1 = poison (norms.hip GN_SYNC_POISON)
+
+
+class GnSyncTimeout(RuntimeError):
+    pass
+
+
+_GN_POLL = {}      # device index -> (pinned int32[1], event of the copy in flight or None)
+
+
+def gn_poison_poll():
+    """Sync-free check of the single-launch GroupNorm's poison word, meant to be called once per optimiser step: looks at
+    the copy issued by the PREVIOUS call (raises ``GnSyncTimeout`` if it is set), then issues the next 4-byte
+    device -> pinned-host copy on the current stream.  A timed-out exchange also turns that GroupNorm's statistics into
+    NaN (norms.hip gn_sweep), so the loss is NaN in the same step; this names the cause at most one step later.
+    The workgroups of such a kernel wait for each other, so the whole grid must be resident: set ADAP_GN_TWO_PASS=1 when a
+    device is shared by several processes / ranks, masked or partitioned."""
+    for idx, buf in _GN_SYNC.items():
+        host, ev = _GN_POLL.get(idx, (None, None))
+        if ev is not None and ev.query() and int(host[0]) != 0:
+            raise GnSyncTimeout(f"cuda:{idx}: a single-launch GroupNorm's in-launch exchange timed out (the grid was not "
+                                "co-resident: device shared, masked or partitioned?); its outputs are NaN. Set "
+                                "ADAP_GN_TWO_PASS=1 for such runs.")
+        if host is None:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if ev is None or ev.query():
+            host.copy_(buf[1:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        _GN_POLL[idx] = (host, ev)
 
 
 def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
@@ -713,3 +744,60 @@ def mask_hinges(maps, fmask, iw, margin, margin_bg_at_mf, have_bg, gout=None, ws
     if not have_bg and G > 1:
         d[..., 1:].zero_()
     return d
+
+
+# --------------------------------------------------------------------------------------------
+# the recon iteration's attention regularisers on the captured token maps (csrc/regloss.hip)
+# --------------------------------------------------------------------------------------------
+
+_REG_TABLES = {}
+
+
+def reg_losses(token_maps, complem_w, pairs, fg_mask, inst_w, Bk, have_bg, margin, margin_bg_at_mf, fg_grad_scale, coefs):
+    """token_maps: list of L f32 [Bt, H, N_l, G] tensors (adap_attention_capture's token maps); complem_w: L floats (the layer's
+    normalised complementary-loss weight, 0 = no part in it); pairs: tuple of (x layer idx, reference layer idx, weight) of the
+    cross-layer consistency loss; fg_mask f32 [Bt, Hm, Hm] or None; inst_w f32 [Bk] or None; coefs = d total / d (L_fg, L_bg,
+    L_complem, L_subj_mb_suppress, L_bg_mf_suppress, L_mask_contrast).
+    -> (parts f32 [8] = the six losses, the total, 0;  [d total / d token_maps[l]])  -- values and gradients in one call."""
+    L = len(token_maps)
+    Bt, H, _, G = token_maps[0].shape
+    Ns = tuple(int(t.shape[2]) for t in token_maps)
+    for t in token_maps:
+        assert t.dtype == F32 and t.is_cuda and t.is_contiguous() and t.shape[0] == Bt and t.shape[1] == H and t.shape[3] == G
+    key = (Ns, tuple(float(w) for w in complem_w), tuple(pairs), int(Bk), int(H), int(G))
+    tab = _REG_TABLES.get(key)
+    if tab is None:
+        if len(_REG_TABLES) > 16:
+            _REG_TABLES.clear()
+        ln = (ctypes.c_int * L)(*Ns)
+        cw = (ctypes.c_float * L)(*[float(w) for w in complem_w])
+        n = len(pairs)
+        px = (ctypes.c_int * max(n, 1))(*[int(a) for a, _, _ in pairs])
+        pr = (ctypes.c_int * max(n, 1))(*[int(b) for _, b, _ in pairs])
+        pw = (ctypes.c_float * max(n, 1))(*[float(w) for _, _, w in pairs])
+        nws = _lib.call_long("adap_reg_losses_workspace_floats", ln, L, px, pr, n, int(Bk), int(H), int(G))
+        assert nws > 0, "adap_reg_losses_workspace_floats: unsupported configuration"
+        offs, o = [], 0
+        for t in token_maps:
+            offs.append(o)
+            o += t.numel()
+        tab = _REG_TABLES[key] = (ln, cw, px, pr, pw, n, int(nws), offs, o)
+    ln, cw, px, pr, pw, n, nws, offs, total = tab
+    dev = token_maps[0].device
+    dflat = torch.empty(total, device=dev, dtype=F32)
+    dtm = [dflat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, token_maps)]
+    ws = torch.empty(nws, device=dev, dtype=F32)
+    parts = torch.empty(8, device=dev, dtype=F32)
+    Hm = 0
+    if fg_mask is not None:
+        assert fg_mask.dtype == F32 and fg_mask.is_contiguous() and fg_mask.dim() == 3 and fg_mask.shape[0] == Bt \
+            and fg_mask.shape[1] == fg_mask.shape[2], fg_mask.shape
+        Hm = fg_mask.shape[1]
+    if inst_w is not None:
+        assert inst_w.dtype == F32 and inst_w.is_contiguous() and inst_w.numel() >= Bk
+    tp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in token_maps])
+    dp = (ctypes.c_void_p * L)(*[t.data_ptr() for t in dtm])
+    _lib.call("adap_reg_losses", tp, dp, ln, cw, L, px, pr, pw, n, _ptr(fg_mask), Hm, _ptr(inst_w), Bt, int(Bk), H, G,
+              int(bool(have_bg)), float(margin), float(margin_bg_at_mf), float(fg_grad_scale), *[float(c) for c in coefs],
+              parts.data_ptr(), ws.data_ptr(), nws, _stream())
+    return parts, dtm

@@ -78,6 +78,10 @@ int adap_conv2d_last_variant(void);
  * stencil-window kernel stores the shader-clock ticks (s_memtime) and the 100 MHz real-time ticks (s_memrealtime) its
  * K loop took -- the in-kernel clock the chip holds under this kernel's load.  NULL (the default) switches it off. */
 int adap_conv2d_set_clock_probe(void* buf);
+/* Diagnostic (tools/gemm_probe.py): force the kernel variant of the calling thread's next adap_conv2d_nhwc calls:
+ * kind 0 = automatic (production), 1 = conv_gemm_kernel, 2 = conv_gemm_ring_kernel<256,.,3>, 3 = conv_gemm_ring_kernel<128,.,4>;
+ * bn 0 = automatic, else the channel tile (64 / 128 / 160).  A combination the problem does not admit is ignored. */
+int adap_conv2d_debug_force(int kind, int bn);
 
 /* OIHW f32 (checkpoint layout, ddpm.py:321-344) -> bf16 [KH*KW][rows][cols].
  * mode 0 (forward): rows >= O, cols >= I, out[t][o][i] = w[o][i][ky][kx] (zero padded).
@@ -360,6 +364,29 @@ int adap_mask_hinges_fwd(const float* S, const float* G, long estride, const flo
 int adap_mask_hinges_bwd(const float* S, const float* G, long estride, const float* fmask, const float* iw,
                          const float* gout, const float* workspace, float* dS, float* dG, long dstride, int L, int B,
                          int H, int N, float margin, float margin_bg_at_mf, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The recon iteration's attention regularisers, values and gradients in one call (csrc/regloss.hip):
+ * calc_fg_bg_xlayer_consist_loss ddpm.py:4259-4387 and calc_fg_bg_complementary_loss ddpm.py:4043-4258 on the token maps
+ * adap_attention_capture emits, with the weighting of ddpm.py:2921-2950 / 3246-3270 folded into six coefficients.
+ *
+ * tm / dtm: HOST arrays of L device pointers: token map of layer l, f32 [Bt][H][layer_N[l]][G] (G = 1 subject, 2 = + background),
+ * and where its gradient goes (same shape; every element is written).  layer_N, complem_w (the layer's normalised
+ * complementary-loss weight, 0 = takes no part), pair_x / pair_r / pair_w (cross-layer pair i compares the head-mean map of layer
+ * pair_x[i] -- 2 x 2 mean-pooled when it has 4x the pixels -- with layer pair_r[i]'s as the reference, weight pair_w[i]) are HOST
+ * arrays too.  fg_mask: f32 [Bt][Hm][Hm] in {0,1} at the latent resolution or NULL (no hinge terms); inst_w f32 [Bk] or NULL.
+ * Only the first Bk instances count.  The total is
+ *   cx_fg * L_fg + cx_bg * L_bg + cc_complem * L_complem + cc_smb * L_subj_mb_suppress + cc_bmf * L_bg_mf_suppress + cc_con * L_mask_contrast
+ * parts (device, 8 floats) receives {L_fg, L_bg, L_complem, L_smb, L_bmf, L_con, total, 0}; dtm the gradient of the total.
+ */
+long adap_reg_losses_workspace_floats(const int* layer_N, int L, const int* pair_x, const int* pair_r, int npairs, int Bk,
+                                      int H, int G);
+int adap_reg_losses(const void* const* tm, void* const* dtm, const int* layer_N, const float* complem_w, int L,
+                    const int* pair_x, const int* pair_r, const float* pair_w, int npairs,
+                    const float* fg_mask, int Hm, const float* inst_w, int Bt, int Bk, int H, int G, int have_bg,
+                    float margin, float margin_bg_at_mf, float fg_grad_scale,
+                    float cx_fg, float cx_bg, float cc_complem, float cc_smb, float cc_bmf, float cc_con,
+                    float* parts, float* workspace, long ws_floats, void* stream);
 
 #ifdef __cplusplus
 }
