@@ -1377,15 +1377,38 @@ static int choose_bn_halo(int Cout) {
     return bn;
 }
 
+// Channel tile and split factor of the stencil-window kernel, from a small cost model calibrated on dependent chains of the
+// UNet's ResBlock convs (tools/conv3_probe.py, in us): a launch costs ~12 (boundary, prologue, epilogue) plus its K steps
+// (9 taps x Cin slices per workgroup) at 0.49 per step for the 128-wide ping-pong tile and 0.78 for the 160-wide one, times
+// the ROUNDS the grid needs on the chip's CUs -- a split that pushes the grid just past one round (280 workgroups on 256
+// CUs) nearly doubles the launch, which is what the old "ceil(256 / tiles)" rule did at 32^2 and 16^2 -- plus, when split,
+// the reduce pass: its own boundary and (splits + 1.5) x the f32 output through L2 at ~5 TB/s.
+static void choose_halo_plan(int B, int H, int W, int Cin, int Cout, int* bn_out, int* ks_out) {
+    const int nchunks = (Cin + BK - 1) / BK;
+    const long M = (long)B * H * W;
+    const int ncu = num_cus();
+    double best = 1e30;
+    int best_bn = choose_bn_halo(Cout), best_ks = 1;
+    for (int bn = 128; bn <= 160; bn += 32) {
+        const long blocks = (long)B * (H * W / 256) * ((Cout + bn - 1) / bn);
+        const double step_us = bn == 128 ? 0.49 : 0.78;
+        for (int ks = 1; ks <= 16 && ks <= nchunks; ++ks) {
+            const int per = (nchunks + ks - 1) / ks;
+            if ((nchunks + per - 1) / per != ks) continue;                 // (the dispatcher would round it to this anyway)
+            const long rounds = (blocks * ks + ncu - 1) / ncu;
+            double t = 4.0 + (8.0 + per * 9 * step_us) * (double)rounds;
+            if (ks > 1) t += 4.0 + (double)M * Cout * 4.0 * (ks + 1.5) / 5.0e6;
+            if (t < best) { best = t; best_bn = bn; best_ks = ks; }
+        }
+    }
+    *bn_out = best_bn;
+    *ks_out = best_ks;
+}
+
 static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
-    int bn = choose_bn_halo(Cout);
-    long blocks = (long)B * (H * W / 256) * ((Cout + bn - 1) / bn);
-    int nchunks = (Cin + BK - 1) / BK;
-    if (blocks >= 200 || nchunks < 2) return 1;
-    int ks = (int)((256 + blocks - 1) / blocks);
-    if (ks > nchunks) ks = nchunks;
-    if (ks > 16) ks = 16;
-    return ks < 1 ? 1 : ks;
+    int bn, ks;
+    choose_halo_plan(B, H, W, Cin, Cout, &bn, &ks);
+    return ks;
 }
 
 // split-K plan: a launch needs >> 256 workgroups to fill the chip; the UNet's 32x32 .. 8x8 levels have few pixel
@@ -1534,7 +1557,12 @@ extern "C" int adap_conv2d_nhwc(
     }
     hipStream_t s = (hipStream_t)stream;
 
-    int bn = halo ? choose_bn_halo(Cout) : choose_bn(Cout);
+    int bn = choose_bn(Cout);
+    if (halo) {
+        int ks_plan;
+        choose_halo_plan(B, Hin, Win, Cin, Cout, &bn, &ks_plan);
+        if (g_force_bn && g_force_bn != 64) bn = g_force_bn;               // diagnostic override (tools/conv3_probe.py)
+    }
     bool use_big = big;
     if (!halo && nbatch == 1 && up == 0 && p.ksplit == 1 && p.ktiles_total >= 4 && narrow_tiles_enabled()) {
         // too few workgroups for 256 CUs and K too short for split-K to pay: trade tile size for workgroups.
