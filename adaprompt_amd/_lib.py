@@ -55,6 +55,16 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     from . import build as _build
+    alt = os.environ.get("ADAP_LIB_PATH")          # A/B timing of two builds on one box (tools/): no stamp check, no rebuild
+    if alt:
+        lib = ctypes.CDLL(alt)
+        _protos = parse_header()
+        for name, (restype, argtypes, _) in _protos.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return lib
     if build_if_missing:
         # no-op when the source stamp matches; otherwise a stale library (sources, header or flags changed since it was
         # built -- the .so is git-ignored but ships with the snapshot) is rebuilt instead of being dlopen'ed

@@ -61,7 +61,7 @@ struct AttnParams {
     float* lse;                 // [B][H][N]
     // backward
     const uint16_t* dout; long lddo;   // bf16 [B,N,H*d]
-    const float* delta;                // [B][H][N]
+    float* delta;                      // [B][H][N]: written by the dQ kernel, read by the dK/dV kernel
     float* dq32; uint16_t* dq16; long lddq;
     float* dk32; uint16_t* dk16; long lddk;
     float* dv32; uint16_t* dv16; long lddv;
@@ -676,40 +676,6 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
 }
 
 // =============================================================================================
-// backward, part 0: delta[b][h][n] = sum_d dO * O      (one wave per token row)
-// =============================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, long ldo,
-                                                         const uint16_t* __restrict__ dout, long lddo,
-                                                         float* __restrict__ delta, int B, int H, int N, int d) {
-    __shared__ float part[4][160];     // C/8 <= 160 chunks
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + w;
-    const int nch = H * d / 8;
-    const bool live = row < (long)B * N;
-    if (live) {
-        for (int ch = lane; ch < nch; ch += 64) {
-            uint4 a = *(const uint4*)(o + row * ldo + ch * 8);
-            uint4 g = *(const uint4*)(dout + row * lddo + ch * 8);
-            float fa[8], fg[8];
-            unpack_bf16x8(a, fa);
-            unpack_bf16x8(g, fg);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += fa[e] * fg[e];
-            part[w][ch] = s;
-        }
-    }
-    __syncthreads();
-    if (live && lane < H) {
-        int cph = d / 8;
-        float s = 0.f;
-        for (int i = 0; i < cph; ++i) s += part[w][lane * cph + i];
-        long b = row / N, n = row - b * N;
-        delta[(b * H + lane) * N + n] = s;
-    }
-}
-
-// =============================================================================================
 // backward, part 1: dQ (query-stationary)
 // =============================================================================================
 template <int KS, int VT>
@@ -741,10 +707,26 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         qf[s] = __builtin_bit_cast(bf16x8, v);
         dof[s] = __builtin_bit_cast(bf16x8, g);
     }
+    // delta[b][h][n] = sum_d dO * O of this query row, computed here (the lane pair l, l ^ 32 holds the even / odd 8-channel
+    // chunks of dO already; O costs KS more 16-byte loads) and left in p.delta for the dK/dV kernel that follows on the
+    // stream -- a separate pass over O and dO was one more launch per attention layer (64 per micro-batch)
     float lse2 = 0.f, dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int ch = 2 * s + h;
+        if (q < p.N && ch * 8 < d) {
+            const uint4 ov = *(const uint4*)(p.o + ((size_t)b * p.N + q) * p.ldo + head * d + ch * 8);
+            float fo[8], fg[8];
+            unpack_bf16x8(ov, fo);
+            unpack_bf16x8(__builtin_bit_cast(uint4, dof[s]), fg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += fo[e] * fg[e];
+        }
+    }
+    dl += __shfl_xor(dl, 32, 64);
     if (q < p.N) {
         lse2 = p.lse[((size_t)b * p.H + head) * p.N + q] * 1.4426950408889634f;
-        dl = p.delta[((size_t)b * p.H + head) * p.N + q];
+        if (h == 0) p.delta[((size_t)b * p.H + head) * p.N + q] = dl;
     }
     f32x16 dQ[VT];
 #pragma unroll
@@ -1204,10 +1186,8 @@ extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long l
                  "attention_bwd: leading dims");
     ADAP_REQUIRE(H * d / 8 <= 160 && H <= 64, ADAP_ERR_UNSUPPORTED, "attention_bwd: H*d too large");
     hipStream_t s = (hipStream_t)stream;
-    long rows = (long)B * N;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const uint16_t*)out, ldo,
-                       (const uint16_t*)dout, lddo, delta_ws, B, H, N, d);
     AttnParams p = {};
+    p.o = (uint16_t*)out; p.ldo = ldo;          // read only: the dQ kernel forms delta = rowsum(dO * O) from it
     p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
     p.kmask = key_mask; p.mcount = key_count; p.lse = (float*)lse; p.dout = (const uint16_t*)dout; p.lddo = lddo;
     p.delta = delta_ws;
