@@ -2,11 +2,11 @@
 (SURVEY 8f-2 / config 5).
 
 TEST INFRASTRUCTURE ONLY.  ``make_ddim_timesteps`` / ``make_ddim_sampling_parameters``
-(ldm/modules/diffusionmodules/util.py:46-77) are importable and pinned by tests/golden/ddim_params.npz;
-``DDIMSampler`` itself hard-codes ``torch.device("cuda")`` in ``register_buffer`` (ddim.py:22-26) and cannot be
-constructed in the CPU-only build container, so ``ddim_sampling`` / ``p_sample_ddim`` (ddim.py:135-292) follow the
-source text and are pinned by known-answer tests (tests/test_ddim_oracle.py): PARITY UNPINNED against reference
-outputs for the loop itself.
+(ldm/modules/diffusionmodules/util.py:46-77) are pinned by tests/golden/ddim_params.npz; the sampler loop --
+``ddim_sampling`` / ``p_sample_ddim`` (ddim.py:135-292) -- by tests/golden/ddim_loop.npz, captured from the reference's
+OWN ``DDIMSampler`` run on CPU (tests/golden/make_golden_ddim.py: its ``register_buffer``, the only place that names
+``torch.device("cuda")``, replaced on the instance; a closed-form eps model): 4 cases incl. guidance annealing on the doubled
+batch, eta > 0 and the "quad" discretisation (tests/test_ddim_golden.py holds this file AND the product's sampler to them).
 """
 import numpy as np
 import torch

@@ -2,13 +2,16 @@
 
     python tests/golden/make_golden_clip_vision.py        # writes tests/golden/clip_vision_<case>.npz
 
-Source of truth: the ``transformers`` package of this image (5.15.0) -- ``CLIPVisionModel``'s own blocks (embeddings,
-pre_layrnorm, encoder layers, post_layernorm) -- called in the order and with the mask construction of the reference's
-``CLIPVisionTransformer_forward`` (adaface/subj_basis_generator.py:670-737).  The reference's subclass itself cannot be
-constructed under transformers 5 (it patches ``self.vision_model``, which ``CLIPVisionModel`` no longer has), and transformers
-< 5 is not installed; nothing of the reference is stood in for.  Weights: ``synth.synthetic_clip_vision_state_dict`` (a
-function of tensor name and seed: only seeds and outputs are committed).  Inputs: seeded pixel values, a mask with hard and
-fractional values (the reference hands a bilinear-resized mask over, ddpm.py:2395-2409)."""
+Source of truth: the reference's OWN ``CLIPVisionTransformer_forward`` (adaface/subj_basis_generator.py:670-737), imported
+from /root/reference and called UNBOUND on the vision transformer of this image's ``transformers`` (5.15.0) ``CLIPVisionModel``
+-- the function the reference's ``CLIPVisionModelWithMask`` binds to ``self.vision_model`` (:740-744).  (The subclass itself
+cannot be constructed under transformers 5 -- ``CLIPVisionModel`` no longer has the ``vision_model`` attribute it patches -- but
+its forward runs as written on the module that attribute used to be.)  The mask handling, the order of the blocks, the pooled
+output and the returned token mask are therefore the reference's; the per-layer hidden states are read with forward hooks on
+``encoder.layers[i]`` (transformers 5's encoder no longer returns them from that call).  Weights:
+``synth.synthetic_clip_vision_state_dict`` (a function of tensor name and seed: only seeds and outputs are committed).  Inputs:
+seeded pixel values, a mask with hard and fractional values (the reference hands a bilinear-resized mask over,
+ddpm.py:2395-2409)."""
 import os
 import sys
 
@@ -43,6 +46,22 @@ def sub(t):
     return t[:, ::4, ::4].contiguous() if t.shape[-1] >= 1024 else t[:, ::2].contiguous()
 
 
+_REF = {}
+
+
+def reference_forward():
+    """adaface.subj_basis_generator.CLIPVisionTransformer_forward, imported from the reference tree (process 2)"""
+    if "f" not in _REF:
+        import types
+        sys.dont_write_bytecode = True
+        sys.modules.setdefault("cv2", types.ModuleType("cv2"))            # adaface/util.py:6, import time only
+        sys.path.insert(0, "/root/reference")
+        import adaface.subj_basis_generator as sbg
+        assert sbg.__file__.startswith("/root/reference")
+        _REF["f"] = sbg.CLIPVisionTransformer_forward
+    return _REF["f"]
+
+
 def run_hf(cfg, sd, x, mask):
     from transformers import CLIPVisionConfig, CLIPVisionModel
     m = CLIPVisionModel(CLIPVisionConfig(**cfg)).eval()
@@ -51,21 +70,19 @@ def run_hf(cfg, sd, x, mask):
     missing, unexpected = m.load_state_dict({k[len(strip):]: v for k, v in sd.items()}, strict=False)
     assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
     vt = m if strip else m.vision_model
+    hidden = []
+    hooks = [vt.pre_layrnorm.register_forward_hook(lambda mod, i, o: hidden.append(o))]
+    for lyr in vt.encoder.layers:
+        hooks.append(lyr.register_forward_hook(lambda mod, i, o: hidden.append(o[0] if isinstance(o, tuple) else o)))
     with torch.no_grad():
-        h = vt.pre_layrnorm(vt.embeddings(x))
-        tm = pair = None
-        if mask is not None:
-            g = int(np.sqrt(h.shape[1] - 1))
-            tm = F.interpolate(mask.unsqueeze(1), size=(g, g), mode="nearest").flatten(2)
-            tm = torch.cat([torch.ones_like(tm[:, :, :1]), tm], dim=-1)
-            pair = torch.matmul(tm.transpose(-1, -2), tm).unsqueeze(1)
-        hidden = [h]
-        for lyr in vt.encoder.layers:
-            h = lyr(h, pair)
-            h = h[0] if isinstance(h, tuple) else h
-            hidden.append(h)
-        pooled = vt.post_layernorm(h[:, 0])
-    return hidden, pooled, tm
+        out = reference_forward()(vt, pixel_values=x, attn_mask=mask, output_attentions=False, output_hidden_states=True,
+                                  return_dict=True)
+    for h in hooks:
+        h.remove()
+    assert len(hidden) == cfg["num_hidden_layers"] + 1
+    assert torch.equal(out.last_hidden_state, hidden[-1])
+    tm = None if out.attn_mask is None else out.attn_mask.permute(0, 2, 1)
+    return hidden, out.pooler_output, tm
 
 
 def main():
