@@ -36,13 +36,31 @@ def is_current():
 
 
 def build(force=False, verbose=True):
+    """Build (or rebuild a stale) library.  Safe when several ranks of one node call it at once (torchrun, bench --gpus N, the
+    two-rank tests): an flock serialises the builders, every builder compiles into its own temporary directory and the
+    library + stamp are moved into place atomically, so nobody ever dlopens or links a half-written file; whoever gets the
+    lock second finds the stamp current and returns."""
+    import fcntl
+    import shutil
+    import tempfile
     stamp_file = OUT + ".stamp"
-    stamp = _stamp()
     if not force and is_current():
         return OUT
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_current():          # another process built it while this one waited
+                return OUT
+            return _build_locked(stamp_file, verbose, tempfile, shutil)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(stamp_file, verbose, tempfile, shutil):
+    stamp = _stamp()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objdir = tempfile.mkdtemp(prefix=f"obj{os.getpid()}_", dir=os.path.join(HERE, "build"))
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -54,12 +72,21 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", OUT]
+    tmp_out = os.path.join(objdir, "libadaprompt_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", tmp_out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    with open(stamp_file, "w") as fh:
+    with open(tmp_out + ".stamp", "w") as fh:
         fh.write(stamp)
+    if os.path.exists(stamp_file):
+        os.remove(stamp_file)                     # never a current stamp next to an older library
+    os.replace(tmp_out, OUT)
+    os.replace(tmp_out + ".stamp", stamp_file)
+    # keep the objects of the last build where tools/ expect them (A/B links), drop the temporary directory
+    for o in objs:
+        os.replace(o, os.path.join(HERE, "build", os.path.basename(o)))
+    shutil.rmtree(objdir, ignore_errors=True)
     return OUT
 
 

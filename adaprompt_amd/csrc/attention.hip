@@ -69,7 +69,16 @@ struct AttnParams {
     float scale;
     int qsplit;                 // dK/dV kernel: the query range is cut into qsplit slices (blockIdx.z), f32 partials
     float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
+    // ping-pong forward only
+    int prio_mode;              // which phase runs at raised priority: 1 = matrix (default), 2 = vector, 0 = neither
+    unsigned long long* stamps; // diagnostic s_memtime stamps (tools/attn_stamps.py) or null
 };
+
+// sample b attends to its first key_count[b] keys, clamped to [1, M]: a count <= 0 would leave the softmax without a
+// denominator (l = 0 -> NaN output); the C ABI documents key_count >= 1 and treats anything smaller as 1
+__device__ __forceinline__ int attn_key_count(const AttnParams& p, int b) {
+    return p.mcount ? max(1, min(p.mcount[b], p.M)) : p.M;
+}
 
 #define MAX_SLACK 5.0f          // see attn_fwd_kernel's running reference point
 
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
-    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count
+    const int Mb = attn_key_count(p, b);          // this sample's key count
     const int ntiles = (Mb + 63) / 64;
     TileRegs<G::NCH> rK, rV;
     TileMap<G::NCH> mapK, mapV;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
-    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count
+    const int Mb = attn_key_count(p, b);          // this sample's key count
     const int ntiles = (Mb + 63) / 64;
     // staging map: thread -> chunk (row, 16-byte column) of a 64-row tile
     const int srow = tid / NCH, sch = tid - srow * NCH;
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
     const int nphases = 2 * ntiles + 1;
     // diagnostic (tools/attn_stamps.py): workgroup (0,0)'s waves 0 and 4 stamp every phase: entry, work done, barrier passed
     unsigned long long* stamps = (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0)
-                                     ? (unsigned long long*)p.part : nullptr;
+                                     ? p.stamps : nullptr;
     for (int ph = 0; ph < nphases; ++ph) {
         if (stamps) stamps[(ph * 2 + grp) * 3 + 0] = __builtin_amdgcn_s_memtime();
         if ((ph & 1) == 0) {                                // tile ph/2 + 2 starts its trip to LDS
@@ -619,13 +628,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
         if (r >= 0 && (r >> 1) < ntiles) {
             const int t = r >> 1;
             if ((r & 1) == 0) {
-                if (p.qsplit == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+                if (p.prio_mode == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
                 softmax(t);
                 __builtin_amdgcn_s_setprio(0);
             } else {
                 // the matrix phase issues first: its 28 MFMAs take 8 issue cycles each and keep the pipe busy for 32; left at equal
                 // priority the vector-phase partner (when it is the older wave) starves them (stamps: 2340 vs 1590 ticks)
-                if (p.qsplit == 1) __builtin_amdgcn_s_setprio(2);
+                if (p.prio_mode == 1) __builtin_amdgcn_s_setprio(2);
                 mm_phase(t, true, t + 1 < ntiles);
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 
     const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
     const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
-    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count
+    const int Mb = attn_key_count(p, b);          // this sample's key count
     const int ntiles = (Mb + 63) / 64;
     TileRegs<G::NCH> rK, rV;
     TileMap<G::NCH> mapK, mapV;
@@ -851,7 +860,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int key = kblk * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
-    const int Mb = p.mcount ? min(p.mcount[b], p.M) : p.M;          // this sample's key count (rows beyond it get zeros)
+    const int Mb = attn_key_count(p, b);          // this sample's key count (rows beyond it get zeros)
 
     // this wave's 32 keys as B operands
     bf16x8 kf[KS], vf[KS];
@@ -1033,13 +1042,45 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnParams p) {
     }
 }
 
+// Kernel-selection switches, read from the environment ONCE (ADAP_ATTN_PP / ADAP_ATTN_FORCE_PP / ADAP_ATTN_PP_PRIO /
+// ADAP_ATTN_QB1 / ADAP_ATTN_DKV_QSPLIT) instead of with getenv() on every launch; tests and the tuning tools change them
+// through adap_attention_set_debug.
+struct AttnDebug {
+    int pp_mode;      // 0 = query-stationary forward (default), 1 = ping-pong where it applies, 2 = ping-pong always
+    int pp_prio;      // ping-pong kernel: phase at raised priority, 1 = matrix (default), 2 = vector, 0 = neither
+    int qb1;          // 1 = one query block per wave even at the 64 x 64 level
+    int dkv_qsplit;   // 0 = heuristic, else the dK/dV kernel's query-split factor
+};
+static AttnDebug& attn_debug() {
+    static AttnDebug d = [] {
+        AttnDebug v;
+        v.pp_mode = getenv("ADAP_ATTN_FORCE_PP") ? 2 : (getenv("ADAP_ATTN_PP") ? 1 : 0);
+        const char* e = getenv("ADAP_ATTN_PP_PRIO");
+        v.pp_prio = e ? atoi(e) : 1;
+        v.qb1 = getenv("ADAP_ATTN_QB1") ? 1 : 0;
+        e = getenv("ADAP_ATTN_DKV_QSPLIT");
+        v.dkv_qsplit = e ? atoi(e) : 0;
+        return v;
+    }();
+    return d;
+}
+extern "C" int adap_attention_set_debug(int pp_mode, int pp_prio, int qb1, int dkv_qsplit) {
+    ADAP_REQUIRE(pp_mode >= -1 && pp_mode <= 2 && pp_prio >= -1 && pp_prio <= 2 && qb1 >= -1 && qb1 <= 1 && dkv_qsplit >= -1 &&
+                 dkv_qsplit <= 16, ADAP_ERR_UNSUPPORTED, "attention_set_debug: %d %d %d %d", pp_mode, pp_prio, qb1, dkv_qsplit);
+    AttnDebug& d = attn_debug();                  // -1 leaves a switch as it is
+    if (pp_mode >= 0) d.pp_mode = pp_mode;
+    if (pp_prio >= 0) d.pp_prio = pp_prio;
+    if (qb1 >= 0) d.qb1 = qb1;
+    if (dkv_qsplit >= 0) d.dkv_qsplit = dkv_qsplit;
+    return ADAP_OK;
+}
+
 // query-split factor of the dK/dV kernel: key-stationary workgroups number ceil(M/128)*B*H, which is only 32 for the
 // cross-attention layers (M = 77) -- far too few for 256 CUs -- so the query loop is cut into slices
 static int dkv_qsplit(int B, int H, int N, int M, int d) {
     const long blocks = (long)((M + 127) / 128) * B * H;
     const int ntiles = (N + 63) / 64;
-    if (const char* e = getenv("ADAP_ATTN_DKV_QSPLIT")) {          // tuning override (tools/attn_bwd_count_probe.py)
-        int q = atoi(e);
+    if (const int q = attn_debug().dkv_qsplit) {                   // tuning override (tools/attn_bwd_count_probe.py)
         if (q >= 1 && q <= 16 && q <= ntiles) return q;
     }
     if (blocks >= 256 || ntiles < 2) return 1;
@@ -1084,13 +1125,8 @@ static int launch_fwd_pp(const AttnParams& p, hipStream_t s) {
     }
     dim3 grid((p.N + 511) / 512, p.B * p.H);
     AttnParams pp = p;
-    pp.part = (float*)g_attn_stamps;          // diagnostic stamps (null in normal runs)
-    static int prio_mode = -1;                // which phase runs at raised priority: 1 = matrix (default), 2 = vector, 0 = neither
-    if (prio_mode < 0) {
-        const char* e = getenv("ADAP_ATTN_PP_PRIO");
-        prio_mode = e ? atoi(e) : 1;
-    }
-    pp.qsplit = prio_mode;                    // (qsplit is a backward-only field: reused to carry the mode)
+    pp.stamps = (unsigned long long*)g_attn_stamps;          // diagnostic stamps (null in normal runs)
+    pp.prio_mode = attn_debug().pp_prio;
     hipLaunchKernelGGL((attn_fwd_pp_kernel<KS, VT>), grid, dim3(512), lds, s, pp);
     g_attn_fwd_variant = 3;
     return adap_check_launch("attn_fwd (ping-pong)");
@@ -1101,12 +1137,12 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
     // The ping-pong kernel (long sequences, short heads) is parity-green and opt-in: under sustained load it measures 155-157 us
     // on B4 N4096 d40 against 153.5 us for the kernel below, and the training step is 0.4 % faster without it.
     if constexpr (KS <= 4) {
-        const int pp_mode = getenv("ADAP_ATTN_FORCE_PP") ? 2 : (getenv("ADAP_ATTN_PP") ? 1 : 0);     // (read per launch: tests toggle it)
+        const int pp_mode = attn_debug().pp_mode;
         if (pp_mode == 2 || (pp_mode == 1 && p.M >= 512 && (long)((p.N + 511) / 512) * p.B * p.H >= 192))
             return launch_fwd_pp<KS, VT>(p, s);
     }
     // two query blocks per wave when that still leaves >= 2 workgroups per CU's worth of work (the 64x64 level)
-    if (KS <= 4 && (long)((p.N + 255) / 256) * p.B * p.H >= 512 && !getenv("ADAP_ATTN_QB1")) return launch_fwd_q<KS, VT, 2>(p, s);
+    if (KS <= 4 && (long)((p.N + 255) / 256) * p.B * p.H >= 512 && !attn_debug().qb1) return launch_fwd_q<KS, VT, 2>(p, s);
     return launch_fwd_q<KS, VT, 1>(p, s);
 }
 

@@ -37,3 +37,33 @@ extern "C" int adap_device_info(char* name, int name_cap, int* num_cus, char* ar
     if (num_cus) *num_cus = prop.multiProcessorCount;
     return ADAP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Diagnostic: a kernel that merely OCCUPIES part of the chip for a while -- `blocks` workgroups of `threads` threads, each
+// holding ~`vgprs_hint` live registers per lane, until `usec` microseconds of the 100 MHz real-time clock have passed -- the
+// shape of a resident collective kernel (RCCL's all-reduce: tens of workgroups for milliseconds).  tests/test_parallel_gpu.py
+// runs the single-launch GroupNorm beside it on another stream.  Every wave reaches the exit condition (bounded by time).
+// ---------------------------------------------------------------------------------------------
+__global__ void adap_occupy_kernel(unsigned long long ticks, float* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    float r[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) r[i] = (float)(threadIdx.x + i);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 96; ++i) r[i] = r[i] * 1.0000001f + 0.5f;          // keeps the registers live
+        __builtin_amdgcn_s_sleep(8);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 96; ++i) s += r[i];
+    if (s == 12345.678f && sink) sink[0] = s;                                 // never true: the loop is not dead code
+}
+
+extern "C" int adap_debug_occupy(int blocks, int threads, int usec, float* sink, void* stream) {
+    ADAP_REQUIRE(blocks >= 1 && blocks <= 1024 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && usec >= 0 && usec <= 200000,
+                 ADAP_ERR_UNSUPPORTED, "debug_occupy: %d blocks x %d threads for %d us", blocks, threads, usec);
+    hipLaunchKernelGGL(adap_occupy_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, sink);
+    return adap_check_launch("debug_occupy");
+}

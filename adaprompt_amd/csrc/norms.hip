@@ -1010,7 +1010,8 @@ __global__ __launch_bounds__(GN_FT) void gn_fused_bwd_kernel(const void* __restr
 static int g_gn_cus = 0;
 static int g_gn_last_variant = 0;          // 0 = two-pass, N > 0 = single launch with N octs per thread
 static int gn_fused_geom(int B, int HW, int C, int max_octs, int* nslab, int* rows_per_slab) {
-    if (getenv("ADAP_GN_TWO_PASS")) return 0;
+    static const bool env_two_pass = getenv("ADAP_GN_TWO_PASS") != nullptr;       // (read once; the host can also pass sync = NULL)
+    if (env_two_pass) return 0;
     if (g_gn_cus == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

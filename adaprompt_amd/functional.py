@@ -139,6 +139,20 @@ def train_of(**layers):
     return out if any_grad else None
 
 
+# GradReducer's bucketed exchange (parallel.GradReducer.begin_backward): called with every parameter whose gradient a block
+# Function has finished writing through raw pointers -- autograd's post-accumulate hooks never fire for those
+GRAD_DONE = None
+
+
+def _grads_done(T):
+    if GRAD_DONE is not None and T is not None:
+        for w, b in T.values():
+            if w is not None and w.requires_grad:
+                GRAD_DONE(w)
+            if b is not None and b.requires_grad:
+                GRAD_DONE(b)
+
+
 def _acc(param):
     if param is None or not param.requires_grad:
         return None
@@ -247,6 +261,7 @@ class ResBlockFn(torch.autograd.Function):
                 dbs[1].add_(tmp[0])
             if not ctx.needs_input_grad[1]:
                 g_emb = None
+        _grads_done(T)
         if sk is None:          # identity skip: dx + g straight into a new tensor (no clone of g)
             gx, gx16 = ops.groupnorm_bwd(ga1, x, g1w, g1b, m1, r1, 1, out_bf16=True, add_from=g)
         else:
@@ -315,11 +330,11 @@ class SpatialTransformerFn(torch.autograd.Function):
         pout = P["proj_out"]
         out, _ = ops.linear(t3, pout.fwd, C, bias=pout.bias, residual=x.view(B, N, C))
         ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
-        ctx.key_mask, ctx.key_compaction, ctx.kv1c = key_mask, kc, kv1c
+        ctx.key_mask, ctx.key_compaction = key_mask, kc
         ctx.tok_w = tok_w if capture else None
         tr = P.get("train") is not None      # weight gradients also need each contraction's input operand
         ctx.save_for_backward(x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh,
-                              ctx_k, ctx_v, *((xn, n1, n2, n3, gg, t3) if tr else (None,) * 6))
+                              ctx_k, ctx_v, *((xn, n1, n2, n3, gg, t3) if tr else (None,) * 6), kv1c)
         out = out.view(B, H, W, C)
         if capture:
             # attnscore and q*d^-1/4 stay in the graph (the cross-layer consistency loss of the recon iteration reads
@@ -333,7 +348,7 @@ class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, g_score=None, _g_prob=None, g_qs=None, g_tokmap=None):
         (x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh, ctx_k,
-         ctx_v, xn, n1, n2, n3, gg, t3) = ctx.saved_tensors
+         ctx_v, xn, n1, n2, n3, gg, t3, kv1c) = ctx.saved_tensors
         P, heads = ctx.P, ctx.heads
         T = P.get("train")
         B, H, W, C = x.shape
@@ -406,7 +421,6 @@ class SpatialTransformerFn(torch.autograd.Function):
         dqkv1 = torch.empty(B, N, 3 * C, device=x.device, dtype=BF16)
         kc = ctx.key_compaction
         if kc is not None:
-            kv1c, ctx.kv1c = ctx.kv1c, None
             dkvc = torch.empty(B, N, 2 * C, device=x.device, dtype=BF16)
             ops.attention_bwd(qkv1[..., :C], kv1c[..., :C], kv1c[..., C:], o1, go1, lse1, heads, None,
                               dq=dqkv1[..., :C], dk=dkvc[..., :C], dv=dkvc[..., C:], key_count=kc.count)
@@ -430,6 +444,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         if T is not None:
             _dw_lin(T, "proj_in", xn.view(B, N, C), gt0h)
             _dw_norm(T, "norm", _op16(gxn).view(B, H, W, C), x, gnw, gnb, gm, gr, 0, 0)
+            _grads_done(T)
         gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None
@@ -462,6 +477,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.train is not None:
             (x,) = ctx.saved_tensors
             _dw_conv(ctx.train, "conv", x, g, 3, 2 if mode == "down" else 1, 1, 1 if mode == "up" else 0)
+            _grads_done(ctx.train)
         if mode == "down":
             gx, _ = ops.conv2d(g, pk.bwd, pk.bwd.shape[1], 3, 1, 1, up=2, out_hw=ctx.in_hw)
         elif mode == "up":
@@ -493,6 +509,7 @@ class OutHeadFn(torch.autograd.Function):
         if ctx.train is not None:
             _dw_conv(ctx.train, "conv", a, g, 3, 1, 1)
             _dw_norm(ctx.train, "gn", _op16(ga), h, ctx.gn[0], ctx.gn[1], m, r, 0, 1)
+            _grads_done(ctx.train)
         gh, _ = ops.groupnorm_bwd(ga, h, ctx.gn[0], ctx.gn[1], m, r, 1)
         return gh, None, None, None
 
@@ -514,6 +531,7 @@ class InConvFn(torch.autograd.Function):
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         _dw_conv(ctx.train, "conv", x, _operand(g), 3, 1, 1)
+        _grads_done(ctx.train)
         return None, None, None, None
 
 

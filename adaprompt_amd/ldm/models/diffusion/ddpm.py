@@ -1383,6 +1383,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             # adds into the same flat gradient buffer (AccumulateGrad and the weight-gradient kernels write it from the
             # very start of the backward)
             reducer.wait()
+            reducer.begin_backward()         # chunks of the gradient buffer go out as the backward completes them
         self.manual_backward(model_output, grad, aux)                      # == manual_backward(loss), ddpm.py:595
         if reducer is not None:
             reducer.reduce()

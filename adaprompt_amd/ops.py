@@ -231,6 +231,17 @@ def batched_matmul_nt(a, b, out_dtype=F32, alpha=1.0):
 
 _GN_SYNC = {}
 _GN_SYNC_STREAM = {}
+_GN_TWO_PASS = 0
+
+
+def gn_two_pass(on):
+    """Hold the GroupNorms to the two-launch kernels while ``on`` (nestable: a count).  The single-launch kernel's workgroups
+    wait for each other inside the launch, so its whole grid (up to one 512-thread workgroup per CU) must be resident; while a
+    collective kernel occupies part of the chip for milliseconds -- ``GradReducer`` between ``reduce()`` and ``wait()`` -- the
+    late workgroups would only start once it ends and the early ones would spin until then (measured:
+    tests/test_parallel_gpu.py::test_groupnorm_beside_a_resident_collective_kernel).  Decided on the host, no sync."""
+    global _GN_TWO_PASS
+    _GN_TWO_PASS = max(0, _GN_TWO_PASS + (1 if on else -1))
 
 
 def set_gn_single_launch_stream(device, raw_stream):
@@ -246,6 +257,8 @@ def gn_sync_buffer(device):
     wait for the rest for ever.  Hence exactly ONE stream per device takes that path (the default stream, where the UNet's
     forward / backward run); GroupNorms issued on any other stream (the prefetchers' side streams) run the two-launch
     kernels.  Kernels of one stream run in order and the counters reset themselves: allocated and zeroed once."""
+    if _GN_TWO_PASS:
+        return 0
     st = _stream()
     owner = _GN_SYNC_STREAM.get(device.index)
     if owner is None:
@@ -406,9 +419,10 @@ def attention_fwd(q, k, v, heads, key_mask=None, scale=None, key_count=None):
     return out, lse
 
 
-def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=None, dv=None, out_dtype=BF16, key_count=None):
+def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=None, dv=None, out_dtype=BF16, key_count=None,
+                  scale=None):
     """dq/dk/dv may be caller-provided pixel-major views (e.g. slices of one fused [B,N,3C] buffer);
-    otherwise fresh tensors of ``out_dtype`` are allocated."""
+    otherwise fresh tensors of ``out_dtype`` are allocated.  ``scale``: the score scale the forward used (default d^-1/2)."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
@@ -426,7 +440,7 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=Non
               _rows_ld(v)[1], _ptr(key_mask), _ptr(key_count), out.data_ptr(), _rows_ld(out)[1], dout.data_ptr(),
               _rows_ld(dout)[1], lse.data_ptr(), delta.data_ptr(),
               dq32, dq16, _rows_ld(dq)[1], dk32, dk16, _rows_ld(dk)[1], dv32, dv16, _rows_ld(dv)[1],
-              B, heads, N, M, d, float(d) ** -0.5, _stream())
+              B, heads, N, M, d, float(d) ** -0.5 if scale is None else float(scale), _stream())
     return dq, dk, dv
 
 

@@ -18,6 +18,8 @@ import os
 import torch
 import torch.distributed as dist
 
+_HOLD_GN = os.environ.get("ADAP_GN_HOLD_DURING_EXCHANGE", "0") == "1"
+
 
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
@@ -125,23 +127,93 @@ class GradReducer:
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg_in_collective = backend == "nccl"
         self._scale_pending = False
+        self._gn_held = False
+        # bucketed mode (begin_backward): which chunks a parameter's gradient lies in, and how many parameters a chunk waits for
+        self._chunk_elems = per
+        self._chunks_of, self._need = {}, [0] * len(self.chunks)
+        base = self.flat.data_ptr()
+        for p_ in self.params:
+            lo = (p_.grad.data_ptr() - base) // 4
+            cs = list(range(lo // per, (lo + p_.numel() - 1) // per + 1))
+            self._chunks_of[id(p_)] = cs
+            for c in cs:
+                self._need[c] += 1
+        self._left = self._issued = self._ready = None
+        self._hooks = []
 
-    def reduce(self):
-        if self.world == 1:
-            return
-        self.wait()
+    # ---- one chunk's collective ----------------------------------------------------------------------------------------
+    def _issue(self, ci):
+        c = self.chunks[ci]
         if self._cabi is not None:
-            self._side.wait_stream(torch.cuda.current_stream())
+            # the chunk's gradients were written on the current (compute) stream: the exchange stream waits for exactly that
+            ev = torch.cuda.Event()
+            ev.record()
+            self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                for c in self.chunks:
-                    self._cabi.allreduce_(c, average=True)
+                self._cabi.allreduce_(c, average=True)
                 self._done = torch.cuda.Event()
                 self._done.record()
             return
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-        for c in self.chunks:
-            self._works.append(dist.all_reduce(c, op=op, group=self.group, async_op=True))
+        self._works.append(dist.all_reduce(c, op=op, group=self.group, async_op=True))
         self._scale_pending = not self._avg_in_collective
+
+    def _hold_groupnorm(self):
+        # Optional (ADAP_GN_HOLD_DURING_EXCHANGE=1): while collective kernels are resident the GroupNorms take the two-launch
+        # form (ops.gn_two_pass).  Off by default: beside a resident kernel of a collective's footprint (48-128 workgroups x
+        # 512 threads x ~100 registers for 4 ms) the single-launch kernel's workgroups still all find room and a call costs
+        # 20 us instead of 17 (two launches: 31 us) -- tests/test_parallel_gpu.py::test_groupnorm_beside_a_resident_collective_kernel.
+        # If a communicator ever did crowd them out, the GroupNorm would last as long as the collective (bounded wait; a
+        # time-out turns its output into NaN and sets the poison word ops.gn_poison_poll reads), and this switch is the remedy.
+        if not _HOLD_GN:
+            return
+        if not self._gn_held and self.flat.is_cuda:
+            from . import ops
+            ops.gn_two_pass(True)
+            self._gn_held = True
+
+    # ---- bucketed exchange: a chunk goes out as soon as the backward has finished every gradient in it -------------------
+    def begin_backward(self):
+        """Arm the bucketed exchange for the backward that follows (call after ``wait()``): with ``unfreeze_model`` the UNet's
+        4.5 GB of gradients are complete block by block, output blocks first, long before the hook's -- each 256 MB chunk's
+        all-reduce starts when the last gradient in it is final (``grad_ready``: autograd's post-accumulate hook for
+        parameters autograd manages, ``functional.GRAD_DONE`` for the ones the block Functions write through raw pointers)
+        and runs under the rest of the backward; ``reduce()`` afterwards sends what is left.  The numbers are those of the
+        single-shot exchange: the same collectives on the same data, only earlier."""
+        if self.world == 1:
+            return
+        assert not self.pending, "begin_backward() with an exchange still in flight: call wait() first"
+        if not self._hooks:
+            from . import functional
+            for p_ in self.params:
+                self._hooks.append(p_.register_post_accumulate_grad_hook(self.grad_ready))
+            functional.GRAD_DONE = self.grad_ready
+        self._left = list(self._need)
+        self._issued = [False] * len(self.chunks)
+        self._ready = set()
+
+    def grad_ready(self, param):
+        """``param.grad`` is final for this backward (idempotent within one backward)."""
+        if self._left is None or id(param) in self._ready or id(param) not in self._chunks_of:
+            return
+        self._ready.add(id(param))
+        for c in self._chunks_of[id(param)]:
+            self._left[c] -= 1
+            if self._left[c] == 0 and not self._issued[c]:
+                self._issued[c] = True
+                self._hold_groupnorm()
+                self._issue(c)
+
+    def reduce(self):
+        if self.world == 1:
+            return
+        issued, self._left, self._issued, self._ready = self._issued, None, None, None
+        if issued is None:
+            self.wait()                       # single-shot mode: nothing of this backward is in flight yet
+        self._hold_groupnorm()
+        for ci in range(len(self.chunks)):
+            if issued is None or not issued[ci]:
+                self._issue(ci)
 
     def wait(self):
         """the current stream waits for the outstanding collectives.  MUST run before anything writes the gradient
@@ -155,6 +227,10 @@ class GradReducer:
         if self._scale_pending:
             self.flat.mul_(1.0 / self.world)
             self._scale_pending = False
+        if self._gn_held:
+            from . import ops
+            ops.gn_two_pass(False)
+            self._gn_held = False
 
     @property
     def pending(self):

@@ -626,6 +626,7 @@ def main():
             loss, grad, out, aux = ld.shared_step(batches[i % 2], t=t, noise=noise, x_start=x_start, anneal_t=True)
             usubmit(i + 1)
             red_u.wait()
+            red_u.begin_backward()          # UNet chunks are exchanged while the backward still runs
             ld.manual_backward(out, grad, aux)
             red_u.reduce()
             if (i + 1) % ld.manual_accumulate_grad_batches == 0:

@@ -40,6 +40,10 @@ extern "C" {
 const char* adap_last_error(void);
 int adap_abi_version(void);
 int adap_device_info(char* name, int name_cap, int* num_cus, char* arch, int arch_cap);
+/* Diagnostic: `blocks` workgroups of `threads` threads (~100 live registers per lane) stay resident for `usec` microseconds
+ * (bounded by the 100 MHz real-time clock) -- the footprint of a collective kernel running beside the compute stream
+ * (tests/test_parallel_gpu.py: the single-launch GroupNorm next to it).  sink: any device float or NULL. */
+int adap_debug_occupy(int blocks, int threads, int usec, float* sink, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Contractions: nn.Conv2d 3x3 / 1x1 and nn.Linear on the matrix cores (implicit GEMM).
@@ -134,7 +138,10 @@ int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, con
  * key_count [B] int32 (device) or NULL: sample b attends to its FIRST key_count[b] keys only -- the form a key mask takes after
  * the kept keys have been compacted to the front (adap_gather_rows_bf16): masked keys contribute exactly 0 to the softmax
  * (attention.py:223-232 fills them with -finfo.max), so leaving them out is the same arithmetic on fewer tiles.  The
- * backward writes zeros into dk / dv rows >= key_count[b].
+ * backward writes zeros into dk / dv rows >= key_count[b].  key_count[b] must be >= 1 (a softmax over no key has no
+ * denominator); values < 1 are treated as 1 and values > M as M.  A sample whose mask keeps NO key is the caller's case to
+ * resolve before compaction: the reference's masked_fill form then averages V uniformly, and KeyMasks.compaction (the host
+ * side) keeps every key for such a sample, which is the same result.
  */
 int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                        const uint8_t* key_mask, const int* key_count, void* out, long ldo, float* lse,
@@ -145,6 +152,11 @@ int adap_attention_fwd_last_variant(void);
 /* Diagnostic (tools/attn_stamps.py): with a non-NULL device buffer of 6 * (2 * ceil(M/64) + 1) uint64, workgroup (0,0) of the
  * ping-pong forward stores shader-clock stamps (entry / work done / barrier passed) per phase and wave half.  NULL = off. */
 int adap_attention_set_stamp_buffer(void* buf);
+/* Kernel-selection switches for tests and tuning tools (defaults come from the environment, read once: ADAP_ATTN_PP /
+ * ADAP_ATTN_FORCE_PP, ADAP_ATTN_PP_PRIO, ADAP_ATTN_QB1, ADAP_ATTN_DKV_QSPLIT); -1 leaves a switch unchanged.
+ * pp_mode 0 = query-stationary forward, 1 = ping-pong forward where it applies, 2 = always; pp_prio: the ping-pong kernel's
+ * raised-priority phase (1 matrix, 2 vector, 0 neither); qb1 = 1: one query block per wave; dkv_qsplit: 0 = heuristic. */
+int adap_attention_set_debug(int pp_mode, int pp_prio, int qb1, int dkv_qsplit);
 /* dq/dk/dv as f32 and/or bf16; workspace: adap_attention_bwd_workspace_floats(...) floats of scratch (the row
  * dots delta = sum(dO * O) and, when few key blocks exist -- cross attention, M = 77 -- the f32 partials of the
  * query-split dK/dV pass, summed in a fixed order). */

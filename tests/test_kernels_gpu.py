@@ -198,7 +198,7 @@ def test_groupnorm_single_launch_path(B, C, H, rows_fwd, rows_bwd):
             outs = {}
             for mode in ("single", "two_pass"):
                 if mode == "two_pass":
-                    os.environ["ADAP_GN_TWO_PASS"] = "1"
+                    ops.gn_two_pass(True)
                 try:
                     for rep in range(3):                                    # back-to-back launches: counters must reset
                         y32, y16, mean, rstd = ops.groupnorm_fwd(xi, gamma.to(dev()), beta.to(dev()), eps, act, out_f32=True,
@@ -210,7 +210,8 @@ def test_groupnorm_single_launch_path(B, C, H, rows_fwd, rows_bwd):
                     _, dx16_only = ops.groupnorm_bwd(gi, xi, gamma.to(dev()), beta.to(dev()), mean, rstd, act, out_f32=False,
                                                      out_bf16=True)
                 finally:
-                    os.environ.pop("ADAP_GN_TWO_PASS", None)
+                    if mode == "two_pass":
+                        ops.gn_two_pass(False)
                 assert (vf, vb) == ((rows_fwd, rows_bwd) if mode == "single" else (0, 0)), (mode, vf, vb)
                 outs[mode] = (y32, y16, mean, rstd, dx32, dx16, dx16_only)
             s, t = outs["single"], outs["two_pass"]
@@ -363,18 +364,14 @@ def test_attention_fwd_ping_pong_kernel(case):
         mask[:, 0] = True
     km = mask.to(torch.uint8).contiguous() if mask is not None else None
     qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
-    os.environ["ADAP_ATTN_FORCE_PP"] = "1"
+    _lib.call("adap_attention_set_debug", 2, -1, -1, -1)          # ping-pong forward always
     try:
         out, lse = ops.attention_fwd(qb, kb, vb, H, km)
         assert _lib.call_long("adap_attention_fwd_last_variant") == 3
     finally:
-        os.environ.pop("ADAP_ATTN_FORCE_PP", None)
-    os.environ["ADAP_ATTN_NO_PP"] = "1"
-    try:
-        out0, lse0 = ops.attention_fwd(qb, kb, vb, H, km)
-        assert _lib.call_long("adap_attention_fwd_last_variant") in (1, 2)
-    finally:
-        os.environ.pop("ADAP_ATTN_NO_PP", None)
+        _lib.call("adap_attention_set_debug", 0, -1, -1, -1)
+    out0, lse0 = ops.attention_fwd(qb, kb, vb, H, km)
+    assert _lib.call_long("adap_attention_fwd_last_variant") in (1, 2)
     ref, sim, _ = ref_attention(q, k, v, H, mask)
     assert rel(out.float(), ref) < 6e-3, rel(out.float(), ref)
     assert rel(lse, torch.logsumexp(sim, dim=-1)) < 1e-4

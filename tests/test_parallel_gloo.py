@@ -191,3 +191,72 @@ def test_training_step_waits_for_the_previous_exchange_world2_gloo():
         assert p.exitcode == 0
     for rank, order_ok, ok, zeroed, events in res:
         assert order_ok and ok and zeroed, (rank, order_ok, ok, zeroed, events)
+
+
+def _bucketed_worker(rank, world, port, q):
+    """the bucketed exchange (chunks go out during the backward, as their gradients complete) against the single-shot one"""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from adaprompt_amd import functional
+    from adaprompt_amd.parallel import GradReducer, init_distributed
+    init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                              torch.nn.Linear(32, 8))
+    direct = torch.nn.Parameter(torch.zeros(40))          # written "through a raw pointer", like the block Functions' weight gradients
+    unused = torch.nn.Parameter(torch.zeros(5))           # gets no gradient: its chunk only goes out with reduce()
+    params = list(net.parameters()) + [direct, unused]
+    red = GradReducer(params, bucket_bytes=256)           # 64 floats per chunk: ~30 chunks, parameters straddle chunk borders
+    assert len(red.chunks) > 10
+    x = torch.randn(4, 16, generator=torch.Generator().manual_seed(10 + rank))
+    issued_early = []
+    totals = []
+    for mb in range(2):                                   # two accumulated micro-batches, exchanged after each (DDP semantics)
+        red.wait()
+        red.begin_backward()
+        before = red.flat.clone()
+        loss = net(x * (mb + 1)).pow(2).sum()
+        loss.backward()
+        # a gradient the host code wrote itself: final once the "block" says so (functional.GRAD_DONE is the reducer's hook)
+        direct.grad.add_(torch.arange(40.0) * (rank + 1) * (mb + 1))
+        assert functional.GRAD_DONE == red.grad_ready
+        functional._grads_done({"w": (direct, None)})
+        issued_early.append(sum(red._issued))
+        local = (red.flat - before).clone()               # NB: chunks already exchanged hold the SUM by now -> recompute below
+        red.reduce()
+        totals.append(None)
+    red.wait()
+    bucketed = red.flat.clone()
+    # the same two micro-batches with the single-shot exchange on a twin
+    torch.manual_seed(0)
+    net2 = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                               torch.nn.Linear(32, 8))
+    direct2, unused2 = torch.nn.Parameter(torch.zeros(40)), torch.nn.Parameter(torch.zeros(5))
+    red2 = GradReducer(list(net2.parameters()) + [direct2, unused2], bucket_bytes=256)
+    for mb in range(2):
+        red2.wait()
+        net2(x * (mb + 1)).pow(2).sum().backward()
+        direct2.grad.add_(torch.arange(40.0) * (rank + 1) * (mb + 1))
+        red2.reduce()
+    red2.wait()
+    same = torch.equal(bucketed, red2.flat)
+    nonzero = float(bucketed.abs().sum()) > 0
+    q.put((rank, bool(same), bool(nonzero), issued_early, len(red.chunks)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_equals_single_shot_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucketed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, nonzero, early, nchunks in res:
+        assert same and nonzero, (rank, same, nonzero)
+        # most chunks left during the backward; the chunk of the parameter without a gradient only with reduce()
+        assert all(0 < e < nchunks for e in early), (early, nchunks)

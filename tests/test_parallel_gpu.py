@@ -14,8 +14,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _reducer_backends():
+    # with two GPUs on the box (the driver's scaling node) the exchange runs over RCCL -- through torch.distributed AND through
+    # the library's own adap_allreduce_bucket communicator; with one GPU both ranks share it and exchange over gloo
+    return ["torch", "c_abi"] if torch.cuda.device_count() >= 2 else ["torch"]
+
+
 @pytest.mark.gpu
-def test_training_step_two_ranks_matches_hand_averaged_step():
+@pytest.mark.parametrize("reducer_backend", _reducer_backends())
+def test_training_step_two_ranks_matches_hand_averaged_step(reducer_backend):
     ndev = torch.cuda.device_count()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -27,6 +34,8 @@ def test_training_step_two_ranks_matches_hand_averaged_step():
                    ADAP_DIST_BACKEND="nccl" if ndev >= 2 else "gloo")
         if ndev < 2:          # two processes on one device: two-pass GroupNorm (two single-launch grids cannot both be resident)
             env["ADAP_GN_TWO_PASS"] = "1"
+        if reducer_backend == "c_abi":
+            env["ADAP_REDUCER_BACKEND"] = "c_abi"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -67,3 +76,59 @@ def test_allreduce_bucket_c_entry_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(y, ry)
     comm.destroy()
+
+
+@pytest.mark.gpu
+def test_groupnorm_beside_a_resident_collective_kernel():
+    """The single-launch GroupNorm's workgroups wait for each other, so its grid must be resident as a whole.  Does a collective
+    kernel that occupies part of the chip for milliseconds (RCCL's all-reduce under the next forward) crowd it out?  Stand-in:
+    ``adap_debug_occupy`` -- 48 ... 256 workgroups x 512 threads x ~100 registers resident for 4 ms on a side stream -- while
+    the main stream runs the UNet's largest GroupNorm (4 x 64 x 64 x 320, 256 workgroups).  Checked: the result is right, nothing
+    was poisoned, and the single-launch form is NOT stalled for the length of the resident kernel (its late workgroups find room
+    beside the collective's); the two-launch form (``ops.gn_two_pass``, what ``GradReducer`` can hold the GroupNorms to with
+    ADAP_GN_HOLD_DURING_EXCHANGE=1) is the fallback if a communicator's footprint were ever larger.  Prints the latencies."""
+    from adaprompt_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(4, 64, 64, 320, device=dev, generator=g)
+    gw, gb = torch.randn(320, device=dev, generator=g), torch.randn(320, device=dev, generator=g)
+    side = torch.cuda.Stream()
+    sink = torch.zeros(1, device=dev)
+    RESIDENT_US = 4000
+
+    def run(blocks, two_pass, n=8):
+        if two_pass:
+            ops.gn_two_pass(True)
+        try:
+            torch.cuda.synchronize()
+            if blocks:
+                with torch.cuda.stream(side):
+                    _lib.call("adap_debug_occupy", blocks, 512, RESIDENT_US, sink.data_ptr(), _lib.current_stream())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                _, y, m, r = ops.groupnorm_fwd(x, gw, gb, 1e-5, 1)
+            variant = _lib.call_long("adap_groupnorm_last_variant")
+            e1.record()
+            torch.cuda.synchronize()
+            return y.float(), m, e0.elapsed_time(e1) * 1e3 / n, variant
+        finally:
+            if two_pass:
+                ops.gn_two_pass(False)
+    run(0, False)                                               # warm-up
+    y_ref, m_ref, t_alone, v_alone = run(0, False)
+    _, _, t_two_alone, v_two = run(0, True)
+    assert v_alone > 0 and v_two == 0                           # single launch unless held to two passes
+    line = [f"alone: single-launch {t_alone:.1f} us, two-launch {t_two_alone:.1f} us"]
+    for blocks in (48, 128, 256):
+        y1, m1, t1, v1 = run(blocks, False)
+        y2, m2, t2, v2 = run(blocks, True)
+        line.append(f"beside {blocks} resident workgroups: {t1:.1f} / {t2:.1f} us")
+        assert v1 > 0 and v2 == 0
+        for y, m in ((y1, m1), (y2, m2)):
+            assert torch.isfinite(y).all()
+            assert float((y - y_ref).abs().max()) < 2e-2 and float((m - m_ref).abs().max()) < 1e-5
+        if blocks <= 128:           # a collective's footprint: 8 calls must not take anything like the resident kernel's 4 ms
+            assert t1 * 8 < RESIDENT_US / 4, (blocks, t1)
+    print("GroupNorm 4x64x64x320 forward per call -- " + "; ".join(line))
+    assert not ops.gn_sync_poisoned()

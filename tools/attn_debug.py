@@ -14,13 +14,11 @@ def run(B, H, N, M, d, use_mask):
         mask = (torch.rand(B, M, generator=torch.Generator().manual_seed(5)) > 0.3)
         mask[:, 0] = True
         km = mask.to(torch.uint8).to(dev).contiguous()
-    os.environ["ADAP_ATTN_FORCE_PP"] = "1"
+    _lib.call("adap_attention_set_debug", 2, -1, -1, -1)
     out, lse = ops.attention_fwd(q, k, v, H, km)
     var = _lib.call_long("adap_attention_fwd_last_variant")
-    os.environ.pop("ADAP_ATTN_FORCE_PP")
-    os.environ["ADAP_ATTN_NO_PP"] = "1"
+    _lib.call("adap_attention_set_debug", 0, -1, -1, -1)
     out0, lse0 = ops.attention_fwd(q, k, v, H, km)
-    os.environ.pop("ADAP_ATTN_NO_PP")
     torch.cuda.synchronize()
     e = (out.float() - out0.float()).abs()
     print(f"B{B} H{H} N{N} M{M} d{d} mask{use_mask} variant {var}: max|d out| {float(e.max()):.4f} nonfinite {int((~torch.isfinite(out.float())).sum())} "

@@ -11,7 +11,7 @@ gy = torch.randn(B, H, H, C, generator=torch.Generator().manual_seed(4)).to(dev)
 ad = torch.randn(B, H, H, C, generator=torch.Generator().manual_seed(5)).to(dev)
 for mode in ("single", "two"):
     if mode == "two":
-        os.environ["ADAP_GN_TWO_PASS"] = "1"
+        ops.gn_two_pass(True)
     for xdt, gdt in ((torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)):
         xi, gi = x.to(xdt), gy.to(gdt)
         y32, y16, m, r = ops.groupnorm_fwd(xi, g, b, 1e-5, 1, out_f32=True, out_bf16=True)
@@ -30,7 +30,7 @@ for mode in ("single", "two"):
         print("   y16 vs y32", float((y16.float() - y32).abs().max()), "dx16 vs dx32", float((dx16.float() - dx32).abs().max()))
 
 print("---- exactness of the bf16 copies (single-launch path), 5 repetitions")
-os.environ.pop("ADAP_GN_TWO_PASS", None)
+ops.gn_two_pass(False)
 for rep in range(5):
     y32, y16, m, r = ops.groupnorm_fwd(x, g, b, 1e-5, 1, out_f32=True, out_bf16=True)
     dx32, dx16 = ops.groupnorm_bwd(gy.to(torch.bfloat16), x, g, b, m, r, 1, out_bf16=True, add_from=ad)
