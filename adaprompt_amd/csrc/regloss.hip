@@ -520,3 +520,163 @@ extern "C" int adap_reg_losses(const void* const* tm, void* const* dtm, const in
     hipLaunchKernelGGL(reg_scatter_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, p, (int)elems);
     return adap_check_launch("reg_losses");
 }
+
+// =============================================================================================
+// The static prompt-delta loss of the recon iteration (reference ldm/util.py:2037 calc_prompt_emb_delta_loss with
+// ortho_subtract :280 and calc_ref_cosine_loss :437), value and gradient in one call -- ~45 torch launches otherwise.
+// emb [4 Bs][R = layers x tokens][D]: subject-single, subject-comp, class-single, class-comp blocks.  Per row (b, r):
+//   x = ortho(sc, ss),  ref = ortho(cc, cs),   ortho(a, b) = a - <a,b> / (<b,b> + 1e-6) b
+//   loss_row = 1 - cos(x - mean x, t),  t = (ref - mean ref) |ref - mean ref|;  the reference's gradient scaled by cls_grad_scale
+//   loss = mean_b [ sum_r loss_row w[b, tok(r)] / (sum_r w + 1e-8) ],  w = (m_single + m_comp)^2 / 4 with the start token's mask
+//   zeroed IN the caller's mask tensor, as the reference does
+// =============================================================================================
+struct DeltaParams {
+    const float* emb; float* demb; float* mask;       // mask [4 Bs][T] (the trailing 1 dropped)
+    int Bs, L, T, D;
+    float coef, cls_scale;
+    float* wsum;      // [Bs]
+    float* lossw;     // [Bs * L * T]  loss_row * w
+    float* out;       // [2]: loss, coef * loss
+};
+
+__global__ __launch_bounds__(256) void delta_prep_kernel(DeltaParams p) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s = 0.f;
+    for (int i = t; i < p.T; i += 256) {
+        const float ms = i == 0 ? 0.f : p.mask[(long)b * p.T + i], mc = i == 0 ? 0.f : p.mask[(long)(p.Bs + b) * p.T + i];
+        const float w = fmaxf((ms + mc) * (ms + mc) * 0.25f, 0.f);
+        s += w;
+    }
+    s = reg_block_sum(s, red);
+    if (t == 0) p.wsum[b] = s * p.L;
+}
+
+// after every reader of the old start-token entries is done (the rows kernel treats token 0 as masked by index anyway)
+__global__ void delta_zero_start_kernel(DeltaParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * p.Bs) p.mask[(long)i * p.T] = 0.f;
+}
+
+#define DELTA_EPT 4           // elements per thread: D <= 1024
+__global__ __launch_bounds__(256) void delta_rows_kernel(DeltaParams p) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, t = threadIdx.x;
+    const int R = p.L * p.T, b = row / R, r = row - b * R, tok = r % p.T;
+    const long blk = (long)p.Bs * R * p.D, off = (long)row * p.D;
+    const float* ss = p.emb + off;
+    const float* sc = p.emb + blk + off;
+    const float* cs = p.emb + 2 * blk + off;
+    const float* cc = p.emb + 3 * blk + off;
+    float a[DELTA_EPT], bb[DELTA_EPT], ca[DELTA_EPT], cb[DELTA_EPT];
+    float ab = 0.f, b2 = 0.f, cab = 0.f, cb2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < DELTA_EPT; ++e) {
+        const int i = t + 256 * e;
+        const bool ok = i < p.D;
+        a[e] = ok ? sc[i] : 0.f; bb[e] = ok ? ss[i] : 0.f; ca[e] = ok ? cc[i] : 0.f; cb[e] = ok ? cs[i] : 0.f;
+        ab += a[e] * bb[e]; b2 += bb[e] * bb[e]; cab += ca[e] * cb[e]; cb2 += cb[e] * cb[e];
+    }
+    ab = reg_block_sum(ab, red); b2 = reg_block_sum(b2, red) + 1e-6f;
+    cab = reg_block_sum(cab, red); cb2 = reg_block_sum(cb2, red) + 1e-6f;
+    const float c1 = ab / b2, c2 = cab / cb2;
+    float x[DELTA_EPT], rr[DELTA_EPT];
+    float sx = 0.f, sr = 0.f;
+#pragma unroll
+    for (int e = 0; e < DELTA_EPT; ++e) {
+        x[e] = a[e] - c1 * bb[e];
+        rr[e] = ca[e] - c2 * cb[e];
+        sx += x[e]; sr += rr[e];                       // (lanes beyond D hold zeros)
+    }
+    sx = reg_block_sum(sx, red) / p.D;
+    sr = reg_block_sum(sr, red) / p.D;
+    float P = 0.f, A = 0.f, Bq = 0.f;
+#pragma unroll
+    for (int e = 0; e < DELTA_EPT; ++e) {
+        if (t + 256 * e < p.D) {
+            const float xt = x[e] - sx, rt = rr[e] - sr, tt = rt * fabsf(rt);
+            P += xt * tt; A += xt * xt; Bq += tt * tt;
+        }
+    }
+    P = reg_block_sum(P, red); A = reg_block_sum(A, red) + 1e-12f; Bq = reg_block_sum(Bq, red) + 1e-12f;
+    const float inv = 1.0f / sqrtf(A * Bq), c = P * inv;
+    const float ms = tok == 0 ? 0.f : p.mask[(long)b * p.T + tok], mc = tok == 0 ? 0.f : p.mask[(long)(p.Bs + b) * p.T + tok];
+    const float w = fmaxf((ms + mc) * (ms + mc) * 0.25f, 0.f);
+    if (t == 0) p.lossw[row] = (1.0f - c) * w;
+    // d total / d loss_row, then through the cosine (align: d loss / d cos = -1) to x and ref
+    const float gl = p.coef * w / (p.wsum[b] + 1e-8f) / p.Bs;
+    const float gc = -gl;
+    float gx[DELTA_EPT], gr[DELTA_EPT];
+    float mx = 0.f, mr = 0.f;
+#pragma unroll
+    for (int e = 0; e < DELTA_EPT; ++e) {
+        gx[e] = 0.f; gr[e] = 0.f;
+        if (t + 256 * e < p.D) {
+            const float xt = x[e] - sx, rt = rr[e] - sr, tt = rt * fabsf(rt);
+            gx[e] = (tt - (P / A) * xt) * inv;
+            gr[e] = (xt - (P / Bq) * tt) * inv * 2.0f * fabsf(rt);
+            mx += gx[e]; mr += gr[e];
+        }
+    }
+    mx = reg_block_sum(mx, red) / p.D;
+    mr = reg_block_sum(mr, red) / p.D;
+    float gxb = 0.f, grb = 0.f;
+#pragma unroll
+    for (int e = 0; e < DELTA_EPT; ++e) {
+        if (t + 256 * e < p.D) {
+            gx[e] = gc * (gx[e] - mx);
+            gr[e] = gc * p.cls_scale * (gr[e] - mr);
+        }
+        gxb += gx[e] * bb[e];
+        grb += gr[e] * cb[e];
+    }
+    gxb = reg_block_sum(gxb, red) / b2;          // (g . b) / (<b,b> + eps)
+    grb = reg_block_sum(grb, red) / cb2;
+    // out = a - c b, c = <a,b> / (<b,b> + eps):  dL/da = g - (g.b)/(bb) b ;  dL/db = -c g - (g.b)/(bb) a + 2 c (g.b)/(bb) b
+    float* d_ss = p.demb + off;
+    float* d_sc = p.demb + blk + off;
+    float* d_cs = p.demb + 2 * blk + off;
+    float* d_cc = p.demb + 3 * blk + off;
+#pragma unroll
+    for (int e = 0; e < DELTA_EPT; ++e) {
+        const int i = t + 256 * e;
+        if (i < p.D) {
+            d_sc[i] = gx[e] - gxb * bb[e];
+            d_ss[i] = -c1 * gx[e] - gxb * a[e] + 2.0f * c1 * gxb * bb[e];
+            d_cc[i] = gr[e] - grb * cb[e];
+            d_cs[i] = -c2 * gr[e] - grb * ca[e] + 2.0f * c2 * grb * cb[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void delta_finish_kernel(DeltaParams p) {
+    __shared__ float red[4];
+    const int t = threadIdx.x, R = p.L * p.T;
+    float tot = 0.f;
+    for (int b = 0; b < p.Bs; ++b) {
+        float s = 0.f;
+        for (int i = t; i < R; i += 256) s += p.lossw[(long)b * R + i];
+        s = reg_block_sum(s, red);
+        tot += s / (p.wsum[b] + 1e-8f);
+    }
+    if (t == 0) {
+        p.out[0] = tot / p.Bs;
+        p.out[1] = p.coef * tot / p.Bs;
+    }
+}
+
+extern "C" long adap_prompt_delta_loss_workspace_floats(int Bs, int L, int T) { return reg_align4(Bs) + reg_align4((long)Bs * L * T); }
+
+extern "C" int adap_prompt_delta_loss(const float* emb4, float* demb4, float* mask4, int Bs, int L, int T, int D, float coef,
+                                      float cls_grad_scale, float* out2, float* workspace, void* stream) {
+    ADAP_REQUIRE(emb4 && demb4 && mask4 && out2 && workspace, ADAP_ERR_SHAPE, "prompt_delta_loss: null pointer");
+    ADAP_REQUIRE(Bs >= 1 && L >= 1 && T >= 1 && D >= 1 && D <= 256 * DELTA_EPT, ADAP_ERR_UNSUPPORTED,
+                 "prompt_delta_loss: Bs %d L %d T %d D %d (D <= %d)", Bs, L, T, D, 256 * DELTA_EPT);
+    DeltaParams p = {emb4, demb4, mask4, Bs, L, T, D, coef, cls_grad_scale, workspace, workspace + reg_align4(Bs), out2};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(delta_prep_kernel, dim3(Bs), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(delta_rows_kernel, dim3((unsigned)((long)Bs * L * T)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(delta_finish_kernel, dim3(1), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(delta_zero_start_kernel, dim3((4 * Bs + 63) / 64), dim3(64), 0, s, p);
+    return adap_check_launch("prompt_delta_loss");
+}

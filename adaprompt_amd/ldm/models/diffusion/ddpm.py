@@ -1105,20 +1105,32 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         -> (differentiable scalar or None, {name: float tensor}).  Backward: ``manual_backward``."""
         from ...util import calc_prompt_emb_delta_loss
         total, parts = None, {}
+        fused_roots = ([], [])
+        extra_info.pop("reg_tokmap_grads", None)
         emb4 = extra_info.get("c_static_emb_4b")
         if do_static_prompt_delta_reg and emb4 is not None and self.prompt_emb_delta_reg_weight > 0:
             scale = 0.5 if self.optimizer_type == "Prodigy" else 1.0
             if self.do_zero_shot:
                 scale /= 5
-            l_delta = calc_prompt_emb_delta_loss(emb4, extra_info.get("prompt_emb_mask"))
-            parts["static_prompt_delta"] = l_delta.detach()
-            total = l_delta * (self.prompt_emb_delta_reg_weight * scale)
+            pmask = extra_info.get("prompt_emb_mask")
+            if (FUSED_REG_LOSSES and emb4.is_cuda and emb4.dtype == torch.float32 and emb4.dim() == 4 and emb4.is_contiguous()
+                    and pmask is not None and pmask.dtype == torch.float32 and pmask.is_contiguous() and emb4.shape[-1] <= 1024):
+                # value and gradient in one call of the HIP library (csrc/regloss.hip); the gradient enters autograd at emb4
+                o2, d_emb4 = ops.prompt_delta_loss(emb4, pmask, self.prompt_emb_delta_reg_weight * scale)
+                parts["static_prompt_delta"] = o2[0]
+                total = o2[1]
+                fused_roots = ([emb4], [d_emb4])
+            else:
+                l_delta = calc_prompt_emb_delta_loss(emb4, pmask)
+                parts["static_prompt_delta"] = l_delta.detach()
+                total = l_delta * (self.prompt_emb_delta_reg_weight * scale)
         subj = extra_info.get("subj_indices")
         acts = extra_info.get("ca_layers_activations")
         tm = None
         if acts is not None and acts.get("attnscore_tokmap") and extra_info.get("ca_tokmap_weights") is not None:
             tm = (acts["attnscore_tokmap"], extra_info["ca_tokmap_weights"])
-        extra_info.pop("reg_tokmap_grads", None)
+        if fused_roots[0]:
+            extra_info["reg_tokmap_grads"] = fused_roots
         if tm is not None and subj is not None and FUSED_REG_LOSSES:
             # both attention regularisers, values and gradients, as one call of the HIP library (csrc/regloss.hip): the host
             # expressions below -- the readable form, and what runs on CPU tensors -- cost ~400 small launches per micro-batch
@@ -1127,7 +1139,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             if fused is not None:
                 f_total, f_parts, roots, grads = fused
                 parts.update(f_parts)
-                extra_info["reg_tokmap_grads"] = (roots, grads)          # manual_backward hands them to autograd as roots
+                # manual_backward hands them to autograd as roots
+                extra_info["reg_tokmap_grads"] = (fused_roots[0] + roots, fused_roots[1] + grads)
                 total = f_total if total is None else total + f_total
                 return total, parts
         if do_complementary and subj is not None and acts is not None and acts.get("attnscore") \
@@ -1392,6 +1405,9 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             if reducer is not None:
                 reducer.wait()
             from ...prodigy import Prodigy
+            # sync-free: raises if a single-launch GroupNorm's exchange timed out since the previous optimiser step (its
+            # outputs were NaN then, so the loss already is; this names the cause)
+            ops.gn_poison_poll()
             if isinstance(optimizer, Prodigy):                 # clip fused into the flat-buffer step
                 optimizer.step(clip_norm=self.grad_clip if self.grad_clip else None)
             else:

@@ -815,3 +815,18 @@ def reg_losses(token_maps, complem_w, pairs, fg_mask, inst_w, Bk, have_bg, margi
               int(bool(have_bg)), float(margin), float(margin_bg_at_mf), float(fg_grad_scale), *[float(c) for c in coefs],
               parts.data_ptr(), ws.data_ptr(), nws, _stream())
     return parts, dtm
+
+
+def prompt_delta_loss(emb4, mask4, coef, cls_grad_scale=0.05):
+    """emb4 f32 [4*Bs, L, T, D] (subject-single / subject-comp / class-single / class-comp static embeddings), mask4 f32
+    [4*Bs, T, 1] or [4*Bs, T] (its start-token column is zeroed in place, as the reference does)
+    -> (out f32 [2] = {loss, coef * loss}, d (coef * loss) / d emb4)."""
+    assert emb4.dtype == F32 and emb4.is_cuda and emb4.is_contiguous() and emb4.dim() == 4 and emb4.shape[0] % 4 == 0
+    Bs, L, T, D = emb4.shape[0] // 4, emb4.shape[1], emb4.shape[2], emb4.shape[3]
+    assert mask4.dtype == F32 and mask4.is_contiguous() and mask4.numel() == 4 * Bs * T, mask4.shape
+    demb = torch.empty_like(emb4)
+    out = torch.empty(2, device=emb4.device, dtype=F32)
+    ws = torch.empty(_lib.size_query("adap_prompt_delta_loss_workspace_floats", Bs, L, T), device=emb4.device, dtype=F32)
+    _lib.call("adap_prompt_delta_loss", emb4.data_ptr(), demb.data_ptr(), mask4.data_ptr(), Bs, L, T, D, float(coef),
+              float(cls_grad_scale), out.data_ptr(), ws.data_ptr(), _stream())
+    return out, demb

@@ -400,6 +400,15 @@ int adap_reg_losses(const void* const* tm, void* const* dtm, const int* layer_N,
                     float cx_fg, float cx_bg, float cc_complem, float cc_smb, float cc_bmf, float cc_con,
                     float* parts, float* workspace, long ws_floats, void* stream);
 
+/* The static prompt-delta loss (ldm/util.py:2037 calc_prompt_emb_delta_loss -> ortho_subtract :280, calc_ref_cosine_loss :437),
+ * value and gradient in one call.  emb4 f32 [4*Bs][L][T][D] contiguous: subject-single, subject-comp, class-single, class-comp
+ * static embeddings (L layers, T tokens); mask4 f32 [4*Bs][T]: the prompt mask, whose start-token column is zeroed IN PLACE as
+ * the reference does.  out2 (device) <- {loss, coef * loss}; demb4 (same shape as emb4) <- d (coef * loss) / d emb4, the class
+ * delta's share scaled by cls_grad_scale (0.05).  workspace: adap_prompt_delta_loss_workspace_floats floats. */
+long adap_prompt_delta_loss_workspace_floats(int Bs, int L, int T);
+int adap_prompt_delta_loss(const float* emb4, float* demb4, float* mask4, int Bs, int L, int T, int D, float coef,
+                           float cls_grad_scale, float* out2, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

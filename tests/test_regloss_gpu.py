@@ -106,3 +106,34 @@ def test_fused_regularisers_are_bit_reproducible():
     a = _run(m, maps, scores, w, subj, bg, 2, fg, None, fused=True)
     b = _run(m, maps, scores, w, subj, bg, 2, fg, None, fused=True)
     assert a[0] == b[0] and all(torch.equal(a[2][li], b[2][li]) for li in a[2])
+
+
+@pytest.mark.parametrize("Bs,L,T,D", [(2, 16, 77, 768), (3, 4, 20, 100)])
+def test_fused_prompt_delta_loss_matches_the_host_expression(Bs, L, T, D):
+    """adap_prompt_delta_loss (value + gradient in one call) against ldm/util.py calc_prompt_emb_delta_loss under autograd -- the
+    mirror that tests/test_regs_oracle.py holds to the reference's vectors."""
+    from adaprompt_amd import ops
+    from adaprompt_amd.ldm.util import calc_prompt_emb_delta_loss
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    emb = (torch.randn(4 * Bs, L, T, D, device=dev, generator=g) * 0.7).requires_grad_(True)
+    mask = torch.full((4 * Bs, T, 1), 0.5, device=dev)
+    for blk, n in enumerate((T // 3, T // 2, T // 3, T // 2)):
+        mask[blk * Bs:(blk + 1) * Bs, :n] = 1.0
+    mask[Bs + 1, 3:6] = 0.0
+    coef = 2e-4 * 0.1
+    m_h = mask.clone()
+    loss_h = calc_prompt_emb_delta_loss(emb, m_h)
+    (loss_h * coef).backward()
+    g_h = emb.grad.clone()
+    m_f = mask.clone()
+    out, d_emb = ops.prompt_delta_loss(emb.detach(), m_f, coef)
+    torch.cuda.synchronize()
+    assert torch.equal(m_f, m_h) and float(m_f[:, 0].abs().sum()) == 0          # the reference's in-place start-token zeroing
+    assert abs(float(out[0]) - float(loss_h)) <= 2e-5 * abs(float(loss_h)), (float(out[0]), float(loss_h))
+    assert abs(float(out[1]) - coef * float(loss_h)) <= 2e-5 * coef * abs(float(loss_h))
+    rel = float((d_emb - g_h).norm() / g_h.norm())
+    assert rel < 2e-4, rel
+    for blk in range(4):                    # each of the four blocks on its own (the class blocks carry 0.05 of the gradient)
+        a, b = d_emb[blk * Bs:(blk + 1) * Bs], g_h[blk * Bs:(blk + 1) * Bs]
+        assert float((a - b).norm() / (b.norm() + 1e-20)) < 5e-4, blk
