@@ -51,6 +51,7 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sh) {
     return r;
 }
 
+#define TOK_MAXG 4
 struct AttnParams {
     const uint16_t* q; long ldq;
     const uint16_t* k; long ldk;
@@ -69,6 +70,13 @@ struct AttnParams {
     float scale;
     int qsplit;                 // dK/dV kernel: the query range is cut into qsplit slices (blockIdx.z), f32 partials
     float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
+    // gradient of the cross-attention token maps folded into this backward (adap_attention_bwd_tok): dq += scale * dT . kw,
+    // dk += scale * w . gq, with kw = w^T K and gq = dT^T Q from adap_attention_tokmap_prep
+    const float* tok_dt;        // [B][H][N][G] or null
+    const float* tok_w;         // [B][M][G]
+    const float* tok_kw;        // [B*H][G][d]
+    const float* tok_gq;        // [B*H][G][d]
+    int tok_G;
     // ping-pong forward only
     int prio_mode;              // which phase runs at raised priority: 1 = matrix (default), 2 = vector, 0 = neither
     unsigned long long* stamps; // diagnostic s_memtime stamps (tools/attn_stamps.py) or null
@@ -824,6 +832,15 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
                 if (d0 < d) {
                     float o0 = dQ[vt][4 * g] * p.scale, o1 = dQ[vt][4 * g + 1] * p.scale;
                     float o2 = dQ[vt][4 * g + 2] * p.scale, o3 = dQ[vt][4 * g + 3] * p.scale;
+                    if (p.tok_dt) {
+                        const float* dtr = p.tok_dt + (((size_t)b * p.H + head) * p.N + q) * p.tok_G;
+                        const float* kwp = p.tok_kw + ((size_t)(b * p.H + head) * p.tok_G) * d + d0;
+                        for (int tg = 0; tg < p.tok_G; ++tg) {
+                            const float t = dtr[tg] * p.scale;
+                            const float4 kq = *(const float4*)(kwp + (size_t)tg * d);
+                            o0 += t * kq.x; o1 += t * kq.y; o2 += t * kq.z; o3 += t * kq.w;
+                        }
+                    }
                     size_t off = ((size_t)b * p.N + q) * p.lddq + head * d + d0;
                     if (p.dq32) *(float4*)(p.dq32 + off) = make_float4(o0, o1, o2, o3);
                     if (p.dq16) {
@@ -992,6 +1009,15 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
                             make_float4(dV[vt][4 * g], dV[vt][4 * g + 1], dV[vt][4 * g + 2], dV[vt][4 * g + 3]);
                         continue;
                     }
+                    if (p.tok_dt) {
+                        const float* wr = p.tok_w + ((size_t)b * p.M + key) * p.tok_G;
+                        const float* gqp = p.tok_gq + ((size_t)(b * p.H + head) * p.tok_G) * d + d0;
+                        for (int tg = 0; tg < p.tok_G; ++tg) {
+                            const float t = wr[tg] * p.scale;
+                            const float4 gv = *(const float4*)(gqp + (size_t)tg * d);
+                            k0 += t * gv.x; k1 += t * gv.y; k2 += t * gv.z; k3 += t * gv.w;
+                        }
+                    }
                     if (p.dk32) *(float4*)(p.dk32 + offk) = make_float4(k0, k1, k2, k3);
                     if (p.dk16) {
                         uint2 w;
@@ -1027,6 +1053,16 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnParams p) {
             for (int sp = 0; sp < p.qsplit; ++sp) {
                 float4 v = *(const float4*)(p.part + (((size_t)sp * 2 + which) * rows + row) * C + c);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (which == 0 && p.tok_dt) {
+                const int b = (int)(row / p.M), head = c / p.d, cd = c - head * p.d;
+                const float* wr = p.tok_w + row * p.tok_G;
+                const float* gqp = p.tok_gq + ((size_t)(b * p.H + head) * p.tok_G) * p.d + cd;
+                for (int tg = 0; tg < p.tok_G; ++tg) {
+                    const float t = wr[tg] * p.scale;
+                    const float4 gv = *(const float4*)(gqp + (size_t)tg * p.d);
+                    acc.x += t * gv.x; acc.y += t * gv.y; acc.z += t * gv.z; acc.w += t * gv.w;
+                }
             }
             float* o32 = which ? p.dv32 : p.dk32;
             uint16_t* o16 = which ? p.dv16 : p.dk16;
@@ -1207,13 +1243,16 @@ extern "C" long adap_attention_bwd_workspace_floats(int B, int H, int N, int M, 
     return delta + (qs > 1 ? (long)qs * 2 * B * M * H * d : 0);
 }
 
-extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
-                                  const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
-                                  long lddo, const float* lse, float* workspace,
-                                  float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
-                                  float* dv32, void* dv16, long lddv,
-                                  int B, int H, int N, int M, int d, float scale, void* stream) {
+static int attention_bwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                              const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
+                              long lddo, const float* lse, float* workspace,
+                              float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
+                              float* dv32, void* dv16, long lddv,
+                              int B, int H, int N, int M, int d, float scale,
+                              const float* tok_dt, const float* tok_w, const float* tok_prep, int tok_G, void* stream) {
     ADAP_REQUIRE(q && k && v && out && dout && lse && workspace, ADAP_ERR_SHAPE, "attention_bwd: null pointer");
+    ADAP_REQUIRE(!tok_dt || (tok_w && tok_prep && tok_G >= 1 && tok_G <= TOK_MAXG && d % 4 == 0), ADAP_ERR_SHAPE,
+                 "attention_bwd_tok: token-map arguments");
     float* delta_ws = workspace;
     ADAP_REQUIRE((dq32 || dq16) && (dk32 || dk16) && (dv32 || dv16), ADAP_ERR_SHAPE, "attention_bwd: missing output");
     int rc = attn_common_checks("attention_bwd", B, H, N, M, d, ldq, ldk, ldv);
@@ -1233,7 +1272,35 @@ extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long l
     p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
     p.qsplit = dkv_qsplit(B, H, N, M, d);
     p.part = workspace + (((size_t)B * H * N + 3) & ~(size_t)3);
+    if (tok_dt) {
+        p.tok_dt = tok_dt; p.tok_w = tok_w; p.tok_G = tok_G;
+        p.tok_kw = tok_prep;
+        p.tok_gq = tok_prep + (size_t)B * H * tok_G * d;
+    }
     ATTN_DISPATCH(launch_bwd, p, s);
+}
+
+extern "C" int adap_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                  const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
+                                  long lddo, const float* lse, float* workspace,
+                                  float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
+                                  float* dv32, void* dv16, long lddv,
+                                  int B, int H, int N, int M, int d, float scale, void* stream) {
+    return attention_bwd_impl(q, ldq, k, ldk, v, ldv, key_mask, key_count, out, ldo, dout, lddo, lse, workspace, dq32, dq16, lddq,
+                              dk32, dk16, lddk, dv32, dv16, lddv, B, H, N, M, d, scale, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// adap_attention_bwd with the gradient of the layer's token maps (adap_attention_capture's side output) folded in:
+// d_tokmap f32 [B][H][N][G], tok_w f32 [B][M][G], tok_prep = the workspace adap_attention_tokmap_prep filled for them.
+extern "C" int adap_attention_bwd_tok(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                      const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
+                                      long lddo, const float* lse, float* workspace,
+                                      float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
+                                      float* dv32, void* dv16, long lddv,
+                                      int B, int H, int N, int M, int d, float scale,
+                                      const float* d_tokmap, const float* tok_w, const float* tok_prep, int G, void* stream) {
+    return attention_bwd_impl(q, ldq, k, ldk, v, ldv, key_mask, key_count, out, ldo, dout, lddo, lse, workspace, dq32, dq16, lddq,
+                              dk32, dk16, lddk, dv32, dv16, lddv, B, H, N, M, d, scale, d_tokmap, tok_w, tok_prep, G, stream);
 }
 
 // =============================================================================================
@@ -1490,7 +1557,6 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dk_finish_kernel(const f
 //   dk[m] += scale * sum_g w[m][g]  * gq[g],   gq[g] = sum_n dT[n][g] q[n]           (G vectors per (b, h))
 // gq is a reduction over the queries: 128-row chunks, two stages, fixed order.
 // =============================================================================================
-#define TOK_MAXG 4
 // kw[bh][g][c] = sum_m w[b][m][g] * k[b][m][head*d + c]  -- G*d numbers per (batch, head), one small workgroup each
 __global__ __launch_bounds__(256) void attn_tokmap_kw_kernel(const float* __restrict__ tok_w, const uint16_t* __restrict__ k,
                                                              long ldk, float* __restrict__ kw, int H, int M, int d, int G) {
@@ -1608,6 +1674,46 @@ __global__ __launch_bounds__(64) void attn_tokmap_bwd_dk_kernel(const float* __r
         uint16_t* o = dk + ((size_t)b * M + m) * lddk + head * d + c;
         *o = f32_to_bf16(bf16_to_f32(*o) + scale * v);
     }
+}
+
+// gq[bh][g][c] = sum over the chunks of part[bh][chunk][g][c], fixed order
+__global__ __launch_bounds__(256) void attn_tokmap_gq_reduce_kernel(const float* __restrict__ part, float* __restrict__ gq, int nchunks,
+                                                                   int Gd, long total) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const long bh = i / Gd;
+    const int e = (int)(i - bh * Gd);
+    float a = 0.f;
+    for (int k = 0; k < nchunks; ++k) a += part[(bh * nchunks + k) * Gd + e];
+    gq[i] = a;
+}
+
+// workspace floats of adap_attention_tokmap_prep: kw | gq | the gq chunk partials
+extern "C" long adap_attention_tokmap_prep_workspace_floats(int B, int H, int N, int d, int G) {
+    return (long)B * H * (((N + CAPB_ROWS - 1) / CAPB_ROWS) + 2) * G * d;
+}
+
+// The part of the token maps' backward that needs neither dq nor dk: kw = w^T K [B*H][G][d] (workspace + 0) and
+// gq = dT^T Q [B*H][G][d] (workspace + B*H*G*d).  adap_attention_bwd_tok then adds scale * dT . kw into dq and
+// scale * w . gq into dk inside its own epilogues -- no extra pass over dq / dk.
+extern "C" int adap_attention_tokmap_prep(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k, long ldk,
+                                          float* workspace, int B, int H, int N, int M, int d, int G, void* stream) {
+    ADAP_REQUIRE(d_tokmap && tok_w && q && k && workspace, ADAP_ERR_SHAPE, "attention_tokmap_prep: null pointer");
+    ADAP_REQUIRE(G >= 1 && G <= TOK_MAXG, ADAP_ERR_UNSUPPORTED, "attention_tokmap_prep: G=%d", G);
+    ADAP_REQUIRE(d >= 1 && d <= 160 && d % 8 == 0 && M >= 1, ADAP_ERR_UNSUPPORTED, "attention_tokmap_prep: d=%d M=%d", d, M);
+    ADAP_REQUIRE((long)B * H <= 65535, ADAP_ERR_SHAPE, "attention_tokmap_prep: B*H");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunks = (N + CAPB_ROWS - 1) / CAPB_ROWS;
+    const long bhgd = (long)B * H * G * d;
+    float* kw = workspace;
+    float* gq = workspace + bhgd;
+    float* part = workspace + 2 * bhgd;
+    hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), 0, s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
+    hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), 0, s, d_tokmap, (const uint16_t*)q, ldq, part, B, H,
+                       N, d, G);
+    hipLaunchKernelGGL(attn_tokmap_gq_reduce_kernel, dim3((unsigned)((bhgd + 255) / 256)), dim3(256), 0, s, part, gq, nchunks, G * d,
+                       bhgd);
+    return adap_check_launch("attention_tokmap_prep");
 }
 
 extern "C" long adap_attention_tokmap_bwd_workspace_floats(int B, int H, int N, int d, int G) {

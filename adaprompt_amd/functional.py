@@ -49,6 +49,65 @@ def _op16(t):
     return t if t is None or t.dtype == BF16 else t.to(BF16)
 
 
+# ---------------------------------------------------------------------------------------------
+# The side lane: a second HIP stream per device for the pieces of a transformer block that do not sit on its dependency
+# chain.  At bs = 4 every kernel of the block is latency-bound (a dependent launch costs ~4 us of boundary on top of a
+# 10-50 us kernel that leaves most CUs idle), so work that only depends on the block's INPUTS -- the cross-attention K/V
+# projection of the 77 context tokens, the capture of the distillation side outputs, the context gradient -- runs beside the
+# chain instead of in it.  fork(): the lane waits for everything issued on the main stream so far; join(ev): the main stream
+# waits for the lane's event.  Tensors allocated inside ``with lane:`` belong to the lane's pool: they are only reused by later
+# lane work, which always starts with a fork issued after the free.  ADAP_SIDE_LANE=0 switches it off.
+# ---------------------------------------------------------------------------------------------
+SIDE_LANE = os.environ.get("ADAP_SIDE_LANE", "1") != "0"
+# the token maps' gradient inside the cross-attention backward's epilogues (0: the separate read-modify-write kernels; A/B aid)
+TOKMAP_FOLD = os.environ.get("ADAP_TOKMAP_FOLD", "1") != "0"
+_LANES = {}
+
+
+class _Lane:
+    def __init__(self, device):
+        self.side = torch.cuda.Stream(device=device)
+        self.pending = None             # event of lane work whose join was deferred (the captures of a UNet forward)
+
+    def fork(self):
+        self.side.wait_stream(torch.cuda.current_stream())
+
+    def __enter__(self):
+        self._ctx = torch.cuda.stream(self.side)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self._ctx.__exit__(*a)
+
+    def mark(self):
+        """an event at the lane's current position (call inside ``with lane``)"""
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return ev
+
+
+def side_lane(t):
+    """the device's side lane, or None (CPU tensors, lane switched off, or inside a side stream already)"""
+    if not SIDE_LANE or not t.is_cuda:
+        return None
+    lane = _LANES.get(t.device.index)
+    if lane is None:
+        lane = _LANES[t.device.index] = _Lane(t.device)
+    if ops._stream() == lane.side.cuda_stream:          # (raw handles: torch.cuda.current_stream() costs ~9 us)
+        return None
+    return lane
+
+
+def join_side_lane(device=None):
+    """the main stream waits for lane work whose join was deferred (UNetModel.forward calls this before it hands out the
+    captured activations)."""
+    for idx, lane in _LANES.items():
+        if lane.pending is not None and (device is None or device.index == idx):
+            torch.cuda.current_stream(lane.side.device).wait_event(lane.pending)
+            lane.pending = None
+
+
 class KeyCompaction:
     """a self-attention key mask [B,N] uint8 with its compaction: ``perm`` / ``inv_perm`` [B,N] int32, ``count`` [B] int32
     (attention.KeyMasks.compaction)."""
@@ -279,6 +338,27 @@ class SpatialTransformerFn(torch.autograd.Function):
         B, H, W, C = x.shape
         N = H * W
         same_ctx = ctx_k is ctx_v or (ctx_k.data_ptr() == ctx_v.data_ptr() and ctx_k.shape == ctx_v.shape)
+        # the cross-attention K/V projection reads only the 77 context tokens: on the side lane, under the block's first half
+        lane = side_lane(x)
+        M = ctx_k.shape[1]
+
+        def project_kv():
+            if same_ctx:
+                return ops.linear(ctx_k, P["kv2"].fwd, 2 * C, out_f32=False, out_bf16=True)[1]
+            kv = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
+            _, kk = ops.linear(ctx_k, P["k2"].fwd, C, out_f32=False, out_bf16=True)
+            _, vv = ops.linear(ctx_v, P["v2"].fwd, C, out_f32=False, out_bf16=True)
+            kv[..., :C].copy_(kk)
+            kv[..., C:].copy_(vv)
+            return kv
+        kv2_ready = None
+        if lane is not None:
+            lane.fork()
+            with lane:
+                kv2 = project_kv()
+                kv2_ready = lane.mark()
+        else:
+            kv2 = project_kv()
         gnw, gnb = P["norm"]
         _, xn, gm, gr = ops.groupnorm_fwd(x, gnw, gnb, 1e-6, 0)
         pin = P["proj_in"]
@@ -300,20 +380,21 @@ class SpatialTransformerFn(torch.autograd.Function):
         # --- attn2 (cross) ----------------------------------------------------------------------
         n2, l2m, l2r = ops.layernorm_fwd(t1, *P["norm2"])
         _, q2 = ops.linear(n2, P["q2"].fwd, C, out_f32=False, out_bf16=True)
-        M = ctx_k.shape[1]
-        if same_ctx:
-            _, kv2 = ops.linear(ctx_k, P["kv2"].fwd, 2 * C, out_f32=False, out_bf16=True)
-        else:
-            kv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
-            _, kk = ops.linear(ctx_k, P["k2"].fwd, C, out_f32=False, out_bf16=True)
-            _, vv = ops.linear(ctx_v, P["v2"].fwd, C, out_f32=False, out_bf16=True)
-            kv2[..., :C].copy_(kk)
-            kv2[..., C:].copy_(vv)
+        if kv2_ready is not None:
+            torch.cuda.current_stream().wait_event(kv2_ready)
         k2, v2 = kv2[..., :C], kv2[..., C:]
         o2, lse2 = ops.attention_fwd(q2, k2, v2, heads, None)
         cap = (None, None, None)
         if capture:
-            cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w)        # (+ token maps when tok_w is given)
+            if lane is not None:
+                # the side outputs are read by the losses after the UNet's forward: the capture runs beside the rest of the
+                # block, its join is deferred to UNetModel.forward (join_side_lane)
+                lane.fork()
+                with lane:
+                    cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w)
+                    lane.pending = lane.mark()
+            else:
+                cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w)        # (+ token maps when tok_w is given)
         to2 = P["to_out2"]
         t2, _ = ops.linear(o2, to2.fwd, C, bias=to2.bias, residual=t1)
         # --- GEGLU feed-forward -----------------------------------------------------------------
@@ -355,6 +436,20 @@ class SpatialTransformerFn(torch.autograd.Function):
         N = H * W
         if g is None:                       # only a side output was used downstream
             g = torch.zeros_like(x)
+        # the token maps' gradient: its dq / dk-independent half (kw = w^T K, gq = dT^T Q) runs on the side lane under the
+        # feed-forward's backward; the cross-attention backward then adds the rest inside its epilogues
+        lane = side_lane(x)
+        tok = tok_ready = None
+        if g_tokmap is not None and not F32_STORAGE and TOKMAP_FOLD:
+            C_ = x.shape[-1]
+            g_tokmap = g_tokmap.contiguous()
+            if lane is not None:
+                lane.fork()
+                with lane:
+                    tok = (g_tokmap, ctx.tok_w, ops.attention_tokmap_prep(g_tokmap, ctx.tok_w, q2, kv2[..., :C_], heads))
+                    tok_ready = lane.mark()
+            else:
+                tok = (g_tokmap, ctx.tok_w, ops.attention_tokmap_prep(g_tokmap, ctx.tok_w, q2, kv2[..., :C_], heads))
         gop = _operand(g)            # bf16 copy if the producer left one; g itself (f32) is only the final addend
         if g.dim() == 4 and not g.is_contiguous():          # a channel slice out of a concat gradient: rows ld apart
             ld = g.stride(-2)
@@ -384,8 +479,12 @@ class SpatialTransformerFn(torch.autograd.Function):
         M = kv2.shape[1]
         dq2 = torch.empty(B, N, C, device=x.device, dtype=BF16)
         dkv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
+        if tok_ready is not None:
+            torch.cuda.current_stream().wait_event(tok_ready)
         ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
-                          dv=dkv2[..., C:])
+                          dv=dkv2[..., C:], tok=tok)
+        if tok is not None:
+            g_tokmap = None                     # already in dq2 / dk2
         dq_acc, dk_acc = dq2, dkv2[..., :C]
         side = g_score is not None or g_qs is not None or g_tokmap is not None
         if F32_STORAGE and side:          # the side outputs' gradients go to their own (zeroed) tensors, summed in f32 below
@@ -408,14 +507,27 @@ class SpatialTransformerFn(torch.autograd.Function):
             _dw_norm(T, "norm2", gn2, t1, P["norm2"][0], None, l2m, l2r, 1, 0)
         gt1, gt1h = ops.layernorm_bwd(gn2, t1, P["norm2"][0], l2m, l2r, accumulate_into=gt2, want_bf16=True)
         g_ck = g_cv = None
-        if ctx.same_ctx:
-            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                g_ck, _ = _lin_bwd(dkv2, P["kv2"])                                # dK Wk + dV Wv in one contraction
+        ctx_grad_ready = None
+
+        def context_grads():
+            gk = gv = None
+            if ctx.same_ctx:
+                if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                    gk, _ = _lin_bwd(dkv2, P["kv2"])                              # dK Wk + dV Wv in one contraction
+            else:
+                if ctx.needs_input_grad[1]:
+                    gk, _ = _lin_bwd(dkv2[..., :C], P["k2"])
+                if ctx.needs_input_grad[2]:
+                    gv, _ = _lin_bwd(dkv2[..., C:], P["v2"])
+            return gk, gv
+        if lane is not None:
+            # the context gradient is an output of the block, not an input of anything in it: beside the self-attention backward
+            lane.fork()
+            with lane:
+                g_ck, g_cv = context_grads()
+                ctx_grad_ready = lane.mark()
         else:
-            if ctx.needs_input_grad[1]:
-                g_ck, _ = _lin_bwd(dkv2[..., :C], P["k2"])
-            if ctx.needs_input_grad[2]:
-                g_cv, _ = _lin_bwd(dkv2[..., C:], P["v2"])
+            g_ck, g_cv = context_grads()
         # self attention
         _, go1 = _lin_bwd(gt1h, P["to_out1"], out_f32=False, out_bf16=True)
         dqkv1 = torch.empty(B, N, 3 * C, device=x.device, dtype=BF16)
@@ -447,6 +559,8 @@ class SpatialTransformerFn(torch.autograd.Function):
             _grads_done(T)
         gx, gx16 = ops.groupnorm_bwd(gxn.view(B, H, W, C), x, gnw, gnb, gm, gr, 0, out_bf16=True,
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
+        if ctx_grad_ready is not None:
+            torch.cuda.current_stream().wait_event(ctx_grad_ready)
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None
 
 

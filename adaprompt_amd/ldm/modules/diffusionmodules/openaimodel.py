@@ -415,6 +415,7 @@ class UNetModel(nn.Module):
             if len(module) > 1 and isinstance(module[1], SpatialTransformer):
                 grab(layer_idx, module[1], h)
             layer_idx += 1
+        HF.join_side_lane(h.device)          # the captures of the distillation layers ran beside their blocks
         if extra_info is not None:
             extra_info["ca_layers_activations"] = {
                 key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q")}

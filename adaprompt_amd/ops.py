@@ -419,10 +419,27 @@ def attention_fwd(q, k, v, heads, key_mask=None, scale=None, key_count=None):
     return out, lse
 
 
+def attention_tokmap_prep(d_tokmap, tok_w, q, k, heads):
+    """the dq / dk-independent half of the token maps' backward (kw = w^T K, gq = d_tokmap^T Q) -> the workspace tensor that
+    ``attention_bwd(..., tok=(d_tokmap, tok_w, ws))`` folds into its epilogues.  May run on another stream."""
+    B, N, C = q.shape
+    M = k.shape[1]
+    d = C // heads
+    G = tok_w.shape[2]
+    assert d_tokmap.dtype == F32 and d_tokmap.is_contiguous() and tuple(d_tokmap.shape) == (B, heads, N, G)
+    assert tok_w.dtype == F32 and tok_w.is_contiguous() and tuple(tok_w.shape) == (B, M, G)
+    ws = torch.empty(_lib.size_query("adap_attention_tokmap_prep_workspace_floats", B, heads, N, d, G), device=q.device, dtype=F32)
+    _lib.call("adap_attention_tokmap_prep", d_tokmap.data_ptr(), tok_w.data_ptr(), q.data_ptr(), _rows_ld(q)[1], k.data_ptr(),
+              _rows_ld(k)[1], ws.data_ptr(), B, heads, N, M, d, G, _stream())
+    return ws
+
+
 def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=None, dv=None, out_dtype=BF16, key_count=None,
-                  scale=None):
+                  scale=None, tok=None):
     """dq/dk/dv may be caller-provided pixel-major views (e.g. slices of one fused [B,N,3C] buffer);
-    otherwise fresh tensors of ``out_dtype`` are allocated.  ``scale``: the score scale the forward used (default d^-1/2)."""
+    otherwise fresh tensors of ``out_dtype`` are allocated.  ``scale``: the score scale the forward used (default d^-1/2).
+    ``tok`` = (d_tokmap, tok_w, attention_tokmap_prep's workspace): the token maps' gradient is added into dq / dk inside the
+    kernels' epilogues."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
@@ -436,11 +453,16 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=Non
     def pp(t):
         return (0, t.data_ptr()) if t.dtype == BF16 else (t.data_ptr(), 0)
     (dq32, dq16), (dk32, dk16), (dv32, dv16) = pp(dq), pp(dk), pp(dv)
-    _lib.call("adap_attention_bwd", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
-              _rows_ld(v)[1], _ptr(key_mask), _ptr(key_count), out.data_ptr(), _rows_ld(out)[1], dout.data_ptr(),
-              _rows_ld(dout)[1], lse.data_ptr(), delta.data_ptr(),
-              dq32, dq16, _rows_ld(dq)[1], dk32, dk16, _rows_ld(dk)[1], dv32, dv16, _rows_ld(dv)[1],
-              B, heads, N, M, d, float(d) ** -0.5 if scale is None else float(scale), _stream())
+    args = (q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], v.data_ptr(),
+            _rows_ld(v)[1], _ptr(key_mask), _ptr(key_count), out.data_ptr(), _rows_ld(out)[1], dout.data_ptr(),
+            _rows_ld(dout)[1], lse.data_ptr(), delta.data_ptr(),
+            dq32, dq16, _rows_ld(dq)[1], dk32, dk16, _rows_ld(dk)[1], dv32, dv16, _rows_ld(dv)[1],
+            B, heads, N, M, d, float(d) ** -0.5 if scale is None else float(scale))
+    if tok is None:
+        _lib.call("adap_attention_bwd", *args, _stream())
+    else:
+        d_tokmap, tok_w, prep = tok
+        _lib.call("adap_attention_bwd_tok", *args, d_tokmap.data_ptr(), tok_w.data_ptr(), prep.data_ptr(), tok_w.shape[2], _stream())
     return dq, dk, dv
 
 

@@ -177,6 +177,20 @@ int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, flo
  * (ddpm.py:4323-4339: mean over heads, sum over the subject / background tokens).  Their gradient is applied to the
  * layer's bf16 dq / dk without ever forming the dense [B][H][N][M] gradient.  workspace:
  * adap_attention_tokmap_bwd_workspace_floats(...) floats. */
+/* The same gradient folded into the attention backward itself (no read-modify-write pass over dq / dk): adap_attention_tokmap_prep
+ * forms kw = w^T K and gq = d_tokmap^T Q (workspace: adap_attention_tokmap_prep_workspace_floats floats; it may run on another
+ * stream as soon as d_tokmap is known), adap_attention_bwd_tok = adap_attention_bwd + scale * d_tokmap . kw into dq and
+ * scale * w . gq into dk inside its epilogues. */
+long adap_attention_tokmap_prep_workspace_floats(int B, int H, int N, int d, int G);
+int adap_attention_tokmap_prep(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k, long ldk,
+                               float* workspace, int B, int H, int N, int M, int d, int G, void* stream);
+int adap_attention_bwd_tok(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                           const uint8_t* key_mask, const int* key_count, const void* out, long ldo, const void* dout,
+                           long lddo, const float* lse, float* workspace,
+                           float* dq32, void* dq16, long lddq, float* dk32, void* dk16, long lddk,
+                           float* dv32, void* dv16, long lddv,
+                           int B, int H, int N, int M, int d, float scale,
+                           const float* d_tokmap, const float* tok_w, const float* tok_prep, int G, void* stream);
 long adap_attention_tokmap_bwd_workspace_floats(int B, int H, int N, int d, int G);
 int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k,
                               long ldk, void* dq16, long lddq, void* dk16, long lddk, float* workspace, int B, int H,

@@ -616,6 +616,41 @@ def test_attention_token_maps_fwd_bwd(B, N, M, d, G):
     assert torch.equal(dq_b, dq) and torch.equal(dk_b, dk)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M,d,G", [(2, 256, 77, 160, 2), (1, 1024, 77, 80, 1), (2, 4096, 77, 40, 2), (1, 100, 154, 40, 3),
+                                       (2, 200, 200, 40, 2)])
+def test_attention_bwd_with_the_token_map_gradient_folded_in(B, N, M, d, G):
+    """adap_attention_bwd_tok (the token maps' gradient added inside the dQ / dK epilogues, kw and gq from
+    adap_attention_tokmap_prep) against adap_attention_bwd followed by the read-modify-write adap_attention_tokmap_bwd: the same
+    dq / dk up to the one bf16 rounding the folded form saves; dv untouched.  (M = 200: the dK/dV kernel's direct epilogue, M = 77 /
+    154: its query-split reduce.)"""
+    H = 8
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(91)
+    q, k, v = (torch.randn(B, n, H * d, generator=g).bfloat16().to(dev) for n in (N, M, M))
+    go = torch.randn(B, N, H * d, generator=g).bfloat16().to(dev)
+    w = ((torch.rand(B, M, G, generator=g) < 0.2).float() * torch.randint(1, 3, (B, M, G), generator=g).float()).to(dev)
+    dt = (torch.randn(B, H, N, G, generator=g) * 0.3).to(dev)
+    out, lse = ops.attention_fwd(q, k, v, H, None)
+    dq0, dk0, dv0 = ops.attention_bwd(q, k, v, out, go, lse, H)
+    dq_ref, dk_ref = dq0.clone(), dk0.clone()
+    ops.attention_tokmap_bwd(dt, w, q, k, dq_ref, dk_ref, H)
+    prep = ops.attention_tokmap_prep(dt, w, q, k, H)
+    dq1, dk1, dv1 = ops.attention_bwd(q, k, v, out, go, lse, H, tok=(dt, w, prep))
+    torch.cuda.synchronize()
+    assert torch.equal(dv1, dv0)
+    assert float((dq_ref.float() - dq0.float()).abs().max()) > 0           # the token maps do contribute
+    assert rel(dq1.float(), dq_ref.float()) < 4e-3 and rel(dk1.float(), dk_ref.float()) < 4e-3
+    # and against fp64: dq0/dk0 (bf16) + the dense formulation
+    qh = q.double().view(B, N, H, d).permute(0, 2, 1, 3).cpu()
+    kh = k.double().view(B, M, H, d).permute(0, 2, 1, 3).cpu()
+    ds = dt.double().cpu() @ w.double().cpu()[:, None].transpose(2, 3)
+    sc = d ** -0.5
+    dq64 = dq0.double().cpu() + (sc * ds @ kh).permute(0, 2, 1, 3).reshape(B, N, H * d)
+    dk64 = dk0.double().cpu() + (sc * ds.transpose(2, 3) @ qh).permute(0, 2, 1, 3).reshape(B, M, H * d)
+    assert rel(dq1.float().cpu(), dq64.float()) < 4e-3 and rel(dk1.float().cpu(), dk64.float()) < 4e-3
+
+
 @pytest.mark.parametrize("expo", [2, 3, 1])
 @pytest.mark.parametrize("R,D,demean,align,rgs", [(8, 4096, True, True, 1.0), (5, 64, True, True, 0.05), (3, 1024, False, False, 1.0),
                                                   (700, 768, True, True, 0.05), (4, 256, True, True, 0.0)])
