@@ -334,7 +334,7 @@ class ResBlockFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None):
+    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None, tokmap_only=False):
         B, H, W, C = x.shape
         N = H * W
         same_ctx = ctx_k is ctx_v or (ctx_k.data_ptr() == ctx_v.data_ptr() and ctx_k.shape == ctx_v.shape)
@@ -385,16 +385,23 @@ class SpatialTransformerFn(torch.autograd.Function):
         k2, v2 = kv2[..., :C], kv2[..., C:]
         o2, lse2 = ops.attention_fwd(q2, k2, v2, heads, None)
         cap = (None, None, None)
+        dense = not (tokmap_only and tok_w is not None)
         if capture:
             if lane is not None:
                 # the side outputs are read by the losses after the UNet's forward: the capture runs beside the rest of the
                 # block, its join is deferred to UNetModel.forward (join_side_lane)
                 lane.fork()
                 with lane:
-                    cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w)
+                    cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w, dense=dense)
                     lane.pending = lane.mark()
             else:
-                cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w)        # (+ token maps when tok_w is given)
+                cap = ops.attention_capture(q2, k2, heads, tok_w=tok_w, dense=dense)   # (+ token maps when tok_w is given)
+            if not dense:
+                # shape-only stand-ins for the dense side outputs (the fused regularisers read the token maps; the host
+                # expressions, given token maps, read only the shapes): one element each, expanded
+                M2 = k2.shape[1]
+                stub = x.new_empty(1)
+                cap = (stub.expand(B, heads, N, M2), stub.expand(B, heads, N, M2), stub.expand(B, heads, N, C // heads), cap[3])
         to2 = P["to_out2"]
         t2, _ = ops.linear(o2, to2.fwd, C, bias=to2.bias, residual=t1)
         # --- GEGLU feed-forward -----------------------------------------------------------------
@@ -422,7 +429,10 @@ class SpatialTransformerFn(torch.autograd.Function):
             # attnscore with gradient, ddpm.py:3246-3270); the probabilities are a monitoring output only.
             # Unused side outputs must cost nothing in backward: their gradients arrive as None, not as zeros.
             ctx.set_materialize_grads(False)
-            ctx.mark_non_differentiable(cap[1])
+            if dense:
+                ctx.mark_non_differentiable(cap[1])
+            else:
+                ctx.mark_non_differentiable(cap[0], cap[1], cap[2])
             return (out,) + tuple(cap)
         return out
 
@@ -561,7 +571,7 @@ class SpatialTransformerFn(torch.autograd.Function):
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
         if ctx_grad_ready is not None:
             torch.cuda.current_stream().wait_event(ctx_grad_ready)
-        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None
+        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

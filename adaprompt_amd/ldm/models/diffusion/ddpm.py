@@ -35,6 +35,11 @@ from .conditioning import ConditioningMixin
 FUSED_REG_LOSSES = os.environ.get("ADAP_FUSED_REG", "1") != "0"
 
 
+# in a recon iteration whose regularisers are fused, the capture kernel forms the token maps only (the dense attnscore / attn /
+# q tensors, 86 MB per 64 x 64 layer at bs 4, are never read); ADAP_CAPTURE_DENSE=1 keeps writing them
+CAPTURE_TOKEN_MAPS_ONLY = os.environ.get("ADAP_CAPTURE_DENSE", "0") != "1"
+
+
 def set_fused_reg_losses(on):
     global FUSED_REG_LOSSES
     FUSED_REG_LOSSES = bool(on)
@@ -1076,6 +1081,9 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         c_emb, c_in, extra_info = cond
         extra_info = dict(extra_info)
         extra_info["img_mask"] = img_mask                                  # ddpm.py:2876
+        if FUSED_REG_LOSSES and CAPTURE_TOKEN_MAPS_ONLY and extra_info.get("subj_indices") is not None:
+            # the regularisers of this iteration read the distillation layers through their token maps (recon_regularizers)
+            extra_info["capture_token_maps_only"] = True
         model_output, x_noisy = self.guided_denoise(x_start, noise, t, (c_emb, c_in, extra_info))
         loss, grad = self.calc_recon_loss(model_output, noise, img_mask, fg_mask, 1.0, self.bg_pixel_weight)
         aux = {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
@@ -1362,7 +1370,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         (ddpm.py:516-572, 1839-1859) -- ``max_steps``, ``composition_regs_iter_gap``, ``arc2face_distill_iter_prob``,
         ``max_num_denoising_steps`` -- then ``training_percent`` is updated and the iteration type is DRAWN as in the
         reference: an Arc2Face-distillation iteration (with its number of denoising steps), else a plain recon
-        iteration with timestep annealing.  Compositional iterations (stage 2) are not built and raise."""
+        iteration with timestep annealing; with the yaml's own conditioning side attached (``embedding_manager``) the
+        compositional iteration of stage 2 runs through ``shared_step`` -> ``compos_distill_step`` (ldm/stage2.py)."""
         tr = getattr(self, "trainer", None)
         if optimizer is None and tr is not None and batch_idx is not None:
             optimizer, scheduler, reducer = tr.optimizer, tr.scheduler, tr.reducer

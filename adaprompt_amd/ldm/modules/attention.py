@@ -182,7 +182,7 @@ class SpatialTransformer(nn.Module):
         if tok_w is not None and (tok_w.shape[0] != B or tok_w.shape[1] != k_ctx.shape[1]):
             tok_w = None
         res = HF.SpatialTransformerFn.apply(x.contiguous(), k_ctx, v_ctx, self._packs(same), self.n_heads, key_mask, capture,
-                                            tok_w)
+                                            tok_w, bool(getattr(blk.attn2, "tokmap_only", False)))
         if capture:
             out, score, prob, qs = res[:4]
             blk.attn2.cached_activations = {"q": qs, "attn": prob, "attnscore": score}

@@ -365,9 +365,13 @@ class UNetModel(nn.Module):
             idx_groups = [ei["subj_indices"]] + ([ei["bg_indices"]] if ei.get("bg_indices") is not None else [])
             ntok = context.shape[1] // (2 if iter_type == "mix_hijk" else 1)
             tok_w = token_weight_matrix(idx_groups, x.shape[0], ntok)
+        # ``capture_token_maps_only``: the caller will read the distillation layers through their token maps alone (the
+        # recon iteration's fused regularisers): the dense attnscore / attn / q side outputs are then shape-only stand-ins
+        tm_only = bool(ei.get("capture_token_maps_only")) and tok_w is not None
         for m_ in self.modules():
             if isinstance(m_, SpatialTransformer):
                 m_.transformer_blocks[0].attn2.token_weights = tok_w
+                m_.transformer_blocks[0].attn2.tokmap_only = tm_only
 
         t_emb = timestep_embedding(timesteps, self.model_channels)
         te = self.time_embed

@@ -466,23 +466,26 @@ def attention_bwd(q, k, v, out, dout, lse, heads, key_mask=None, dq=None, dk=Non
     return dq, dk, dv
 
 
-def attention_capture(q, k, heads, want_q=True, tok_w=None):
+def attention_capture(q, k, heads, want_q=True, tok_w=None, dense=True):
     """side outputs of attention.py:245-255 -> (attnscore, attn, q_scaled[, tokmap]).  ``tok_w`` f32 [B, M, G]: also
-    the per-head token maps [B, heads, N, G] = attnscore . tok_w (what the cross-layer consistency loss reads)."""
+    the per-head token maps [B, heads, N, G] = attnscore . tok_w (what the cross-layer consistency loss reads).
+    ``dense=False`` (needs ``tok_w``): only the token maps are formed -- the three dense tensors (86 MB per 64 x 64 layer
+    at bs 4) are neither computed to memory nor returned (None)."""
     B, N, C = q.shape
     M = k.shape[1]
     d = C // heads
     dev = q.device
-    score = torch.empty(B, heads, N, M, device=dev, dtype=F32)
-    prob = torch.empty(B, heads, N, M, device=dev, dtype=F32)
-    qs = torch.empty(B, heads, N, d, device=dev, dtype=F32) if want_q else None
+    assert dense or tok_w is not None
+    score = torch.empty(B, heads, N, M, device=dev, dtype=F32) if dense else None
+    prob = torch.empty(B, heads, N, M, device=dev, dtype=F32) if dense else None
+    qs = torch.empty(B, heads, N, d, device=dev, dtype=F32) if (want_q and dense) else None
     tokmap, G = None, 0
     if tok_w is not None:
         assert tok_w.dtype == F32 and tok_w.is_contiguous() and tok_w.shape[:2] == (B, M) and tok_w.shape[2] <= 4, tok_w.shape
         G = tok_w.shape[2]
         tokmap = torch.empty(B, heads, N, G, device=dev, dtype=F32)
-    _lib.call("adap_attention_capture", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], score.data_ptr(),
-              prob.data_ptr(), _ptr(qs), _ptr(tok_w), _ptr(tokmap), G, B, heads, N, M, d, float(d) ** -0.5, _stream())
+    _lib.call("adap_attention_capture", q.data_ptr(), _rows_ld(q)[1], k.data_ptr(), _rows_ld(k)[1], _ptr(score),
+              _ptr(prob), _ptr(qs), _ptr(tok_w), _ptr(tokmap), G, B, heads, N, M, d, float(d) ** -0.5, _stream())
     return (score, prob, qs) if tok_w is None else (score, prob, qs, tokmap)
 
 
@@ -813,12 +816,12 @@ def reg_losses(token_maps, complem_w, pairs, fg_mask, inst_w, Bk, have_bg, margi
         pw = (ctypes.c_float * max(n, 1))(*[float(w) for _, _, w in pairs])
         nws = _lib.call_long("adap_reg_losses_workspace_floats", ln, L, px, pr, n, int(Bk), int(H), int(G))
         assert nws > 0, "adap_reg_losses_workspace_floats: unsupported configuration"
-        offs, o = [], 0
-        for t in token_maps:
-            offs.append(o)
-            o += t.numel()
-        tab = _REG_TABLES[key] = (ln, cw, px, pr, pw, n, int(nws), offs, o)
-    ln, cw, px, pr, pw, n, nws, offs, total = tab
+        tab = _REG_TABLES[key] = (ln, cw, px, pr, pw, n, int(nws))
+    ln, cw, px, pr, pw, n, nws = tab
+    offs, total = [], 0                 # (not part of the cached tables: the maps' batch size Bt is not in their key)
+    for t in token_maps:
+        offs.append(total)
+        total += t.numel()
     dev = token_maps[0].device
     dflat = torch.empty(total, device=dev, dtype=F32)
     dtm = [dflat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, token_maps)]

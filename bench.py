@@ -165,6 +165,7 @@ def main():
                          "45.1 vs 44.3 ms/step on MI355X -- the step is GPU-bound, not launch-bound, so eager is the default")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-batch", type=int, default=1, help="batch of the cpu_baseline sample (BASELINE.md section 3 unit: 4)")
+    ap.add_argument("--no-cpu-k8", action="store_true", help="skip the second, 8-thread cpu_baseline sample")
     ap.add_argument("--no-ddim", action="store_true",
                     help="skip the extra leg that times config 5 (50-step DDIM at bs=8 with guidance + VAE decode)")
     ap.add_argument("--no-clock-probe", action="store_true",
@@ -671,6 +672,13 @@ def main():
         del ld, hook, reducer, opt, sched
         torch.cuda.empty_cache()
         cpu = cpu_baseline(threads, batch=args.cpu_batch)
+        if threads > 8 and not args.no_cpu_k8:
+            # the survey container's figure (0.048 img/s for the reference's modules) was taken on 8
+            # cores: one more bounded sample on 8 threads for comparability (1 warm-up + 1 timed, ~25 s)
+            k8 = cpu_baseline(8, batch=1, timed=1)
+            cpu["k8_threads_sample"] = {"value": k8["value"], "unit": k8["unit"], "cores": 8,
+                                        "seconds_per_micro_batch": k8["seconds_per_micro_batch"],
+                                        "achieved_gflops": k8["achieved_gflops"], "sample": "bs=1, 1 warm-up + 1 timed"}
 
     if rank == 0:
         imgs = world * B * args.steps
