@@ -45,13 +45,20 @@ def test_decoder_absent_fails_loudly():
         vae.decode(torch.zeros(1, 4, 8, 8, device=dev()))
 
 
-def test_ddim_sampler_vs_oracle_and_decode_first_stage():
+@pytest.mark.parametrize("size,B", [("narrow", 2), ("sd15", 1)])
+def test_ddim_sampler_vs_oracle_and_decode_first_stage(size, B):
+    """4 guided DDIM steps + VAE decode against the oracle loop (itself pinned by the reference's own DDIMSampler,
+    tests/test_ddim_golden.py) with the fp32 UNet / decoder restatements: at narrow widths and at the FULL SD-1.5 sizes (859.5 M
+    UNet, 49.5 M decoder; one image, ~40 s of CPU oracle)."""
     from adaprompt_amd.ldm.models.diffusion.ddim import DDIMSampler
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from oracle import ddim_oracle as DO
     from oracle import ldm_oracle as O
-    ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
-    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
+    if size == "narrow":
+        ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+        vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
+    else:
+        ucfg, vdd = dict(synth.SD15_UNET), dict(synth.SD15_VAE_DD)
     ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL",
                           "params": {"ddconfig": vdd, "embed_dim": 4, "with_decoder": True}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
@@ -60,7 +67,7 @@ def test_ddim_sampler_vs_oracle_and_decode_first_stage():
     missing, unexpected = ld.load_state_dict({**usd, **vsd}, strict=False)
     assert not unexpected
     ld = ld.to(dev()).eval()
-    B, S = 2, 4
+    S = 4
     x_T = synth.synthetic_input("ddim.xT", (B, 4, 64, 64))
     ctx = synth.synthetic_input("ddim.ctx", (16 * B, 77, ucfg["context_dim"]))
     uctx = synth.synthetic_input("ddim.uctx", (16 * B, 77, ucfg["context_dim"]))
@@ -85,7 +92,7 @@ def test_ddim_sampler_vs_oracle_and_decode_first_stage():
     e = rel_err(z.cpu(), z_ref)
     img = ld.decode_first_stage(z)
     ei = rel_err(img.float().cpu(), img_ref)
-    print(f"[ddim] latent rel L2 after {S} guided steps {e:.3e}; decoded image rel L2 {ei:.3e}")
+    print(f"[ddim {size}] latent rel L2 after {S} guided steps {e:.3e}; decoded image rel L2 {ei:.3e}")
     assert e < DDIM_TOL
     assert img.shape == (B, 3, 512, 512) and ei < 2 * DDIM_TOL
     with pytest.raises(ValueError):

@@ -12,7 +12,8 @@ from conftest import load_golden, rel_err, ellipse_mask, border_mask, subsample_
 
 pytestmark = pytest.mark.gpu
 
-EPS_TOL = 2.5e-2       # relative L2 of eps-hat (bf16 operands through ~60 contractions)
+EPS_TOL = 1.5e-2       # relative L2 of eps-hat (bf16 operands through ~60 contractions): measured 8.7e-3 full size, 9.2e-3 narrow
+GRAD_CTX_TOL = 2.5e-2  # d loss / d context: measured 1.42e-2 full size, 1.69e-2 narrow (tests/test_precision_gpu.py holds 2e-2)
 LOSS_TOL = 1e-3        # north_star: eps-pred MSE, relative
 
 
@@ -79,7 +80,7 @@ def run_unet_case(cfg, tag, g, with_grad, subs_grad=False):
         got = gr[:, ::4, ::8] if subs_grad else gr
         eg = rel_err(got, ref)
         print(f"[{tag}] grad_context rel L2 {eg:.3e}  norm hip {float(gr.norm()):.5f} ref {float(g['grad_context_norm']):.5f}")
-        assert eg < 5e-2
+        assert eg < GRAD_CTX_TOL
         assert abs(float(gr.norm()) / float(g["grad_context_norm"]) - 1) < 2e-2
 
 
@@ -143,7 +144,7 @@ def test_unet_narrow_weight_gradients_vs_oracle():
     print(f"[unet weight grads] context gradient vs oracle: training run {e_tr:.2e}, frozen run {e_fr:.2e}, "
           f"between them {rel_err(gctx.cpu(), gctx_frozen.cpu()):.2e}")
     assert e_tr < 1.25 * e_fr + 1e-3
-    assert rel_err(gctx.cpu(), ctx_ref.grad) < 5e-2
+    assert rel_err(gctx.cpu(), ctx_ref.grad) < GRAD_CTX_TOL
     num = den = 0.0
     worst = (0.0, None)
     n = 0
@@ -280,7 +281,7 @@ def test_training_step_matches_oracle():
     eps_hip.backward(grad)
     print(f"[step] loss hip {float(loss_hip):.6f} ref {float(loss_ref):.6f}  grad rel {rel_err(ctx_hip.grad.cpu(), g_ref):.3e}")
     assert abs(float(loss_hip) - float(loss_ref)) / float(loss_ref) < LOSS_TOL
-    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
+    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 2e-2                      # measured 9.1e-3
 
 
 def test_recon_step_with_regularizers_matches_oracle():
@@ -362,7 +363,7 @@ def test_recon_step_with_regularizers_matches_oracle():
     reg_share = float((e_ref.grad - e_ref2.grad).norm() / e_ref.grad.norm())
     print(f"[recon+regs] d loss / d embeddings rel {ge:.3e}; the regularisers carry {reg_share:.2f} of its norm")
     assert reg_share > 0.3          # otherwise this test would not see them
-    assert ge < 5e-2
+    assert ge < GRAD_CTX_TOL        # measured 1.37e-2
 
 
 def test_probably_anneal_t_device_path_has_the_reference_distribution():
@@ -569,7 +570,7 @@ def test_arc2face_distill_step_vs_oracle():
           f"grad rel {rel_err(ctx_hip.grad.cpu(), g_ref):.3e}")
     assert abs(float(loss) - lr_) / lr_ < DISTILL_LOSS_TOL
     assert abs(lr_seq - lr_) / lr_ < DISTILL_LOSS_TOL              # the one-by-one path against the oracle too
-    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 5e-2
+    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 1.5e-2                    # measured 6.2e-3
 
 
 def test_guided_denoise_cfg_pixel_recon_vs_oracle():

@@ -19,7 +19,10 @@ from adaprompt_amd import synth          # noqa: E402
 from conftest import rel_err          # noqa: E402
 
 
-X0_TOL, PART_TOL, GRAD_TOL = 0.25, 4e-2, 0.2
+# measured (round 2/3): x_start_cache 0.19, every loss part <= 2.2e-2, the gradient into the subject vectors 2.0e-2.  The cached
+# x0 is the guided eps divided by sqrt(alpha_bar_t) ~ 0.07 at t ~ 900: an eps error of 9e-3 (the UNet gate) times the guidance
+# scale becomes ~0.2 of it by construction, hence its own, loose gate; the other two sit at <= 2x what is measured
+X0_TOL, PART_TOL, GRAD_TOL = 0.25, 4e-2, 4e-2
 VEC_SCALE = 1.0
 
 
@@ -55,23 +58,30 @@ def _score_fn(prompts, images):
 
 
 @pytest.mark.gpu
-def test_compositional_micro_batch_vs_oracle():
+@pytest.mark.parametrize("size,B", [("narrow", 3), ("sd15", 1)])
+def test_compositional_micro_batch_vs_oracle(size, B):
+    """``narrow``: BASELINE config 4's bs = 3 at model_channels 64.  ``sd15``: the same micro-batch at the FULL SD-1.5 sizes
+    (859.5 M UNet, 768-wide context, full VAE decoder) with one instance -- 4 prompt types with gradient, a teacher-filter pass
+    of UNet batch 8 -- so that the fp32 oracle's autograd fits a test box (~2 min of CPU)."""
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from oracle import ldm_oracle as O
     dev = torch.device("cuda:0")
-    ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
-    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
+    if size == "narrow":
+        ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+        vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=512)
+    else:
+        ucfg, vdd = dict(synth.SD15_UNET), dict(synth.SD15_VAE_DD)
+    cdim = ucfg["context_dim"]
     usd = synth.synthetic_unet_state_dict(ucfg)
     vsd = synth.synthetic_vae_state_dict(vdd, decoder=True)
-    B = 3
     x0 = synth.synthetic_input("s2.x0", (B, 4, 64, 64))
     noise = synth.synthetic_input("s2.noise", (B, 4, 64, 64))
     fresh = synth.synthetic_input("s2.fresh", (B, 4, 64, 64))
-    t = torch.tensor([931, 872, 990])
+    t = torch.tensor([931, 872, 990][:B])
 
     def run(device, oracle):
         torch.manual_seed(0)
-        ld = LatentDiffusion(**_params(ucfg, vdd, 128))
+        ld = LatentDiffusion(**_params(ucfg, vdd, cdim))
         missing, unexpected = ld.load_state_dict({**usd, **vsd}, strict=False)
         assert not unexpected
         ld = ld.to(device)
@@ -110,7 +120,7 @@ def test_compositional_micro_batch_vs_oracle():
     for k in po:
         if k != "best_cand_idx":
             report[k] = abs(ph[k] - po[k]) / (abs(po[k]) + 1e-12)
-    print("stage-2 micro-batch, HIP vs oracle (relative):", {k: round(v, 5) for k, v in report.items()})
+    print(f"stage-2 micro-batch [{size}], HIP vs oracle (relative):", {k: round(v, 5) for k, v in report.items()})
     # the x0 prediction cached for the reuse iteration: guided noise prediction (scale ~3) of the selected candidate, divided by
     # sqrt(alphas_cumprod[t]) ~ 0.07 at t ~ 900 -- the bf16 path's ~1 % noise-prediction error is amplified ~10x
     assert report["x_start_cache"] < X0_TOL
