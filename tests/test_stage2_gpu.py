@@ -130,7 +130,11 @@ def test_compositional_micro_batch_vs_oracle(size, B):
         if k not in ("best_cand_idx", "loss_clip_subj_comp", "loss_clip_cls_comp"):
             # feat_delta_align is a difference of differences of nearly equal features: bf16 operands leave a floor of
             # ~(2^-9 |feat|)^2 ~ 2e-5 under it, whatever its value
-            assert abs(ph[k] - po[k]) < PART_TOL * abs(po[k]) + (4e-5 if k == "feat_delta_align" else 2e-6), (k, ph[k], po[k])
+            # comp_single_map_align (~4e-4) sums what is left after a HARD elastic matching of query positions: a handful of
+            # matches flip with the bf16 noise -- and from run to run with the summation order of the torch / rocBLAS products
+            # in that loss (measured over 5 runs: 1.3e-2 ... 5.8e-2 of it) -- so it gets an absolute floor as well
+            floor = {"feat_delta_align": 4e-5, "comp_single_map_align": 3e-5}.get(k, 2e-6)
+            assert abs(ph[k] - po[k]) < PART_TOL * abs(po[k]) + floor, (k, ph[k], po[k])
     assert report["loss"] < PART_TOL
     assert float(go["z"].norm()) > 0
     assert report["grad_z"] < GRAD_TOL, report
