@@ -68,6 +68,9 @@ struct AttnParams {
     float* dv32; uint16_t* dv16; long lddv;
     int B, H, N, M, d;
     float scale;
+    int pre;                    // q already carries scale * log2(e) (folded into the projection's weight pack): the scores come out
+                                // of the matrix core in the exp2 domain and, with the reference point / -lse as the accumulator's
+                                // initial value, go into v_exp_f32 as they are -- one VALU instruction per score less
     int qsplit;                 // dK/dV kernel: the query range is cut into qsplit slices (blockIdx.z), f32 partials
     float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
     // gradient of the cross-attention token maps folded into this backward (adap_attention_bwd_tok): dq += scale * dT . kw,
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
     const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
+    const bool pre = p.pre != 0;          // wave-uniform
 
     // Q fragments stay exactly the caller's bf16 values: scale*log2(e) is applied in f32 inside the exponent's fma
     // (pre-multiplying Q would round q*cs to bf16 again and cost ~2e-4 of LSE accuracy for ~1% of a step)
@@ -260,12 +264,15 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
             tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, Mb - key1));
         }
         f32x16 S[QB][2];
+        float sinit[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sinit[qb] = (pre && m[qb] != -INFINITY) ? -m[qb] : 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[qb][t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) S[qb][t][r] = sinit[qb];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
@@ -297,22 +304,46 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
             // running reference point in the exp2 domain (cs > 0): raised only when a row's max outgrows it by more than
             // 2^MAX_SLACK (or it is still -inf) -- p <= 2^MAX_SLACK keeps its full f32 / bf16 relative precision, and the O
             // rescale below (64 multiplies) then runs on a handful of tiles instead of on every second one
-            const float mcand = mx * cs;
-            const bool grow = mcand > m[qb] + MAX_SLACK;
-            if (__any(grow)) {                          // wave-uniform
-                const float mnew = grow ? mcand : m[qb];
-                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);      // 1 for the rows that keep their reference
+            if (pre) {
+                // S is already in the exp2 domain and relative to the reference point m (absolute while m is still -inf)
+                const bool first = m[qb] == -INFINITY;
+                const bool grow = first ? (mx > -INFINITY) : (mx > MAX_SLACK);
+                if (__any(grow)) {                      // wave-uniform, rare: the reference moves up by `shift`
+                    const float shift = grow ? mx : 0.f;
+                    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
-                for (int vt = 0; vt < VT; ++vt)
+                    for (int vt = 0; vt < VT; ++vt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
-                l[qb] *= alpha;
-                m[qb] = mnew;
+                        for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
+                    l[qb] *= alpha;
+                    if (grow) m[qb] = first ? mx : m[qb] + shift;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[qb][t][r] -= shift;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(S[qb][t][r]);
+            } else {
+                const float mcand = mx * cs;
+                const bool grow = mcand > m[qb] + MAX_SLACK;
+                if (__any(grow)) {                          // wave-uniform
+                    const float mnew = grow ? mcand : m[qb];
+                    const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);      // 1 for the rows that keep their reference
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
+                    l[qb] *= alpha;
+                    m[qb] = mnew;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(fmaf(S[qb][t][r], cs, -m[qb]));
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(fmaf(S[qb][t][r], cs, -m[qb]));
             if (!ones_col) {
                 float psum = 0.f;
 #pragma unroll
@@ -710,6 +741,7 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const int q = blockIdx.x * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
+    const bool pre = p.pre != 0;          // wave-uniform
 
     // -delta rides in as the dP accumulator's initial value (exact in f32), so dS = P * dP' needs no subtraction
     bf16x8 qf[KS], dof[KS];
@@ -787,8 +819,9 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 S, dP;
+            const float s0 = pre ? -lse2 : 0.f;          // pre-scaled q: -lse rides in as the accumulator's initial value
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = -dl; }
+            for (int r = 0; r < 16; ++r) { S[r] = s0; dP[r] = -dl; }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
@@ -803,8 +836,13 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
                     S[4 * g] += bv.x; S[4 * g + 1] += bv.y; S[4 * g + 2] += bv.z; S[4 * g + 3] += bv.w;
                 }
             }
+            if (pre) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(fmaf(S[r], cs, -lse2)) * dP[r];      // dS^T
+                for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(S[r]) * dP[r];                   // dS^T
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(fmaf(S[r], cs, -lse2)) * dP[r];  // dS^T
+            }
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 bf16x8 dsf = acc_to_frag(S, sh);
@@ -877,6 +915,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int key = kblk * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
+    const bool pre = p.pre != 0;          // wave-uniform
     const int Mb = attn_key_count(p, b);          // this sample's key count (rows beyond it get zeros)
 
     // this wave's 32 keys as B operands
@@ -949,7 +988,8 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
                 float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
                 float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
                 nl[4 * g] = lv.x; nl[4 * g + 1] = lv.y; nl[4 * g + 2] = lv.z; nl[4 * g + 3] = lv.w;
-                S[4 * g] = 0.f; S[4 * g + 1] = 0.f; S[4 * g + 2] = 0.f; S[4 * g + 3] = 0.f;
+                if (pre) { S[4 * g] = lv.x; S[4 * g + 1] = lv.y; S[4 * g + 2] = lv.z; S[4 * g + 3] = lv.w; }
+                else { S[4 * g] = 0.f; S[4 * g + 1] = 0.f; S[4 * g + 2] = 0.f; S[4 * g + 3] = 0.f; }
                 dP[4 * g] = dv.x; dP[4 * g + 1] = dv.y; dP[4 * g + 2] = dv.z; dP[4 * g + 3] = dv.w;
             }
 #pragma unroll
@@ -963,11 +1003,20 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[r] += bias;
             }
+            if (pre) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(S[r], cs, nl[r]));
-                S[r] = pv;                 // P
-                dP[r] = pv * dP[r];        // dS
+                for (int r = 0; r < 16; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(S[r]);
+                    S[r] = pv;                 // P
+                    dP[r] = pv * dP[r];        // dS
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(fmaf(S[r], cs, nl[r]));
+                    S[r] = pv;                 // P
+                    dP[r] = pv * dP[r];        // dS
+                }
             }
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
@@ -1173,7 +1222,7 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
     // The ping-pong kernel (long sequences, short heads) is parity-green and opt-in: under sustained load it measures 155-157 us
     // on B4 N4096 d40 against 153.5 us for the kernel below, and the training step is 0.4 % faster without it.
     if constexpr (KS <= 4) {
-        const int pp_mode = attn_debug().pp_mode;
+        const int pp_mode = p.pre ? 0 : attn_debug().pp_mode;          // (the ping-pong kernel has no pre-scaled form)
         if (pp_mode == 2 || (pp_mode == 1 && p.M >= 512 && (long)((p.N + 511) / 512) * p.B * p.H >= 192))
             return launch_fwd_pp<KS, VT>(p, s);
     }
@@ -1232,6 +1281,11 @@ extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long l
     p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
     p.kmask = key_mask; p.mcount = key_count; p.o = (uint16_t*)out; p.ldo = ldo; p.lse = lse;
     p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    ADAP_REQUIRE(scale >= 0.f, ADAP_ERR_UNSUPPORTED, "attention_fwd: scale %g", (double)scale);
+    if (scale == 0.f) {            // q carries d^-1/2 * log2(e) already (see the header): scores arrive in the exp2 domain
+        p.pre = 1;
+        p.scale = 0.6931471805599453f;          // 1 / log2(e): cs == 1 in the kernels
+    }
     ATTN_DISPATCH(launch_fwd, p, (hipStream_t)stream);
 }
 
@@ -1270,6 +1324,11 @@ static int attention_bwd_impl(const void* q, long ldq, const void* k, long ldk, 
     p.dk32 = dk32; p.dk16 = (uint16_t*)dk16; p.lddk = lddk;
     p.dv32 = dv32; p.dv16 = (uint16_t*)dv16; p.lddv = lddv;
     p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    ADAP_REQUIRE(scale >= 0.f && (scale > 0.f || !tok_dt), ADAP_ERR_UNSUPPORTED, "attention_bwd: scale %g", (double)scale);
+    if (scale == 0.f) {            // pre-scaled q: dq is the gradient with respect to THAT q, i.e. ln 2 * dS K; dk = ln 2 * dS^T q
+        p.pre = 1;
+        p.scale = 0.6931471805599453f;
+    }
     p.qsplit = dkv_qsplit(B, H, N, M, d);
     p.part = workspace + (((size_t)B * H * N + 3) & ~(size_t)3);
     if (tok_dt) {

@@ -58,6 +58,19 @@ def _op16(t):
 # waits for the lane's event.  Tensors allocated inside ``with lane:`` belong to the lane's pool: they are only reused by later
 # lane work, which always starts with a fork issued after the free.  ADAP_SIDE_LANE=0 switches it off.
 # ---------------------------------------------------------------------------------------------
+# ADAP_PRESCALE_Q=1: the self-attention query projection's weight pack carries d^-1/2 * log2(e) (folded in before the pack's one
+# bf16 rounding), so the attention kernels get their scores in the exp2 domain straight from the matrix core
+# (adap_attention_fwd / _bwd with scale = 0): one VALU instruction per score less.  Parity-green (tests/test_kernels_gpu.py,
+# the model tests) and OFF by default: three interleaved A/B pairs of the training step measured 124.27 vs 124.40 img/s -- the
+# softmax phase is bound by its dependency chain (MFMA -> exp -> convert -> MFMA with two waves per SIMD), not by issue slots.
+PRESCALE_Q = os.environ.get("ADAP_PRESCALE_Q", "0") == "1"
+LOG2E = 1.4426950408889634
+
+
+def q_prescale(d_head):
+    return float(d_head) ** -0.5 * LOG2E
+
+
 SIDE_LANE = os.environ.get("ADAP_SIDE_LANE", "1") != "0"
 # the token maps' gradient inside the cross-attention backward's epilogues (0: the separate read-modify-write kernels; A/B aid)
 TOKMAP_FOLD = os.environ.get("ADAP_TOKMAP_FOLD", "1") != "0"
@@ -127,14 +140,19 @@ class WeightCache:
     def __init__(self):
         self._packs = {}
 
-    def get(self, key, weights, bias=None, cat_dim0=False):
+    def get(self, key, weights, bias=None, cat_dim0=False, row_scales=None):
+        """``row_scales``: one factor per weight in ``weights``, applied in f32 before the pack's single bf16 rounding (the
+        self-attention query projection carries d^-1/2 * log2(e): PRESCALE_Q)."""
         ws = weights if isinstance(weights, (list, tuple)) else [weights]
         bs = bias if isinstance(bias, (list, tuple)) else [bias]
-        stamp = tuple((w.data_ptr(), w._version) for w in ws) + tuple((b.data_ptr(), b._version) for b in bs if b is not None)
+        stamp = tuple((w.data_ptr(), w._version) for w in ws) + tuple((b.data_ptr(), b._version) for b in bs if b is not None) \
+            + (tuple(row_scales) if row_scales is not None else ())
         hit = self._packs.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
         with torch.no_grad():
+            if row_scales is not None:
+                ws = [x.detach().float() * float(f) if f != 1.0 else x for x, f in zip(ws, row_scales)]
             w = torch.cat([x.detach() for x in ws], dim=0) if len(ws) > 1 else ws[0].detach()
             b = None
             if bs[0] is not None:
@@ -366,15 +384,16 @@ class SpatialTransformerFn(torch.autograd.Function):
         # --- attn1 (self) : fused q|k|v projection -------------------------------------------
         n1, l1m, l1r = ops.layernorm_fwd(t0, *P["norm1"])
         qkv = P["qkv1"]
+        sc1 = 0.0 if P.get("q1_prescaled") else None       # 0 = "q carries d^-1/2 log2(e)" (include/adaprompt_hip.h)
         _, qkv1 = ops.linear(n1, qkv.fwd, 3 * C, out_f32=False, out_bf16=True)
         q1, k1, v1 = qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:]
         kc, kv1c = None, None
         if isinstance(key_mask, KeyCompaction):
             kc, key_mask = key_mask, key_mask.mask
             kv1c = ops.gather_rows_bf16(qkv1[..., C:], kc.perm)                   # kept keys first: [B,N,2C]
-            o1, lse1 = ops.attention_fwd(q1, kv1c[..., :C], kv1c[..., C:], heads, None, key_count=kc.count)
+            o1, lse1 = ops.attention_fwd(q1, kv1c[..., :C], kv1c[..., C:], heads, None, key_count=kc.count, scale=sc1)
         else:
-            o1, lse1 = ops.attention_fwd(q1, k1, v1, heads, key_mask)
+            o1, lse1 = ops.attention_fwd(q1, k1, v1, heads, key_mask, scale=sc1)
         to1 = P["to_out1"]
         t1, _ = ops.linear(o1, to1.fwd, C, bias=to1.bias, residual=t0)
         # --- attn2 (cross) ----------------------------------------------------------------------
@@ -541,19 +560,21 @@ class SpatialTransformerFn(torch.autograd.Function):
         # self attention
         _, go1 = _lin_bwd(gt1h, P["to_out1"], out_f32=False, out_bf16=True)
         dqkv1 = torch.empty(B, N, 3 * C, device=x.device, dtype=BF16)
+        sc1 = 0.0 if P.get("q1_prescaled") else None
         kc = ctx.key_compaction
         if kc is not None:
             dkvc = torch.empty(B, N, 2 * C, device=x.device, dtype=BF16)
             ops.attention_bwd(qkv1[..., :C], kv1c[..., :C], kv1c[..., C:], o1, go1, lse1, heads, None,
-                              dq=dqkv1[..., :C], dk=dkvc[..., :C], dv=dkvc[..., C:], key_count=kc.count)
+                              dq=dqkv1[..., :C], dk=dkvc[..., :C], dv=dkvc[..., C:], key_count=kc.count, scale=sc1)
             ops.gather_rows_bf16(dkvc, kc.inv_perm, out=dqkv1[..., C:])          # back to pixel order (masked keys: zeros)
         else:
             ops.attention_bwd(qkv1[..., :C], qkv1[..., C:2 * C], qkv1[..., 2 * C:], o1, go1, lse1, heads, ctx.key_mask,
-                              dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:])
+                              dq=dqkv1[..., :C], dk=dqkv1[..., C:2 * C], dv=dqkv1[..., 2 * C:], scale=sc1)
         gn1, _ = _lin_bwd(dqkv1, P["qkv1"])
         if T is not None:
             _dw_lin(T, "to_out1", o1, gt1h)
-            _dw_lin(T, "q1", n1, dqkv1[..., :C])
+            # (with the pre-scaled pack dq is the gradient with respect to c * q: the parameter's own gradient is c times it)
+            _dw_lin(T, "q1", n1, dqkv1[..., :C] if sc1 is None else (dqkv1[..., :C].float() * q_prescale(C // heads)).to(BF16))
             _dw_lin(T, "k1", n1, dqkv1[..., C:2 * C])
             _dw_lin(T, "v1", n1, dqkv1[..., 2 * C:])
             _dw_norm(T, "norm1", gn1, t0, P["norm1"][0], None, l1m, l1r, 1, 0)

@@ -130,7 +130,9 @@ class SpatialTransformer(nn.Module):
             "norm1": (b.norm1.weight, b.norm1.bias),
             "norm2": (b.norm2.weight, b.norm2.bias),
             "norm3": (b.norm3.weight, b.norm3.bias),
-            "qkv1": wc.get("qkv1", [b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight]),
+            "qkv1": wc.get("qkv1", [b.attn1.to_q.weight, b.attn1.to_k.weight, b.attn1.to_v.weight],
+                           row_scales=(HF.q_prescale(b.attn1.to_q.weight.shape[0] // self.n_heads), 1.0, 1.0) if HF.PRESCALE_Q else None),
+            "q1_prescaled": HF.PRESCALE_Q,
             "to_out1": wc.get("to_out1", b.attn1.to_out[0].weight, b.attn1.to_out[0].bias),
             "q2": wc.get("q2", b.attn2.to_q.weight),
             "to_out2": wc.get("to_out2", b.attn2.to_out[0].weight, b.attn2.to_out[0].bias),

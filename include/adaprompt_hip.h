@@ -142,6 +142,10 @@ int adap_layernorm_bwd(const float* dy, long lddy, const float* x, long ldx, con
  * denominator); values < 1 are treated as 1 and values > M as M.  A sample whose mask keeps NO key is the caller's case to
  * resolve before compaction: the reference's masked_fill form then averages V uniformly, and KeyMasks.compaction (the host
  * side) keeps every key for such a sample, which is the same result.
+ * scale = 0 means "q is PRE-SCALED": it already carries d^-1/2 * log2(e) (folded into to_q's weight pack before its one bf16
+ * rounding), so the scores leave the matrix core in the exp2 domain and need no multiply.  adap_attention_bwd with scale = 0
+ * returns dq with respect to that pre-scaled q (= ln 2 * dS K) and dk = ln 2 * dS^T q: pushed through the same scaled pack they
+ * give the unscaled projection's input gradient.  out / lse are the same numbers in both forms.
  */
 int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                        const uint8_t* key_mask, const int* key_count, void* out, long ldo, float* lse,

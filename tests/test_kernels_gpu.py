@@ -788,3 +788,43 @@ def test_attention_with_compacted_keys_equals_masked_attention(B, H, N, d):
     assert rel(dkv[..., :C].float(), dk_m.float()) < 6e-3 and rel(dkv[..., C:].float(), dv_m.float()) < 6e-3
     # masked keys receive exactly zero gradient
     assert float(dkv[~mask].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,N,M,d,masked", [(2, 8, 4096, 4096, 40, False), (2, 8, 1024, 1024, 80, True), (1, 8, 256, 256, 160, False),
+                                              (2, 4, 300, 333, 40, True)])
+def test_attention_with_pre_scaled_queries(B, H, N, M, d, masked):
+    """scale = 0: q carries d^-1/2 * log2(e) (the self-attention projection's pack, functional.PRESCALE_Q) -- forward output /
+    lse and the backward's dq (with respect to the pre-scaled q), dk, dv against fp64 autograd of the same function."""
+    from adaprompt_amd import functional as HF
+    C = H * d
+    c = HF.q_prescale(d)
+    g = torch.Generator().manual_seed(17)
+    q0 = torch.randn(B, N, C, generator=g)
+    qp = (q0 * c).bfloat16()                                   # what the scaled projection would emit
+    k, v = torch.randn(B, M, C, generator=g).bfloat16(), torch.randn(B, M, C, generator=g).bfloat16()
+    go = torch.randn(B, N, C, generator=g).bfloat16()
+    mask = None
+    if masked:
+        mask = torch.rand(B, M, generator=g) > 0.3
+        mask[:, 0] = True
+    km = None if mask is None else mask.to(torch.uint8).contiguous().to(dev())
+    out, lse = ops.attention_fwd(qp.to(dev()), k.to(dev()), v.to(dev()), H, km, scale=0.0)
+    dq, dk, dv = ops.attention_bwd(qp.to(dev()), k.to(dev()), v.to(dev()), out, go.to(dev()), lse, H, km, scale=0.0)
+    # fp64: scores = ln2 * (q' . k), i.e. the plain attention of q = q' / c with scale d^-1/2
+    qd = qp.double().requires_grad_(True)
+    kd, vd = k.double().requires_grad_(True), v.double().requires_grad_(True)
+    qh = qd.view(B, N, H, d).permute(0, 2, 1, 3)
+    kh, vh = kd.view(B, M, H, d).permute(0, 2, 1, 3), vd.view(B, M, H, d).permute(0, 2, 1, 3)
+    sim = (qh @ kh.transpose(2, 3)) * 0.6931471805599453
+    if mask is not None:
+        sim = sim.masked_fill(~mask[:, None, None, :], -torch.finfo(torch.float32).max)
+    ref = (sim.softmax(-1) @ vh).permute(0, 2, 1, 3).reshape(B, N, C)
+    (ref * go.double()).sum().backward()
+    assert rel(out.float().cpu(), ref.detach().float()) < 6e-3
+    assert rel(lse.cpu(), torch.logsumexp(sim.detach(), dim=-1).float()) < 1e-4
+    assert rel(dq.float().cpu(), qd.grad.float()) < 1.2e-2
+    assert rel(dk.float().cpu(), kd.grad.float()) < 1.2e-2
+    assert rel(dv.float().cpu(), vd.grad.float()) < 1.2e-2
+    # the plain form on the same values agrees to rounding (same kernels otherwise)
+    out2, lse2 = ops.attention_fwd((qp.float() / c).bfloat16().to(dev()), k.to(dev()), v.to(dev()), H, km)
+    assert rel(out.float(), out2.float()) < 1e-2
