@@ -55,6 +55,14 @@ struct ConvParams {
     long batch_stride_w;
     long batch_stride_y32;
     long batch_stride_y16;
+    // fused GEGLU epilogues of the feed-forward (attention.py:32-59); the 8C pre-activation h is kept in a PERMUTED channel
+    // order -- blocks of 16 value channels alternate with the blocks of their 16 gate channels (the weight pack's rows are
+    // permuted accordingly) -- so that a lane holds a value quad and its gate quad in two accumulator tiles of the same wave:
+    //   epi 1 (ff.net.0.proj forward): y16 <- h (bf16, permuted), z16 <- a * gelu(gate)              [M][Cout / 2]
+    //   epi 2 (ff.net.2 data gradient, Cout = 4C): acc = d(a * gelu(gate)); reads h16, y16 <- dh (bf16, permuted) [M][2 Cout]
+    int epi;
+    uint16_t* z16; long ldz16;
+    const uint16_t* h16; long ldh16;
     int dbg;                // what-if switches for tuning (env ADAP_CONV_DEBUG; 0 in production): 1 no DMA in the loop,
                             // 2 no MFMA, 4 no epilogue stores -- results are garbage with any of them set
     unsigned long long* clk;  // diagnostic (adap_conv2d_set_clock_probe; NULL in production): per workgroup of the
@@ -76,6 +84,93 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // launch on the 128 x 160 tile (in-kernel stamps, tools/gemm_timeline.py).  Each lane only ever re-reads addresses it
 // writes itself, so hoisting the loads is safe under that aliasing.
 // ---------------------------------------------------------------------------------------------
+// Phi(g), phi(g) of the exact GELU: erf by Abramowitz-Stegun 7.1.26 on v_rcp_f32 / v_exp_f32 (misc.hip gelu_cdf_pdf: the same
+// arithmetic, so the fused and the separate GEGLU kernels agree bit for bit)
+__device__ __forceinline__ void conv_gelu_cdf_pdf(float g, float& cdf, float& pdf) {
+    const float x = fabsf(g) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    const float e = __expf(-x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, g));
+    pdf = 0.3989422804014327f * e;
+}
+
+__device__ __forceinline__ void unpack_bf16x4(uint2 v, float* f) {
+    f[0] = __builtin_bit_cast(float, v.x << 16); f[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, v.y << 16); f[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+}
+
+// epi 1: accumulator tiles (i, i + 1) of a wave are a block of 16 value channels and the block of their gates
+template <int MT, int PT, class Geo>
+__device__ __forceinline__ void conv_epilogue_geglu_fwd(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo) {
+    if constexpr (MT % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; i += 2) {
+            const unsigned ca = (unsigned)geo.chan(i), cg = (unsigned)geo.chan(i + 1);
+            if ((int)cg >= p.Cout) continue;
+            float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+            if (p.bias) {
+                ba = *(const float4*)(p.bias + ca);
+                bg = *(const float4*)(p.bias + cg);
+            }
+            const unsigned cz = (ca >> 5) * 16u + (ca & 15u);              // the value channels' position in the 4C output
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                int m, b;
+                if (!geo.pixel(j, m, b)) continue;
+                const uint2 ha = make_uint2(pack_bf16x2(acc[i][j][0] * p.alpha + ba.x, acc[i][j][1] * p.alpha + ba.y),
+                                            pack_bf16x2(acc[i][j][2] * p.alpha + ba.z, acc[i][j][3] * p.alpha + ba.w));
+                const uint2 hg = make_uint2(pack_bf16x2(acc[i + 1][j][0] * p.alpha + bg.x, acc[i + 1][j][1] * p.alpha + bg.y),
+                                            pack_bf16x2(acc[i + 1][j][2] * p.alpha + bg.z, acc[i + 1][j][3] * p.alpha + bg.w));
+                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ca) = ha;
+                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + cg) = hg;
+                float a[4], g[4], o[4];
+                unpack_bf16x4(ha, a);                  // (from the rounded values: what the backward will read)
+                unpack_bf16x4(hg, g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float cdf, pdf;
+                    conv_gelu_cdf_pdf(g[e], cdf, pdf);
+                    o[e] = a[e] * (g[e] * cdf);
+                }
+                *(uint2*)(p.z16 + (size_t)m * p.ldz16 + cz) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            }
+        }
+    }
+}
+
+// epi 2: acc = d out of the 4C activations; dh = [d out * gelu(gate) | d out * a * gelu'(gate)] in the permuted 8C layout
+template <int MT, int PT, class Geo>
+__device__ __forceinline__ void conv_epilogue_geglu_bwd(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const unsigned c = (unsigned)geo.chan(i);
+        if ((int)c >= p.Cout) continue;
+        const unsigned ch = (c >> 4) * 32u + (c & 15u);                    // the value quad's position in h; its gates: + 16
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            int m, b;
+            if (!geo.pixel(j, m, b)) continue;
+            float a[4], g[4], da[4], dg[4];
+            unpack_bf16x4(*(const uint2*)(p.h16 + (size_t)m * p.ldh16 + ch), a);
+            unpack_bf16x4(*(const uint2*)(p.h16 + (size_t)m * p.ldh16 + ch + 16), g);
+            // (the separate kernel read d out as bf16: round it the same way)
+            float d[4];
+            unpack_bf16x4(make_uint2(pack_bf16x2(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha),
+                                     pack_bf16x2(acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha)), d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float cdf, pdf;
+                conv_gelu_cdf_pdf(g[e], cdf, pdf);
+                da[e] = d[e] * g[e] * cdf;
+                dg[e] = d[e] * a[e] * (cdf + g[e] * pdf);
+            }
+            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ch) = make_uint2(pack_bf16x2(da[0], da[1]), pack_bf16x2(da[2], da[3]));
+            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ch + 16) = make_uint2(pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3]));
+        }
+    }
+}
+
 template <int MT, int PT, class Geo, int JB = (MT * PT > 16 ? PT / 2 : PT)>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo, float* y32,
                                               uint16_t* y16) {
@@ -481,6 +576,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     uint16_t* y16 = p.y16 ? p.y16 + (size_t)bz * p.batch_stride_y16 : nullptr;
     const GemmGeo geo{m0 + wm * 64, n0 + wn * WN, M, HWo, frow, fchunk};
     if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+    else if (p.epi == 1) conv_epilogue_geglu_fwd<MT, PT>(p, acc, geo);
+    else if (p.epi == 2) conv_epilogue_geglu_bwd<MT, PT>(p, acc, geo);
     else conv_epilogue<MT, PT, GemmGeo, 1>(p, acc, geo, y32, y16);      // (batches of one pixel fragment: this kernel lives on 2-3 workgroups per CU)
 }
 
@@ -779,6 +876,8 @@ __device__ __forceinline__ void ring_body(const ConvParams& p) {
     {
         const GemmGeo geo{m0 + wm * 64, n0 + wn * WN, M, HWo, frow, fchunk};
         if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+        else if (p.epi == 1) conv_epilogue_geglu_fwd<MT, PT>(p, acc, geo);
+        else if (p.epi == 2) conv_epilogue_geglu_bwd<MT, PT>(p, acc, geo);
         else conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16);
     }
     if (stamps && tid == 0) {
@@ -1466,6 +1565,10 @@ extern "C" int adap_conv2d_set_clock_probe(void* buf) {
 static thread_local int g_last_variant = -1;
 extern "C" int adap_conv2d_last_variant(void) { return g_last_variant; }
 
+// the fused-GEGLU entry points below hand their extra operands to adap_conv2d_nhwc through this (same thread, next call)
+struct EpiExt { int epi; uint16_t* z16; long ldz16; const uint16_t* h16; long ldh16; };
+static thread_local EpiExt g_epi_ext = {0, nullptr, 0, nullptr, 0};
+
 static thread_local int g_force_kind = 0, g_force_bn = 0;
 extern "C" int adap_conv2d_debug_force(int kind, int bn) {
     ADAP_REQUIRE(kind >= 0 && kind <= 3 && (bn == 0 || bn == 64 || bn == 128 || bn == 160), ADAP_ERR_UNSUPPORTED,
@@ -1520,6 +1623,7 @@ extern "C" int adap_conv2d_nhwc(
     p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.up = up;
     p.ktiles_per_tap = (Cin + BK - 1) / BK;
     p.ktiles_total = KH * KW * p.ktiles_per_tap;
+    p.epi = g_epi_ext.epi; p.z16 = g_epi_ext.z16; p.ldz16 = g_epi_ext.ldz16; p.h16 = g_epi_ext.h16; p.ldh16 = g_epi_ext.ldh16;
     const bool halo = choose_halo(Hin, Win, Hout, Wout, Cin, Cout, KH, KW, stride, pad, up, x_dtype, nbatch);
     const bool big = !halo && choose_big(M, Cout, p.ktiles_total, x_dtype, nbatch, up);
     const int ksplit_units = halo ? p.ktiles_per_tap : p.ktiles_total;      // the halo kernel splits over Cin slices
@@ -1558,6 +1662,7 @@ extern "C" int adap_conv2d_nhwc(
     hipStream_t s = (hipStream_t)stream;
 
     int bn = choose_bn(Cout);
+    if (p.epi == 1) bn = Cout % 128 == 0 ? 128 : 64;       // a wave must hold value / gate tile PAIRS: 4 or 2 tiles per wave
     if (halo) {
         int ks_plan;
         choose_halo_plan(B, Hin, Win, Cin, Cout, &bn, &ks_plan);
@@ -1595,6 +1700,10 @@ extern "C" int adap_conv2d_nhwc(
             if (bn == 128) return launch<128, false>(p, nbatch, s);
             return launch<64, false>(p, nbatch, s);
         }
+    }
+    if (use_big && bn == 64) {                              // (no 256 x 64 ring variant)
+        use_big = false;
+        p.ntiles_m = (int)((M + BM - 1) / BM);
     }
     p.ntiles_n = (Cout + bn - 1) / bn;
     if (halo) {
@@ -1713,4 +1822,38 @@ extern "C" int adap_pack_conv_weight(const float* w_oihw, void* out_bf16, int O,
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), lds, (hipStream_t)stream, w_oihw, (uint16_t*)out_bf16, O, I, taps,
                        mode, rows, cols);
     return adap_check_launch("pack_weight");
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// FeedForward's GEGLU fused into its two contractions (attention.py:32-59).  The 8C pre-activation is kept in the permuted
+// channel order of ConvParams::epi (16 value channels, their 16 gates, the next 16 values, ...): w_packed / bias of
+// adap_linear_geglu_fwd are the packs of ff.net.0.proj with their rows in that order.
+// ---------------------------------------------------------------------------------------------
+extern "C" int adap_linear_geglu_fwd(const void* x16, long ldx, const void* w_packed, const float* bias, void* h16, long ldh,
+                                     void* out16, long ldo, long rows, int Cin, int C8, void* stream) {
+    ADAP_REQUIRE(x16 && w_packed && h16 && out16, ADAP_ERR_SHAPE, "linear_geglu_fwd: null pointer");
+    ADAP_REQUIRE(C8 % 32 == 0 && ldh >= C8 && ldo >= C8 / 2 && ldh % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out16 % 8) == 0,
+                 ADAP_ERR_ALIGN, "linear_geglu_fwd: C8=%d ldh=%ld ldo=%ld", C8, ldh, ldo);
+    ADAP_REQUIRE(rows >= 1 && rows < (1L << 31), ADAP_ERR_SHAPE, "linear_geglu_fwd: rows");
+    g_epi_ext = {1, (uint16_t*)out16, ldo, nullptr, 0};
+    const int rc = adap_conv2d_nhwc(x16, 1, ldx, w_packed, bias, nullptr, 0, nullptr, 0, nullptr, 0, h16, ldh, 1, (int)rows, 1, Cin,
+                                    (int)rows, 1, C8, 1, 1, 1, 0, 0, 1.0f, 1, nullptr, 1, 0, 0, 0, 0, stream);
+    g_epi_ext = {0, nullptr, 0, nullptr, 0};
+    return rc;
+}
+
+// d out [rows][C] (bf16, the gradient of ff.net.2's output) -> dh [rows][8C] (bf16, permuted order): ff.net.2's data gradient
+// with d(a * gelu(gate)) applied in the epilogue; w_packed_bwd: ff.net.2's data-gradient pack [1][4C][C].
+extern "C" int adap_linear_geglu_bwd(const void* g16, long ldg, const void* w_packed_bwd, const void* h16, long ldh, void* dh16,
+                                     long lddh, long rows, int C, int C4, void* stream) {
+    ADAP_REQUIRE(g16 && w_packed_bwd && h16 && dh16, ADAP_ERR_SHAPE, "linear_geglu_bwd: null pointer");
+    ADAP_REQUIRE(C4 % 16 == 0 && ldh >= 2 * C4 && lddh >= 2 * C4 && ldh % 4 == 0 && lddh % 4 == 0 && ((uintptr_t)h16 % 8) == 0 &&
+                 ((uintptr_t)dh16 % 8) == 0, ADAP_ERR_ALIGN, "linear_geglu_bwd: C4=%d ldh=%ld lddh=%ld", C4, ldh, lddh);
+    ADAP_REQUIRE(rows >= 1 && rows < (1L << 31), ADAP_ERR_SHAPE, "linear_geglu_bwd: rows");
+    g_epi_ext = {2, nullptr, 0, (const uint16_t*)h16, ldh};
+    const int rc = adap_conv2d_nhwc(g16, 1, ldg, w_packed_bwd, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, dh16, lddh, 1, (int)rows, 1, C,
+                                    (int)rows, 1, C4, 1, 1, 1, 0, 0, 1.0f, 1, nullptr, 1, 0, 0, 0, 0, stream);
+    g_epi_ext = {0, nullptr, 0, nullptr, 0};
+    return rc;
 }

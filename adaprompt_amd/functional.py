@@ -74,6 +74,8 @@ def q_prescale(d_head):
 SIDE_LANE = os.environ.get("ADAP_SIDE_LANE", "1") != "0"
 # the token maps' gradient inside the cross-attention backward's epilogues (0: the separate read-modify-write kernels; A/B aid)
 TOKMAP_FOLD = os.environ.get("ADAP_TOKMAP_FOLD", "1") != "0"
+# FeedForward's GEGLU inside its two contractions (ops.linear_geglu_fwd / _bwd): the frozen-UNet path; 0 = separate kernels
+GEGLU_FUSED = os.environ.get("ADAP_GEGLU_FUSED", "1") != "0"
 _LANES = {}
 
 
@@ -140,13 +142,13 @@ class WeightCache:
     def __init__(self):
         self._packs = {}
 
-    def get(self, key, weights, bias=None, cat_dim0=False, row_scales=None):
+    def get(self, key, weights, bias=None, cat_dim0=False, row_scales=None, row_perm=None):
         """``row_scales``: one factor per weight in ``weights``, applied in f32 before the pack's single bf16 rounding (the
         self-attention query projection carries d^-1/2 * log2(e): PRESCALE_Q)."""
         ws = weights if isinstance(weights, (list, tuple)) else [weights]
         bs = bias if isinstance(bias, (list, tuple)) else [bias]
         stamp = tuple((w.data_ptr(), w._version) for w in ws) + tuple((b.data_ptr(), b._version) for b in bs if b is not None) \
-            + (tuple(row_scales) if row_scales is not None else ())
+            + (tuple(row_scales) if row_scales is not None else ()) + ((row_perm,) if row_perm is not None else ())
         hit = self._packs.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -157,6 +159,10 @@ class WeightCache:
             b = None
             if bs[0] is not None:
                 b = torch.cat([x.detach() for x in bs], dim=0) if len(bs) > 1 else bs[0].detach()
+            if row_perm == "geglu":          # the fused-GEGLU row order of ff.net.0.proj (ops.geglu_row_permutation)
+                perm = ops.geglu_row_permutation(w.shape[0], w.device)
+                w = w[perm]
+                b = None if b is None else b[perm]
             pk = ops.PackedConv(w, b)
         self._packs[key] = (stamp, pk)
         return pk
@@ -426,12 +432,18 @@ class SpatialTransformerFn(torch.autograd.Function):
         # --- GEGLU feed-forward -----------------------------------------------------------------
         n3, l3m, l3r = ops.layernorm_fwd(t2, *P["norm3"])
         ff1, ff2 = P["ff1"], P["ff2"]
-        hh32, hh = ops.linear(n3, ff1.fwd, 8 * C, bias=ff1.bias, out_f32=F32_STORAGE, out_bf16=not F32_STORAGE)
-        if F32_STORAGE:
-            hh = hh32
-            gg = _geglu_fwd_f32(hh)
+        ff1g = P.get("ff1g") if (GEGLU_FUSED and not F32_STORAGE and P.get("train") is None) else None
+        if ff1g is not None:
+            # h stays in the permuted channel order of the fused epilogue; the backward uses the same pack's data gradient
+            hh, gg = ops.linear_geglu_fwd(n3, ff1g())
         else:
-            gg = ops.geglu_fwd(hh)
+            hh32, hh = ops.linear(n3, ff1.fwd, 8 * C, bias=ff1.bias, out_f32=F32_STORAGE, out_bf16=not F32_STORAGE)
+            if F32_STORAGE:
+                hh = hh32
+                gg = _geglu_fwd_f32(hh)
+            else:
+                gg = ops.geglu_fwd(hh)
+        ctx.geglu_fused = ff1g is not None
         # t3 only feeds proj_out, whose matrix-core operand is bf16 anyway: write it as bf16 only
         _, t3 = ops.linear(gg, ff2.fwd, C, bias=ff2.bias, residual=t2, out_f32=False, out_bf16=True)
         pout = P["proj_out"]
@@ -490,13 +502,17 @@ class SpatialTransformerFn(torch.autograd.Function):
         # data-gradient contraction reads bf16 (LDS-DMA path) instead of converting f32 on the fly
         gt3, gt3h = _lin_bwd(gop, P["proj_out"], out_f32=True, out_bf16=True)     # [B,N,C]
         # feed-forward
-        if F32_STORAGE:
-            ggg, _ = _lin_bwd(gt3h, P["ff2"], out_f32=True, out_bf16=False)
-            ghh = _geglu_bwd_f32(ggg, hh)
+        if ctx.geglu_fused:
+            ghh = ops.linear_geglu_bwd(gt3h, P["ff2"], hh)                         # bf16 [B,N,8C], permuted channel order
+            gn3, _ = _lin_bwd(ghh, P["ff1g"]())
         else:
-            _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)       # bf16 [B,N,4C]
-            ghh = ops.geglu_bwd(ggg, hh)                                           # bf16 [B,N,8C]
-        gn3, _ = _lin_bwd(ghh, P["ff1"])
+            if F32_STORAGE:
+                ggg, _ = _lin_bwd(gt3h, P["ff2"], out_f32=True, out_bf16=False)
+                ghh = _geglu_bwd_f32(ggg, hh)
+            else:
+                _, ggg = _lin_bwd(gt3h, P["ff2"], out_f32=False, out_bf16=True)       # bf16 [B,N,4C]
+                ghh = ops.geglu_bwd(ggg, hh)                                           # bf16 [B,N,8C]
+            gn3, _ = _lin_bwd(ghh, P["ff1"])
         if T is not None:
             _dw_lin(T, "proj_out", t3, gop)
             _dw_lin(T, "ff2", gg, gt3h)

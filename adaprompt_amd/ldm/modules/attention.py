@@ -137,6 +137,8 @@ class SpatialTransformer(nn.Module):
             "q2": wc.get("q2", b.attn2.to_q.weight),
             "to_out2": wc.get("to_out2", b.attn2.to_out[0].weight, b.attn2.to_out[0].bias),
             "ff1": wc.get("ff1", b.ff.net[0].proj.weight, b.ff.net[0].proj.bias),
+            # the same projection with its rows in the fused-GEGLU order: built on first use (the frozen path)
+            "ff1g": lambda: wc.get("ff1g", b.ff.net[0].proj.weight, b.ff.net[0].proj.bias, row_perm="geglu"),
             "ff2": wc.get("ff2", b.ff.net[2].weight, b.ff.net[2].bias),
             "proj_out": wc.get("proj_out", self.proj_out.weight, self.proj_out.bias),
         }

@@ -855,3 +855,42 @@ def prompt_delta_loss(emb4, mask4, coef, cls_grad_scale=0.05):
     _lib.call("adap_prompt_delta_loss", emb4.data_ptr(), demb.data_ptr(), mask4.data_ptr(), Bs, L, T, D, float(coef),
               float(cls_grad_scale), out.data_ptr(), ws.data_ptr(), _stream())
     return out, demb
+
+
+# --------------------------------------------------------------------------------------------
+# FeedForward with its GEGLU inside the two contractions (csrc/conv_gemm.hip, ConvParams::epi)
+# --------------------------------------------------------------------------------------------
+
+def geglu_row_permutation(C8, device):
+    """perm [C8] int64: row r of the permuted ff.net.0.proj pack is row perm[r] of the checkpoint's weight (blocks of 16 value
+    channels alternate with the blocks of their 16 gate channels)."""
+    r = torch.arange(C8, device=device)
+    blk, half, within = r // 32, (r % 32) // 16, r % 16
+    return blk * 16 + within + half * (C8 // 2)
+
+
+def linear_geglu_fwd(x16, pk_perm):
+    """x16 bf16 [..., Cin], pk_perm: PackedConv of ff.net.0.proj with rows in ``geglu_row_permutation`` order
+    -> (h bf16 [..., 8C] permuted order (for the backward), a * gelu(gate) bf16 [..., 4C])."""
+    assert x16.dtype == BF16
+    rows, ldx = _rows_ld(x16)
+    C8 = pk_perm.O4
+    h = torch.empty(tuple(x16.shape[:-1]) + (C8,), device=x16.device, dtype=BF16)
+    out = torch.empty(tuple(x16.shape[:-1]) + (C8 // 2,), device=x16.device, dtype=BF16)
+    _lib.call("adap_linear_geglu_fwd", x16.data_ptr(), ldx, pk_perm.fwd.data_ptr(), _ptr(pk_perm.bias), h.data_ptr(), C8,
+              out.data_ptr(), C8 // 2, rows, x16.shape[-1], C8, _stream())
+    return h, out
+
+
+def linear_geglu_bwd(g16, pk_ff2, h):
+    """g16 bf16 [..., C] = d(ff.net.2 output); pk_ff2: PackedConv of ff.net.2; h: the permuted pre-activation of the forward
+    -> dh bf16 [..., 8C] (permuted order: the operand of the permuted ff.net.0.proj data-gradient pack)."""
+    assert g16.dtype == BF16 and h.dtype == BF16 and h.is_contiguous()
+    rows, ldg = _rows_ld(g16)
+    C8 = h.shape[-1]
+    bw = pk_ff2.bwd                     # [1][4C][C]
+    assert bw.shape[1] == C8 // 2 and bw.shape[2] == g16.shape[-1]
+    dh = torch.empty(h.shape, device=h.device, dtype=BF16)
+    _lib.call("adap_linear_geglu_bwd", g16.data_ptr(), ldg, bw.data_ptr(), h.data_ptr(), C8, dh.data_ptr(), C8, rows,
+              g16.shape[-1], C8 // 2, _stream())
+    return dh

@@ -87,6 +87,18 @@ int adap_conv2d_set_clock_probe(void* buf);
  * bn 0 = automatic, else the channel tile (64 / 128 / 160).  A combination the problem does not admit is ignored. */
 int adap_conv2d_debug_force(int kind, int bn);
 
+/* FeedForward with its GEGLU fused into the two contractions (attention.py:32-59: proj -> chunk -> a * gelu(gate) -> Linear).
+ * The 8C pre-activation h is stored in a PERMUTED channel order -- 16 value channels, then their 16 gate channels, then the next
+ * 16 values ... (new row 32 k + j <- value channel 16 k + j, new row 32 k + 16 + j <- gate channel 16 k + j) -- and w_packed /
+ * bias of adap_linear_geglu_fwd are ff.net.0.proj's packs with their rows in that order (so is the data-gradient pack that
+ * consumes dh).  fwd: x16 bf16 [rows][Cin] -> h16 bf16 [rows][C8] (kept for the backward) and out16 = a * gelu(gate) bf16
+ * [rows][C8 / 2].  bwd: g16 = d(ff.net.2 output) bf16 [rows][C], w_packed_bwd = ff.net.2's data-gradient pack [1][C4][C] ->
+ * dh16 bf16 [rows][2 * C4] (permuted).  Same arithmetic as adap_geglu_fwd / _bwd around adap_conv2d_nhwc, bit for bit. */
+int adap_linear_geglu_fwd(const void* x16, long ldx, const void* w_packed, const float* bias, void* h16, long ldh,
+                          void* out16, long ldo, long rows, int Cin, int C8, void* stream);
+int adap_linear_geglu_bwd(const void* g16, long ldg, const void* w_packed_bwd, const void* h16, long ldh, void* dh16,
+                          long lddh, long rows, int C, int C4, void* stream);
+
 /* OIHW f32 (checkpoint layout, ddpm.py:321-344) -> bf16 [KH*KW][rows][cols].
  * mode 0 (forward): rows >= O, cols >= I, out[t][o][i] = w[o][i][ky][kx] (zero padded).
  * mode 1 (data gradient): rows >= I, cols >= O, out[t][i][o] = w[o][i][KH-1-ky][KW-1-kx]. */

@@ -828,3 +828,40 @@ def test_attention_with_pre_scaled_queries(B, H, N, M, d, masked):
     # the plain form on the same values agrees to rounding (same kernels otherwise)
     out2, lse2 = ops.attention_fwd((qp.float() / c).bfloat16().to(dev()), k.to(dev()), v.to(dev()), H, km)
     assert rel(out.float(), out2.float()) < 1e-2
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (300, 1280), (64, 1280)])
+def test_feed_forward_with_the_geglu_inside_its_contractions(rows, C):
+    """adap_linear_geglu_fwd / _bwd (GEGLU in the epilogues of ff.net.0.proj and of ff.net.2's data gradient, the 8C
+    pre-activation in a permuted channel order) against the separate kernels around the plain contractions: bit for bit."""
+    from adaprompt_amd import functional as HF
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn(1, rows, C, generator=g) * 0.7).bfloat16().to(dev())
+    w1 = (torch.randn(8 * C, C, generator=g) * C ** -0.5).to(dev())
+    b1 = (torch.randn(8 * C, generator=g) * 0.1).to(dev())
+    w2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(dev())
+    go = (torch.randn(1, rows, C, generator=g) * 0.5).bfloat16().to(dev())
+    wc = HF.WeightCache()
+    p1, p1g, p2 = wc.get("ff1", w1, b1), wc.get("ff1g", w1, b1, row_perm="geglu"), wc.get("ff2", w2)
+    # separate kernels
+    _, h_u = ops.linear(x, p1.fwd, 8 * C, bias=p1.bias, out_f32=False, out_bf16=True)
+    gg_u = ops.geglu_fwd(h_u)
+    _, dgg = ops.linear(go, p2.bwd, 4 * C, out_f32=False, out_bf16=True)
+    dh_u = ops.geglu_bwd(dgg, h_u)
+    gx_u, _ = ops.linear(dh_u, p1.bwd, C)
+    # fused
+    h_f, gg_f = ops.linear_geglu_fwd(x, p1g)
+    dh_f = ops.linear_geglu_bwd(go, p2, h_f)
+    gx_f, _ = ops.linear(dh_f, p1g.bwd, C)
+    torch.cuda.synchronize()
+    perm = ops.geglu_row_permutation(8 * C, dev())
+    assert torch.equal(h_f, h_u[..., perm])
+    assert torch.equal(gg_f, gg_u)
+    assert torch.equal(dh_f, dh_u[..., perm])
+    # the input gradient sums the same 8C products in a different order
+    assert rel(gx_f, gx_u) < 1e-5
+    # and the whole thing against torch in fp32
+    hh = torch.nn.functional.linear(x.float(), w1.bfloat16().float(), b1)
+    a, gate = hh.chunk(2, dim=-1)
+    ref = a * torch.nn.functional.gelu(gate)
+    assert rel(gg_f.float(), ref) < 6e-3
