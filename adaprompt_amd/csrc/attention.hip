@@ -179,7 +179,9 @@ __device__ __forceinline__ void tile_store(const TileRegs<NCH>& r, const TileMap
 // =============================================================================================
 // QB = 32-row query blocks per wave.  QB = 2 (long sequences): every K fragment and every transposed V fragment read
 // from LDS feeds two MFMAs instead of one, and the two blocks' softmax chains are independent work inside one wave.
-template <int KS, int VT, int QB>
+// PRE: the pre-scaled-query form (AttnParams::pre) -- a template parameter, not a run-time branch: with the branch in the loop
+// the default form lost its schedule (B4 h8 N4096 d40: 152 -> 284 us; MFMA pipe 27 -> 17 %)
+template <int KS, int VT, int QB, bool PRE>
 __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int KSTRIDE = G::RSTRIDE;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
     const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
-    const bool pre = p.pre != 0;          // wave-uniform
+    constexpr bool pre = PRE;
 
     // Q fragments stay exactly the caller's bf16 values: scale*log2(e) is applied in f32 inside the exponent's fma
     // (pre-multiplying Q would round q*cs to bf16 again and cost ~2e-4 of LSE accuracy for ~1% of a step)
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
             // running reference point in the exp2 domain (cs > 0): raised only when a row's max outgrows it by more than
             // 2^MAX_SLACK (or it is still -inf) -- p <= 2^MAX_SLACK keeps its full f32 / bf16 relative precision, and the O
             // rescale below (64 multiplies) then runs on a handful of tiles instead of on every second one
-            if (pre) {
+            if constexpr (pre) {
                 // S is already in the exp2 domain and relative to the reference point m (absolute while m is still -inf)
                 const bool first = m[qb] == -INFINITY;
                 const bool grow = first ? (mx > -INFINITY) : (mx > MAX_SLACK);
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
 // =============================================================================================
 // backward, part 1: dQ (query-stationary)
 // =============================================================================================
-template <int KS, int VT>
+template <int KS, int VT, bool PRE>
 __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int KSTRIDE = G::RSTRIDE;
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const int q = blockIdx.x * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
-    const bool pre = p.pre != 0;          // wave-uniform
+    constexpr bool pre = PRE;             // (a template parameter: see attn_fwd_kernel)
 
     // -delta rides in as the dP accumulator's initial value (exact in f32), so dS = P * dP' needs no subtraction
     bf16x8 qf[KS], dof[KS];
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 // =============================================================================================
 // backward, part 2: dK, dV (key-stationary: a wave owns 32 keys, the workgroup 128 keys)
 // =============================================================================================
-template <int KS, int VT>
+template <int KS, int VT, bool PRE>
 __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int QSTRIDE = G::RSTRIDE;
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int key = kblk * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
-    const bool pre = p.pre != 0;          // wave-uniform
+    constexpr bool pre = PRE;             // (a template parameter: see attn_fwd_kernel)
     const int Mb = attn_key_count(p, b);          // this sample's key count (rows beyond it get zeros)
 
     // this wave's 32 keys as B operands
@@ -1186,18 +1188,23 @@ static void* g_attn_stamps = nullptr;
 extern "C" int adap_attention_set_stamp_buffer(void* buf) { g_attn_stamps = buf; return ADAP_OK; }
 static int g_attn_fwd_variant = 0;       // 1 / 2: attn_fwd_kernel with QB = 1 / 2 query blocks per wave; 3: ping-pong kernel
 
-template <int KS, int VT, int QB>
-static int launch_fwd_q(const AttnParams& p, hipStream_t s) {
+template <int KS, int VT, int QB, bool PRE>
+static int launch_fwd_qp(const AttnParams& p, hipStream_t s) {
     size_t lds = 2 * (64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE) + 2 * 68 * 4;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, VT, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<KS, VT, QB, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((p.N + 128 * QB - 1) / (128 * QB), p.B * p.H);
-    hipLaunchKernelGGL((attn_fwd_kernel<KS, VT, QB>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<KS, VT, QB, PRE>), grid, dim3(256), lds, s, p);
     g_attn_fwd_variant = QB;
     return adap_check_launch("attn_fwd");
+}
+
+template <int KS, int VT, int QB>
+static int launch_fwd_q(const AttnParams& p, hipStream_t s) {
+    return p.pre ? launch_fwd_qp<KS, VT, QB, true>(p, s) : launch_fwd_qp<KS, VT, QB, false>(p, s);
 }
 
 template <int KS, int VT>
@@ -1235,10 +1242,12 @@ template <int KS, int VT>
 static int launch_bwd(const AttnParams& p, hipStream_t s) {
     size_t lds1 = 2 * 64 * TileGeom<KS>::RSTRIDE + 68 * 4;
     dim3 g1((p.N + 127) / 128, p.B * p.H);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT>), g1, dim3(256), lds1, s, p);
+    if (p.pre) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT, true>), g1, dim3(256), lds1, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT, false>), g1, dim3(256), lds1, s, p);
     size_t lds2 = 2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4;
     dim3 g2((p.M + 127) / 128, p.B * p.H, p.qsplit);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT>), g2, dim3(256), lds2, s, p);
+    if (p.pre) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, true>), g2, dim3(256), lds2, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, false>), g2, dim3(256), lds2, s, p);
     if (p.qsplit > 1) {
         long tot = (long)p.B * p.M * (p.H * p.d / 4);
         long nb = (tot + 255) / 256;
