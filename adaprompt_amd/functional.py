@@ -102,25 +102,39 @@ class _Lane:
         return ev
 
 
+_LANE_STREAMS = set()
+
+
 def side_lane(t):
-    """the device's side lane, or None (CPU tensors, lane switched off, or inside a side stream already)"""
+    """the side lane of the CURRENT stream on t's device, or None (CPU tensors, lane switched off, or inside a lane already).
+    One lane per issuing stream: the prefetchers run whole UNet passes on streams of their own (the distillation teacher's
+    rollout), and a lane shared with the main stream would chain the two pipelines to each other through its fork / join
+    events (measured: config 2's mix 75 -> 63 img/s)."""
     if not SIDE_LANE or not t.is_cuda:
         return None
-    lane = _LANES.get(t.device.index)
-    if lane is None:
-        lane = _LANES[t.device.index] = _Lane(t.device)
-    if ops._stream() == lane.side.cuda_stream:          # (raw handles: torch.cuda.current_stream() costs ~9 us)
+    cur = ops._stream()                                  # (raw handle: torch.cuda.current_stream() costs ~9 us)
+    if cur in _LANE_STREAMS:
         return None
+    key = (t.device.index, cur)
+    lane = _LANES.get(key)
+    if lane is None:
+        if len(_LANES) >= 8:                             # streams come and go (tests): do not collect lanes for ever
+            return None
+        lane = _LANES[key] = _Lane(t.device)
+        _LANE_STREAMS.add(lane.side.cuda_stream)
     return lane
 
 
 def join_side_lane(device=None):
-    """the main stream waits for lane work whose join was deferred (UNetModel.forward calls this before it hands out the
-    captured activations)."""
-    for idx, lane in _LANES.items():
-        if lane.pending is not None and (device is None or device.index == idx):
-            torch.cuda.current_stream(lane.side.device).wait_event(lane.pending)
-            lane.pending = None
+    """the current stream waits for its lane's work whose join was deferred (UNetModel.forward calls this before it hands out
+    the captured activations)."""
+    if not _LANES:
+        return
+    idx = torch.cuda.current_device() if device is None else device.index
+    lane = _LANES.get((idx, ops._stream()))
+    if lane is not None and lane.pending is not None:
+        torch.cuda.current_stream(lane.side.device).wait_event(lane.pending)
+        lane.pending = None
 
 
 class KeyCompaction:
