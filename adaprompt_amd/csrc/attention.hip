@@ -129,15 +129,15 @@ __device__ __forceinline__ void stage_tile(char* dst, int stride, int nch, const
 // Register-staged prefetch of a [64 x NCH*8] bf16 tile: the global loads of tile t+1 are issued before tile t is
 // multiplied and written to LDS after it (guide T14), so HBM/L2 latency hides under the MFMA phase.  The chunk ->
 // (row, column) decode is done once per kernel (TileMap), not per tile.
-template <int NCH>
+template <int NCH, int NT = 256>
 struct TileRegs {
-    static constexpr int CPT = (64 * NCH + 255) / 256;
+    static constexpr int CPT = (64 * NCH + NT - 1) / NT;
     uint4 v[CPT];
 };
 
-template <int NCH>
+template <int NCH, int NT = 256>
 struct TileMap {
-    static constexpr int CPT = (64 * NCH + 255) / 256;
+    static constexpr int CPT = (64 * NCH + NT - 1) / NT;
     int row[CPT];       // tile row of chunk i, or 64 (never valid)
     int goff[CPT];      // element offset in the global tile
     int loff[CPT];      // byte offset in the LDS image, or -1
@@ -145,7 +145,7 @@ struct TileMap {
     __device__ __forceinline__ void init(long ld, int stride, int d, int tid, int ones_chunk = -1) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            int idx = tid + 256 * i;
+            int idx = tid + NT * i;
             int r = idx / NCH, ch = idx - r * NCH;
             bool in = idx < 64 * NCH;
             row[i] = (in && ch * 8 < d) ? r : 64;
@@ -164,6 +164,27 @@ __device__ __forceinline__ void tile_load(TileRegs<NCH>& r, const TileMap<NCH>& 
         if (mp.row[i] < nvalid) v = *(const uint4*)(src + mp.goff[i]);
         if (mp.one[i]) v.x = 0x3F80u;
         r.v[i] = v;
+    }
+}
+
+// The same for a staging pipeline more than one step deep.  The load has no divergent branch around it (an invalid chunk reads
+// the tile's first chunk), so the number of loads in flight is the same on every path and the compiler can wait for an OLDER
+// set with a counted vmcnt; zero fill and the ones column are applied when the registers are STORED (tile_store_fix, same
+// nvalid) -- applied at load time they would be the loaded registers' first use and drain the queue in the step that issued them.
+template <int NCH, int NT>
+__device__ __forceinline__ void tile_load_raw(TileRegs<NCH, NT>& r, const TileMap<NCH, NT>& mp, const uint16_t* src, int nvalid) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<NCH, NT>::CPT; ++i) r.v[i] = *(const uint4*)(src + (mp.row[i] < nvalid ? mp.goff[i] : 0));
+}
+
+template <int NCH, int NT>
+__device__ __forceinline__ void tile_store_fix(const TileRegs<NCH, NT>& r, const TileMap<NCH, NT>& mp, char* dst, int nvalid) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<NCH, NT>::CPT; ++i) {
+        uint4 v = r.v[i];
+        if (!(mp.row[i] < nvalid)) v = make_uint4(0, 0, 0, 0);
+        if (mp.one[i]) v.x = 0x3F80u;
+        if (mp.loff[i] >= 0) *(uint4*)(dst + mp.loff[i]) = v;
     }
 }
 
@@ -726,6 +747,304 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
 }
 
 // =============================================================================================
+// forward, matrix and vector work interleaved INSIDE each wave (long sequences, d = 40)
+// =============================================================================================
+// In attn_fwd_kernel a wave's stream is phase after phase -- 12 MFMAs (Q K^T), ~210 vector instructions (softmax), 16 MFMAs
+// (P V) -- each waiting for the one before, and the SIMD's second wave drifts through the same phases at the same time: a
+// tile costs a SIMD about the SUM of its matrix time (28 x 32 cycles) and its vector issue time (~1100 cycles), 2200-2300
+// cycles measured.  Here the wave is software-pipelined over the key tiles so that every step holds three
+// INDEPENDENT pieces of work -- P V of tile t-1, the softmax of tile t, Q K^T of tile t+1 -- and the step's 28 MFMAs are
+// issued one fragment at a time between slices of the softmax (two or three exponent pairs per fragment, order pinned by
+// sched_barrier): the matrix pipe runs under the vector stream of the SAME wave, whatever its partner does.  The step is
+// then bound by vector issue alone (160 instructions + 28 MFMA issue slots), not by the sum.
+//   LDS: two buffers, each K | V.  Step t reads K(t+1) and V(t-1) from buffer (t+1)&1 and writes K(t+2) and V(t) into buffer
+//   t&1 (their previous contents were last read in step t-1, one barrier ago).  One barrier per step.
+//   The reference point's rare move (MAX_SLACK) is decided before the exponents, as in attn_fwd_kernel; the rescale of O is
+//   applied at the END of the step, after P V of tile t-1 -- whose P still carries the old reference -- has been issued.
+//   Requires the spare "ones" column of V (the softmax denominator comes out of the P V product): d = 40.
+template <int KS, int VT, int QB, int NW>
+__global__ __launch_bounds__(64 * NW, (QB == 1 && NW == 4) ? 2 : 1) void attn_fwd_il_kernel(AttnParams p) {
+    constexpr int NT = 64 * NW;                         // NW waves share the K / V tiles: 32 QB NW queries per workgroup
+    using G = TileGeom<KS>;
+    constexpr int KSTRIDE = G::RSTRIDE;
+    constexpr int VSTRIDE = VGeom<VT>::VSTRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 64 * KSTRIDE + 64 * VSTRIDE;
+    char* sKV = smem;                                   // [2][ K [64][KSTRIDE] | V [64][VSTRIDE] ]
+    float* sBiasAll = (float*)(smem + 2 * TILE);        // [2][68]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
+    const int q0 = blockIdx.x * (32 * NW * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
+    const int d = p.d;
+    const float cs = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            int ch = 2 * s + h, q = q0 + 32 * qb;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.N && ch * 8 < d) v = *(const uint4*)(p.q + ((size_t)b * p.N + q) * p.ldq + head * d + ch * 8);
+            qf[qb][s] = __builtin_bit_cast(bf16x8, v);
+        }
+    f32x16 O[QB][VT];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[qb][vt][r] = 0.f;
+    float m[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) m[qb] = -INFINITY;
+
+    const uint16_t* kb = p.k + (size_t)b * p.M * p.ldk + head * d;
+    const uint16_t* vb = p.v + (size_t)b * p.M * p.ldv + head * d;
+    const int Mb = attn_key_count(p, b);
+    const int ntiles = (Mb + 63) / 64;
+    // global -> register -> LDS staging TWO steps deep (two register sets): the loads issued in step t are written to LDS at
+    // the end of step t+1.  One step (~1 us) does not cover an L2 round trip under load -- measured with the loads removed:
+    // 197 -> 130 us -- and the wait for them sat at the end of every step
+    TileRegs<G::NCH, NT> rKa, rVa, rKb, rVb;
+    TileMap<G::NCH, NT> mapK, mapV;
+    mapK.init(p.ldk, KSTRIDE, d, tid);
+    mapV.init(p.ldv, VSTRIDE, d, tid, d >> 3);          // the ones column (the launcher checked that it exists)
+    // the key mask byte of a tile's key `lane` is loaded by every wave, without a branch and BEFORE the step's tile loads (a
+    // younger load could only be waited for by draining those: vmcnt counts in order); wave 0 turns it into the tile's bias row
+    const unsigned char* km = p.kmask ? p.kmask + (size_t)b * p.M : (const unsigned char*)p.q;
+    auto mask_byte = [&](int key0) -> unsigned { return km[min(key0 + lane, p.M - 1)]; };
+    auto key_bias = [&](int key0, float* sBias, unsigned mbyte) {
+        if (tid < 64) {
+            int key = key0 + tid;
+            float bias = 0.f;
+            if (key >= Mb) bias = -INFINITY;
+            else if (p.kmask && !mbyte) bias = -FLT_MAX;
+            sBias[tid] = bias;
+            unsigned long long any = __ballot(bias != 0.f);
+            if (tid == 0) sBias[64] = any ? 1.f : 0.f;
+        }
+    };
+    // one operand fragment per item of a step: items 0 .. 4 VT - 1 are P V of the previous tile ((tt, sh) = (g >> 1, g & 1),
+    // g = item / VT, d tile = item % VT: a transposed V fragment), the rest Q K^T of the next tile ((tt, s): a K fragment)
+    constexpr int NPV = 4 * VT, NI = 4 * VT + 2 * KS;
+    auto frag = [&](const char* sK, const char* sV, int i) -> bf16x8 {
+        if (i < NPV) {
+            const int g = i / VT, vt = i - g * VT;
+            return lds_tr_frag(sV, VSTRIDE, 32 * (g >> 1) + 16 * (g & 1), 32 * vt, lane);
+        }
+        const int j = i - NPV, tt = j / KS, s = j - tt * KS;
+        return *(const bf16x8*)(sK + (32 * tt + c) * KSTRIDE + (2 * s + h) * 16);
+    };
+
+    f32x16 SA[QB][2], SB[QB][2];
+    uint4 PA[QB][2][2], PB[QB][2][2];                   // P fragments (bf16 pairs) of the previous / the current tile
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) PA[qb][tt][sh] = make_uint4(0, 0, 0, 0);
+
+    // ---- prologue: K(0), K(1) in LDS, V(-1) = 0 (step 0's P V adds nothing), S(0) in registers
+    tile_load_raw(rKa, mapK, kb, min(64, Mb));
+    tile_store_fix(rKa, mapK, sKV, min(64, Mb));
+    if (ntiles > 1) {
+        tile_load_raw(rKa, mapK, kb + (size_t)64 * p.ldk, min(64, Mb - 64));
+        tile_store_fix(rKa, mapK, sKV + TILE, min(64, Mb - 64));
+    }
+    // what "step -1" would have loaded: K(2) and V(0), stored at the end of step 0
+    if (ntiles > 2) tile_load_raw(rKb, mapK, kb + (size_t)128 * p.ldk, min(64, Mb - 128));
+    tile_load_raw(rVb, mapV, vb, min(64, Mb));
+    for (int idx = tid; idx < 64 * VSTRIDE / 16; idx += NT) *(uint4*)(sKV + TILE + 64 * KSTRIDE + idx * 16) = make_uint4(0, 0, 0, 0);
+    key_bias(0, sBiasAll, mask_byte(0));
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 kf = *(const bf16x8*)(sKV + (32 * tt + c) * KSTRIDE + (2 * s + h) * 16);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                if (s == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    SA[qb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][s], z, 0, 0, 0);
+                } else {
+                    SA[qb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][s], SA[qb][tt], 0, 0, 0);
+                }
+            }
+        }
+    __syncthreads();                                    // K(0) has been read by everyone before step 0 overwrites it with K(2)
+
+    auto step = [&](int t, f32x16 (&Sc)[QB][2], f32x16 (&Sn)[QB][2], uint4 (&Pp)[QB][2][2], uint4 (&Pn)[QB][2][2],
+                    TileRegs<G::NCH, NT>& rKl, TileRegs<G::NCH, NT>& rVl, const TileRegs<G::NCH, NT>& rKs,
+                    const TileRegs<G::NCH, NT>& rVs) {
+        const char* sK = sKV + ((t + 1) & 1) * TILE;   // K(t+1) | V(t-1)
+        const char* sV = sK + 64 * KSTRIDE;
+        const float* sBias = sBiasAll + (t & 1) * 68;
+        const bool k2 = t + 2 < ntiles;
+        const unsigned mbyte = mask_byte((t + 1) * 64);
+        // loads of this step: K(t+3), V(t+1) -- stored at the end of the NEXT step
+        // (past the last tile they re-read the last tile's rows and are never stored: no branch around a load)
+        {
+            const int tk = min(t + 3, ntiles - 1), tv = min(t + 1, ntiles - 1);
+            tile_load_raw(rKl, mapK, kb + (size_t)tk * 64 * p.ldk, min(64, Mb - tk * 64));
+            tile_load_raw(rVl, mapV, vb + (size_t)tv * 64 * p.ldv, min(64, Mb - tv * 64));
+        }
+        // ---- the tile's row maxima and the reference point (as attn_fwd_kernel)
+        const bool biased = (p.kmask != nullptr || (t + 1 == ntiles && (Mb & 63) != 0)) && sBias[64] != 0.f;
+        if (biased) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float4 bv = *(const float4*)(sBias + 32 * tt + 8 * g + 4 * h);
+                        Sc[qb][tt][4 * g] += bv.x; Sc[qb][tt][4 * g + 1] += bv.y;
+                        Sc[qb][tt][4 * g + 2] += bv.z; Sc[qb][tt][4 * g + 3] += bv.w;
+                    }
+        }
+        float alpha[QB];
+        bool anyg = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, Sc[qb][tt][r]);
+            mx = xor32_max(mx);
+            const float mcand = mx * cs;
+            const bool grow = mcand > m[qb] + MAX_SLACK;
+            const float mnew = grow ? mcand : m[qb];
+            alpha[qb] = __builtin_amdgcn_exp2f(m[qb] - mnew);          // 1 for the rows that keep their reference
+            m[qb] = mnew;
+            anyg = anyg || __any(grow);
+        }
+        // ---- exponents of tile t between the MFMAs of P V (t-1) and Q K^T (t+1), one fragment at a time
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NP = QB * 16;                     // pairs of scores per lane
+        // operand fragments two items ahead of their MFMAs (a ring of three), each read pinned in a region of its own: left
+        // inside the item's region the compiler sinks it to just above its use and every MFMA waits a full LDS round trip
+        bf16x8 fr[3];
+        fr[0] = frag(sK, sV, 0);
+        fr[1] = frag(sK, sV, 1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + 2 < NI) fr[(i + 2) % 3] = frag(sK, sV, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 fcur = fr[i % 3];
+#pragma unroll
+            for (int pi = i * NP / NI; pi < (i + 1) * NP / NI; ++pi) {
+                const int qb = pi / 16, rest = pi - qb * 16, tt = rest >> 3, r = 2 * (rest & 7);
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(Sc[qb][tt][r], cs, -m[qb]));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(Sc[qb][tt][r + 1], cs, -m[qb]));
+                unsigned w = pack_bf16x2(e0, e1);
+                // pinned HERE: left to itself the compiler sinks the whole exponent stream to the fragments' first use, the
+                // next step's P V -- i.e. out of the MFMAs' shadow it is placed in
+                asm volatile("" : "+v"(w));
+                const int wi = (r & 7) >> 1;
+                if (wi == 0) Pn[qb][tt][r >> 3].x = w;
+                else if (wi == 1) Pn[qb][tt][r >> 3].y = w;
+                else if (wi == 2) Pn[qb][tt][r >> 3].z = w;
+                else Pn[qb][tt][r >> 3].w = w;
+            }
+            if (i < NPV) {
+                const int g = i / VT, vt = i - g * VT;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fcur, __builtin_bit_cast(bf16x8, Pp[qb][g >> 1][g & 1]), O[qb][vt], 0, 0, 0);
+            } else {
+                const int j = i - NPV, tt = j / KS, s = j - tt * KS;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (s == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        Sn[qb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fcur, qf[qb][s], z, 0, 0, 0);
+                    } else {
+                        Sn[qb][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fcur, qf[qb][s], Sn[qb][tt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (anyg) {                                     // wave-uniform, rare: O (P V of t-1 included) moves to the new reference
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha[qb];
+        }
+        char* wb = sKV + (t & 1) * TILE;               // K(t+2) | V(t): their buffers' last readers passed the previous barrier
+        if (k2) tile_store_fix(rKs, mapK, wb, min(64, Mb - (t + 2) * 64));             // (loaded in the previous step)
+        tile_store_fix(rVs, mapV, wb + 64 * KSTRIDE, min(64, Mb - t * 64));
+        if (t + 1 < ntiles) key_bias((t + 1) * 64, sBiasAll + ((t + 1) & 1) * 68, mbyte);
+        __syncthreads();
+    };
+    // (pairs of steps in a loop without a branch between them, the odd last step after it: with `if (t + 1 < ntiles)` inside
+    // the loop the register sets of the staging pipeline were shuffled at the join -- a v_mov of a register still being loaded
+    // = s_waitcnt vmcnt(0) at the end of every second step)
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+        step(t, SA, SB, PA, PB, rKa, rVa, rKb, rVb);
+        step(t + 1, SB, SA, PB, PA, rKb, rVb, rKa, rVa);
+    }
+    if (t < ntiles) step(t, SA, SB, PA, PB, rKa, rVa, rKb, rVb);
+    {   // P V of the last tile
+        const char* sV = sKV + ((ntiles - 1) & 1) * TILE + 64 * KSTRIDE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) {
+                bf16x8 vf = lds_tr_frag(sV, VSTRIDE, 32 * (g >> 1) + 16 * (g & 1), 32 * vt, lane);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    if (ntiles & 1) O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, PB[qb][g >> 1][g & 1]), O[qb][vt], 0, 0, 0);
+                    else O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, PA[qb][g >> 1][g & 1]), O[qb][vt], 0, 0, 0);
+                }
+            }
+    }
+    // ---- epilogue (as in attn_fwd_kernel, denominator from the ones column)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + 32 * qb;
+        const int vt0 = d >> 5, rin = d & 31, hh = (rin >> 2) & 1, reg = (rin & 3) + 4 * (rin >> 3);
+        float lv = 0.f;
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (vt == vt0 && r == reg) lv = O[qb][vt][r];
+        const float ltot = __shfl(lv, c + 32 * hh, 64);
+        const float inv = 1.0f / ltot;
+        if (q < p.N) {
+            uint16_t* orow = p.o + ((size_t)b * p.N + q) * p.ldo + head * d;
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int d0 = 32 * vt + 8 * g + 4 * h;
+                    if (d0 < d) {
+                        uint2 w;
+                        w.x = pack_bf16x2(O[qb][vt][4 * g] * inv, O[qb][vt][4 * g + 1] * inv);
+                        w.y = pack_bf16x2(O[qb][vt][4 * g + 2] * inv, O[qb][vt][4 * g + 3] * inv);
+                        *(uint2*)(orow + d0) = w;
+                    }
+                }
+            if (h == 0 && p.lse) p.lse[((size_t)b * p.H + head) * p.N + q] = (m[qb] + log2f(ltot)) * 0.6931471805599453f;
+        }
+    }
+}
+
+// =============================================================================================
 // backward, part 1: dQ (query-stationary)
 // =============================================================================================
 template <int KS, int VT, bool PRE>
@@ -1133,7 +1452,8 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnParams p) {
 // ADAP_ATTN_QB1 / ADAP_ATTN_DKV_QSPLIT) instead of with getenv() on every launch; tests and the tuning tools change them
 // through adap_attention_set_debug.
 struct AttnDebug {
-    int pp_mode;      // 0 = query-stationary forward (default), 1 = ping-pong where it applies, 2 = ping-pong always
+    int pp_mode;      // 0 = default choice, 1 = ping-pong where it applies, 2 = ping-pong always, 3 / 4 = the interleaved
+                      // forward with 8 / 4 waves per workgroup wherever it applies, 5 = attn_fwd_kernel always
     int pp_prio;      // ping-pong kernel: phase at raised priority, 1 = matrix (default), 2 = vector, 0 = neither
     int qb1;          // 1 = one query block per wave even at the 64 x 64 level
     int dkv_qsplit;   // 0 = heuristic, else the dK/dV kernel's query-split factor
@@ -1142,7 +1462,9 @@ static AttnDebug& attn_debug() {
     static AttnDebug d = [] {
         AttnDebug v;
         v.pp_mode = getenv("ADAP_ATTN_FORCE_PP") ? 2 : (getenv("ADAP_ATTN_PP") ? 1 : 0);
-        const char* e = getenv("ADAP_ATTN_PP_PRIO");
+        const char* e = getenv("ADAP_ATTN_FWD_MODE");
+        if (e) v.pp_mode = atoi(e);
+        e = getenv("ADAP_ATTN_PP_PRIO");
         v.pp_prio = e ? atoi(e) : 1;
         v.qb1 = getenv("ADAP_ATTN_QB1") ? 1 : 0;
         e = getenv("ADAP_ATTN_DKV_QSPLIT");
@@ -1152,7 +1474,7 @@ static AttnDebug& attn_debug() {
     return d;
 }
 extern "C" int adap_attention_set_debug(int pp_mode, int pp_prio, int qb1, int dkv_qsplit) {
-    ADAP_REQUIRE(pp_mode >= -1 && pp_mode <= 2 && pp_prio >= -1 && pp_prio <= 2 && qb1 >= -1 && qb1 <= 1 && dkv_qsplit >= -1 &&
+    ADAP_REQUIRE(pp_mode >= -1 && pp_mode <= 5 && pp_prio >= -1 && pp_prio <= 2 && qb1 >= -1 && qb1 <= 1 && dkv_qsplit >= -1 &&
                  dkv_qsplit <= 16, ADAP_ERR_UNSUPPORTED, "attention_set_debug: %d %d %d %d", pp_mode, pp_prio, qb1, dkv_qsplit);
     AttnDebug& d = attn_debug();                  // -1 leaves a switch as it is
     if (pp_mode >= 0) d.pp_mode = pp_mode;
@@ -1224,8 +1546,31 @@ static int launch_fwd_pp(const AttnParams& p, hipStream_t s) {
     return adap_check_launch("attn_fwd (ping-pong)");
 }
 
+template <int KS, int VT, int QB, int NW>
+static int launch_fwd_il(const AttnParams& p, hipStream_t s) {
+    size_t lds = 2 * (64 * TileGeom<KS>::RSTRIDE + 64 * VGeom<VT>::VSTRIDE) + 2 * 68 * 4;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipFuncSetAttribute((const void*)attn_fwd_il_kernel<KS, VT, QB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.N + 32 * NW * QB - 1) / (32 * NW * QB), p.B * p.H);
+    hipLaunchKernelGGL((attn_fwd_il_kernel<KS, VT, QB, NW>), grid, dim3(64 * NW), lds, s, p);
+    g_attn_fwd_variant = 3 + QB + (NW == 8 ? 2 : 0);
+    return adap_check_launch("attn_fwd (interleaved)");
+}
+
 template <int KS, int VT>
 static int launch_fwd(const AttnParams& p, hipStream_t s) {
+    // the interleaved kernel: needs V's spare ones column (d = 40) and a long key loop to pipeline over
+    if constexpr (KS <= 4) {
+        const int mode = attn_debug().pp_mode;
+        const bool ones_col = 32 * VT > p.d && (p.d >> 3) < TileGeom<KS>::NCH;
+        if ((mode == 3 || mode == 4) && !p.pre && ones_col && p.M >= 256) {
+            if (mode == 3) return launch_fwd_il<KS, VT, 1, 8>(p, s);
+            return launch_fwd_il<KS, VT, 1, 4>(p, s);
+        }
+    }
     // The ping-pong kernel (long sequences, short heads) is parity-green and opt-in: under sustained load it measures 155-157 us
     // on B4 N4096 d40 against 153.5 us for the kernel below, and the training step is 0.4 % faster without it.
     if constexpr (KS <= 4) {

@@ -163,14 +163,18 @@ int adap_attention_fwd(const void* q, long ldq, const void* k, long ldk, const v
                        const uint8_t* key_mask, const int* key_count, void* out, long ldo, float* lse,
                        int B, int H, int N, int M, int d, float scale, void* stream);
 /* which forward kernel the last adap_attention_fwd dispatched to: 1 / 2 = query-stationary kernel with 1 / 2 query blocks per
- * wave, 3 = the ping-pong kernel (512-query workgroups, SIMD partners half a tile apart; N >= 512 keys, d <= 64) */
+ * wave, 3 = the ping-pong kernel (512-query workgroups, SIMD partners half a tile apart; N >= 512 keys, d <= 64), 4 / 6 = the
+ * interleaved kernel (P V of tile t-1, softmax of t, Q K^T of t+1 in one instruction stream; d = 40-like heads with a spare
+ * V column, M >= 256) with 4 / 8 waves per workgroup */
 int adap_attention_fwd_last_variant(void);
 /* Diagnostic (tools/attn_stamps.py): with a non-NULL device buffer of 6 * (2 * ceil(M/64) + 1) uint64, workgroup (0,0) of the
  * ping-pong forward stores shader-clock stamps (entry / work done / barrier passed) per phase and wave half.  NULL = off. */
 int adap_attention_set_stamp_buffer(void* buf);
 /* Kernel-selection switches for tests and tuning tools (defaults come from the environment, read once: ADAP_ATTN_PP /
  * ADAP_ATTN_FORCE_PP, ADAP_ATTN_PP_PRIO, ADAP_ATTN_QB1, ADAP_ATTN_DKV_QSPLIT); -1 leaves a switch unchanged.
- * pp_mode 0 = query-stationary forward, 1 = ping-pong forward where it applies, 2 = always; pp_prio: the ping-pong kernel's
+ * pp_mode 0 = default choice (query-stationary forward), 1 = ping-pong forward where it applies, 2 = always, 3 / 4 = the
+ * interleaved forward with 8 / 4 waves per workgroup where it applies, 5 = query-stationary always (also ADAP_ATTN_FWD_MODE);
+ * pp_prio: the ping-pong kernel's
  * raised-priority phase (1 matrix, 2 vector, 0 neither); qb1 = 1: one query block per wave; dkv_qsplit: 0 = heuristic. */
 int adap_attention_set_debug(int pp_mode, int pp_prio, int qb1, int dkv_qsplit);
 /* dq/dk/dv as f32 and/or bf16; workspace: adap_attention_bwd_workspace_floats(...) floats of scratch (the row

@@ -347,6 +347,40 @@ ATTN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("case", [(2, 8, 300, 333, 40, True), (1, 8, 1024, 1024, 40, False), (1, 8, 512, 257, 40, True),
+                                  (2, 8, 260, 256, 40, False), (4, 8, 4096, 4096, 40, True), (1, 8, 700, 700, 24, True)])
+def test_attention_fwd_interleaved_kernel(case, mode):
+    """``attn_fwd_il_kernel`` (opt-in: the wave software-pipelined over the key tiles, P V of tile t-1 / softmax of t / Q K^T of
+    t+1 in one instruction stream, staging two steps deep; 8 or 4 waves per workgroup): ragged, masked, odd and even tile
+    counts, full size -- output and LSE against fp32 torch and against the default kernel.  The keys' magnitude grows along the
+    sequence, so the running reference point moves in LATE tiles too (the rescale of O deferred to the end of a step)."""
+    from adaprompt_amd import _lib
+    B, H, N, M, d, use_mask = case
+    C = H * d
+    q, k, v = bf(rnd(B, N, C, seed=1)) * 2.0, bf(rnd(B, M, C, seed=2)), bf(rnd(B, M, C, seed=3))
+    k = k * torch.linspace(0.5, 3.0, M, device=k.device).view(1, M, 1)
+    mask = None
+    if use_mask:
+        mask = (torch.rand(B, M, generator=torch.Generator().manual_seed(5)) > 0.3).to(dev())
+        mask[:, 0] = True
+    km = mask.to(torch.uint8).contiguous() if mask is not None else None
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    q, k, v = qb.float(), kb.float(), vb.float()
+    _lib.call("adap_attention_set_debug", mode, -1, -1, -1)
+    try:
+        out, lse = ops.attention_fwd(qb, kb, vb, H, km)
+        assert _lib.call_long("adap_attention_fwd_last_variant") == {3: 6, 4: 4}[mode]
+    finally:
+        _lib.call("adap_attention_set_debug", 0, -1, -1, -1)
+    out0, lse0 = ops.attention_fwd(qb, kb, vb, H, km)
+    assert _lib.call_long("adap_attention_fwd_last_variant") in (1, 2)
+    ref, sim, _ = ref_attention(q, k, v, H, mask)
+    assert rel(out.float(), ref) < 6e-3, rel(out.float(), ref)
+    assert rel(lse, torch.logsumexp(sim, dim=-1)) < 1e-4
+    assert rel(out.float(), out0.float()) < 6e-3 and rel(lse, lse0) < 1e-4
+
+
 @pytest.mark.parametrize("case", [(2, 8, 300, 333, 40, True), (1, 8, 1024, 1024, 40, False), (2, 8, 520, 77, 40, False),
                                   (1, 8, 64, 64, 32, False), (2, 8, 96, 40, 8, False), (1, 8, 700, 700, 64, True),
                                   (4, 8, 4096, 4096, 40, False)])
