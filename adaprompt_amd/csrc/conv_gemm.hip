@@ -63,6 +63,11 @@ struct ConvParams {
     int epi;
     uint16_t* z16; long ldz16;
     const uint16_t* h16; long ldh16;
+    // GroupNorm statistics of the OUTPUT from the epilogue (adap_conv2d_next_gn_partial; stencil-window kernel, unsplit):
+    // gn_part [B][Hout * Wout / 64][32 groups][2] f32 <- (sum, sum of squares) of every group's channels over 64 pixels (one wave's
+    // share of a tile) -- the format of the two-pass GroupNorm's statistics pass, which the consumer then skips
+    float* gn_part;
+    int gn_cpg;             // channels per group (Cout / 32)
     int dbg;                // what-if switches for tuning (env ADAP_CONV_DEBUG; 0 in production): 1 no DMA in the loop,
                             // 2 no MFMA, 4 no epilogue stores -- results are garbage with any of them set
     unsigned long long* clk;  // diagnostic (adap_conv2d_set_clock_probe; NULL in production): per workgroup of the
@@ -173,7 +178,8 @@ __device__ __forceinline__ void conv_epilogue_geglu_bwd(const ConvParams& p, con
 
 template <int MT, int PT, class Geo, int JB = (MT * PT > 16 ? PT / 2 : PT)>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo, float* y32,
-                                              uint16_t* y16) {
+                                              uint16_t* y16, float (*st)[2] = nullptr) {
+    // st (stencil-window kernel with p.gn_part): per channel tile, this lane's sum and sum of squares of the values it writes
     static_assert(PT % JB == 0, "pixel fragments are processed in batches of JB");
     // 32-bit byte offsets against wave-uniform bases (global_load/store saddr form): twenty 64-bit addresses per tensor
     // would otherwise be live across the batch (the host checks that every tensor spans < 4 GiB)
@@ -230,6 +236,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (
                 const f32x4 a = acc[i][j0 + j];
                 const float v0 = a[0] * p.alpha + bq[i].x + rq[i][j].x, v1 = a[1] * p.alpha + bq[i].y + rq[i][j].y;
                 const float v2 = a[2] * p.alpha + bq[i].z + rq[i][j].z, v3 = a[3] * p.alpha + bq[i].w + rq[i][j].w;
+                if (st) {
+                    // BEFORE the stores, and pinned there: placed after them the compiler builds these sums in the registers the
+                    // store still reads (they are dead to it) a handful of instructions later, and gfx950 does not interlock a
+                    // VALU write against a global store's data read that late -- one dword of a 16-lane row of the output came
+                    // out wrong now and then (tests/test_kernels_gpu.py's bit-reproducibility loop found it)
+                    st[i][0] += (v0 + v1) + (v2 + v3);
+                    st[i][1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                    asm volatile("" : "+v"(st[i][0]), "+v"(st[i][1]) :: "memory");
+                }
                 if (y32) *(float4*)((char*)y32 + (mm[j] * ld32 + cc[i]) * 4u) = make_float4(v0, v1, v2, v3);
                 if (y16) {
                     uint2 o;
@@ -253,6 +268,41 @@ __device__ __forceinline__ void conv_store_slab(const ConvParams& p, const f32x4
             const int c0 = geo.chan(i);
             if (c0 < p.Cout)
                 *(float4*)(slab + (size_t)m * p.Cout + c0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// GroupNorm statistics of a wave's share of the output tile (p.gn_part; the consumer's statistics pass -- 4 or 2 bytes per element
+// of HBM reads -- is then skipped).  Every contraction kernel has the same wave layout: a wave owns 64 pixels x MT channel tiles
+// of 16; a lane's quad = 4 consecutive channels of one pixel, the 16 lanes of a row = the 16 pixels of a fragment.  Wave-local
+// and in a fixed order: lane sums over the wave's pixel fragments (conv_epilogue's st) -> butterfly over the 16 pixels -> over
+// the 1 / 2 / 4 quads of a group (4 / 8 / 16 channels per group) -> one record per (wave's pixel range, group).  No LDS, no
+// barrier: `chunk` numbers the wave's pixel range within the whole output (image-major).
+template <int MT>
+__device__ __forceinline__ void epilogue_gn_stats(const ConvParams& p, float (&st)[MT][2], int frow, int fchunk, int wave_c0,
+                                                  size_t chunk) {
+    const int qpg = p.gn_cpg >> 2;              // quads per group: 1, 2 or 4
+    // The butterfly's ds_bpermute results land in registers the register allocator has just freed -- the data registers of
+    // the epilogue's last global stores.  gfx950 does not interlock an LDS return against a VMEM store still reading its data:
+    // without this wait one dword of a 16-lane row of the OUTPUT came out wrong now and then (found by the bit-reproducibility
+    // check of tests/test_kernels_gpu.py; the same family as the store hazard noted in norms.hip).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = st[i][k];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (qpg >= 2) v += __shfl_xor(v, 16, 64);
+            if (qpg == 4) v += __shfl_xor(v, 32, 64);
+            st[i][k] = v;
+        }
+    if (frow == 0 && (fchunk & (qpg - 1)) == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int g = (wave_c0 + i * 16 + fchunk * 4) / p.gn_cpg;
+            *(float2*)(p.gn_part + (chunk * 32 + g) * 2) = make_float2(st[i][0], st[i][1]);
         }
     }
 }
@@ -578,7 +628,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvParams p) {
     if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
     else if (p.epi == 1) conv_epilogue_geglu_fwd<MT, PT>(p, acc, geo);
     else if (p.epi == 2) conv_epilogue_geglu_bwd<MT, PT>(p, acc, geo);
-    else conv_epilogue<MT, PT, GemmGeo, 1>(p, acc, geo, y32, y16);      // (batches of one pixel fragment: this kernel lives on 2-3 workgroups per CU)
+    else if (p.gn_part == nullptr) {
+        conv_epilogue<MT, PT, GemmGeo, 1>(p, acc, geo, y32, y16);      // (batches of one pixel fragment: this kernel lives on 2-3 workgroups per CU)
+    } else {                                   // + GroupNorm statistics of the tile (epilogue_gn_stats; HWo % 128 == 0: host)
+        float st[MT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { st[i][0] = 0.f; st[i][1] = 0.f; }
+        conv_epilogue<MT, PT, GemmGeo, 1>(p, acc, geo, y32, y16, st);
+        epilogue_gn_stats<MT>(p, st, frow, fchunk, n0 + wn * WN, (size_t)(m0 / 64) + wm);      // 64-pixel ranges, image-major
+    }
 }
 
 // split-K second pass: fixed-order sum of the slabs + the fused epilogue
@@ -878,7 +936,15 @@ __device__ __forceinline__ void ring_body(const ConvParams& p) {
         if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
         else if (p.epi == 1) conv_epilogue_geglu_fwd<MT, PT>(p, acc, geo);
         else if (p.epi == 2) conv_epilogue_geglu_bwd<MT, PT>(p, acc, geo);
-        else conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16);
+        else if (p.gn_part == nullptr) {
+            conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16);
+        } else {                               // + GroupNorm statistics of the tile (epilogue_gn_stats; HWo % BMT == 0: host)
+            float st[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { st[i][0] = 0.f; st[i][1] = 0.f; }
+            conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16, st);
+            epilogue_gn_stats<MT>(p, st, frow, fchunk, n0 + wn * WN, (size_t)(m0 / 64) + wm);  // 64-pixel ranges, image-major
+        }
     }
     if (stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1089,8 +1155,18 @@ __device__ __forceinline__ void halo_body(const ConvParams& p) {
     const int M = p.B * p.Hin * p.Win;
     auto epilogue = [&](int c_bimg, int c_y0, int c_x0, int c_n0) {
         const PatchGeo<WIDE> geo{c_bimg, c_y0, c_x0, c_n0 + wn * WN, p.Hin, p.Win, wm, frow, fchunk};
-        if (p.ksplit > 1) conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
-        else conv_epilogue<MT, PT>(p, acc, geo, p.y32, p.y16);
+        if (p.ksplit > 1) {
+            conv_store_slab<MT, PT>(p, acc, geo, p.ws + (size_t)blockIdx.z * M * p.Cout);
+        } else if (p.gn_part == nullptr) {
+            conv_epilogue<MT, PT>(p, acc, geo, p.y32, p.y16);
+        } else {
+            float st[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { st[i][0] = 0.f; st[i][1] = 0.f; }
+            conv_epilogue<MT, PT>(p, acc, geo, p.y32, p.y16, st);
+            epilogue_gn_stats<MT>(p, st, frow, fchunk, c_n0 + wn * WN,
+                                  ((size_t)c_bimg * (tiles_x * tiles_y) + (c_y0 / HALO_TH) * tiles_x + c_x0 / HALO_TW) * 4 + wm);
+        }
     };
 
     // ---- the step stream.  A step = (chunk, tap); the nine taps of a chunk are unrolled (ring slot = tap % 3 because
@@ -1569,6 +1645,19 @@ extern "C" int adap_conv2d_last_variant(void) { return g_last_variant; }
 struct EpiExt { int epi; uint16_t* z16; long ldz16; const uint16_t* h16; long ldh16; };
 static thread_local EpiExt g_epi_ext = {0, nullptr, 0, nullptr, 0};
 
+// GroupNorm statistics from the NEXT adap_conv2d_nhwc call's epilogue (one shot, same thread)
+static thread_local float* g_gn_next = nullptr;
+static thread_local int g_gn_next_cpg = 0;
+static thread_local int g_gn_last_chunks = 0;
+extern "C" int adap_conv2d_next_gn_partial(float* partial, int channels_per_group) {
+    ADAP_REQUIRE(!partial || (channels_per_group > 0 && ((uintptr_t)partial % 8) == 0), ADAP_ERR_SHAPE,
+                 "conv2d_next_gn_partial: cpg %d", channels_per_group);
+    g_gn_next = partial;
+    g_gn_next_cpg = channels_per_group;
+    return ADAP_OK;
+}
+extern "C" int adap_conv2d_last_gn_chunks(void) { return g_gn_last_chunks; }
+
 static thread_local int g_force_kind = 0, g_force_bn = 0;
 extern "C" int adap_conv2d_debug_force(int kind, int bn) {
     ADAP_REQUIRE(kind >= 0 && kind <= 3 && (bn == 0 || bn == 64 || bn == 128 || bn == 160), ADAP_ERR_UNSUPPORTED,
@@ -1624,6 +1713,12 @@ extern "C" int adap_conv2d_nhwc(
     p.ktiles_per_tap = (Cin + BK - 1) / BK;
     p.ktiles_total = KH * KW * p.ktiles_per_tap;
     p.epi = g_epi_ext.epi; p.z16 = g_epi_ext.z16; p.ldz16 = g_epi_ext.ldz16; p.h16 = g_epi_ext.h16; p.ldh16 = g_epi_ext.ldh16;
+    float* const gn_next = g_gn_next;            // one shot: consumed by this call whatever kernel it dispatches to
+    const int gn_next_cpg = g_gn_next_cpg;
+    g_gn_next = nullptr;
+    g_gn_last_chunks = 0;
+    p.gn_part = nullptr;
+    p.gn_cpg = 0;
     const bool halo = choose_halo(Hin, Win, Hout, Wout, Cin, Cout, KH, KW, stride, pad, up, x_dtype, nbatch);
     const bool big = !halo && choose_big(M, Cout, p.ktiles_total, x_dtype, nbatch, up);
     const int ksplit_units = halo ? p.ktiles_per_tap : p.ktiles_total;      // the halo kernel splits over Cin slices
@@ -1726,6 +1821,13 @@ extern "C" int adap_conv2d_nhwc(
             if (halo_shape(Hin, Win) == 1) return launch_win32<128, true>(p, s);
             return launch_win32<128, false>(p, s);
         }
+        // GroupNorm statistics in the epilogue: unsplit 128-wide tiles whose channel quads do not straddle groups
+        if (gn_next && p.ksplit == 1 && bn == 128 && p.epi == 0 && Cout % 128 == 0 && gn_next_cpg * 32 == Cout &&
+            gn_next_cpg % 4 == 0 && 128 % gn_next_cpg == 0) {
+            p.gn_part = gn_next;
+            p.gn_cpg = gn_next_cpg;
+            g_gn_last_chunks = Hin * Win / 64;
+        }
         if (halo_shape(Hin, Win) == 1) {
             if (bn == 160) return launch_halo<160, true>(p, s);
             return launch_halo<128, true>(p, s);
@@ -1733,9 +1835,21 @@ extern "C" int adap_conv2d_nhwc(
         if (bn == 160) return launch_halo<160, false>(p, s);
         return launch_halo<128, false>(p, s);
     }
+    // GroupNorm statistics in the epilogue (adap_conv2d_next_gn_partial): 128-channel tiles of an unsplit, unbatched call whose
+    // pixel tiles do not straddle images and whose channel quads do not straddle groups
+    const bool gn_ok = gn_next && p.ksplit == 1 && nbatch == 1 && bn == 128 && p.epi == 0 && Cout % 128 == 0 &&
+                       gn_next_cpg * 32 == Cout && gn_next_cpg % 4 == 0 && 128 % gn_next_cpg == 0;
+    auto arm_gn = [&](int tile_px) {
+        if (gn_ok && (Hout * Wout) % tile_px == 0) {
+            p.gn_part = gn_next;
+            p.gn_cpg = gn_next_cpg;
+            g_gn_last_chunks = Hout * Wout / 64;
+        }
+    };
     if (use_big) {
         g_last_variant = 2000 + bn;
         if (bn == 160) return launch_ring<256, 160, 3>(p, s);
+        arm_gn(256);
         return launch_ring<256, 128, 3>(p, s);
     }
     // few workgroups (< 1.2 per CU): the 4-deep LDS-DMA ring hides the K-loop latency that occupancy cannot
@@ -1743,10 +1857,11 @@ extern "C" int adap_conv2d_nhwc(
         (long)p.ntiles_m * p.ntiles_n * p.ksplit <= 300) {
         g_last_variant = 3000 + bn;
         if (bn == 160) return launch_ring<128, 160, 4>(p, s);
-        if (bn == 128) return launch_ring<128, 128, 4>(p, s);
+        if (bn == 128) { arm_gn(128); return launch_ring<128, 128, 4>(p, s); }
         return launch_ring<128, 64, 4>(p, s);
     }
     g_last_variant = (x_dtype == 0 ? 0 : 1000) + bn;
+    if (bn == 128) arm_gn(BM);
     if (x_dtype == 0) {
         if (bn == 160) return launch<160, true>(p, nbatch, s);
         if (bn == 128) return launch<128, true>(p, nbatch, s);

@@ -183,7 +183,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
     const int tid = threadIdx.x;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cpg = C / GN_G;
-    {
+    if (stats_chunks == 0) {                    // statistics already finished (gn_finish_kernel): mean_out / rstd_out are inputs
+        if (tid < GN_G) {
+            lmean[tid] = mean_out[b * GN_G + tid];
+            lrstd[tid] = rstd_out[b * GN_G + tid];
+        }
+    } else {
         double su, sq;
         gn_finish_partials(partial, b, stats_chunks, tid, &su, &sq);
         if ((tid & 7) == 0) {
@@ -254,6 +259,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Statistics that came out of the producing contraction's epilogue (adap_conv2d_next_gn_partial): up to 1024 tile records
+// per sample.  Finished ONCE here -- 16 threads per (group, statistic) walk the records in a fixed order in fp64 -- instead
+// of by every apply workgroup (256 of them would each re-read 256 KB).  grid B, block 1024.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gn_finish_kernel(const float* __restrict__ partial, int nchunks, double count, float eps,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double acc[16][64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int v = tid & 63, part = tid >> 6;                        // v = group * 2 + statistic
+    const float* pp = partial + (size_t)b * nchunks * 64 + v;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;                   // four loads in flight per thread (a fixed order all the same)
+    int c = part;
+    for (; c + 48 < nchunks; c += 64) {
+        const float x0 = pp[(size_t)c * 64], x1 = pp[(size_t)(c + 16) * 64], x2 = pp[(size_t)(c + 32) * 64], x3 = pp[(size_t)(c + 48) * 64];
+        a0 += (double)x0; a1 += (double)x1; a2 += (double)x2; a3 += (double)x3;
+    }
+    for (; c < nchunks; c += 16) a0 += (double)pp[(size_t)c * 64];
+    acc[part][v] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (tid < GN_G) {
+        double su = 0.0, sq = 0.0;
+        for (int k = 0; k < 16; ++k) { su += acc[k][2 * tid]; sq += acc[k][2 * tid + 1]; }
+        const double mean = su / count;
+        double var = sq / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_out[b * GN_G + tid] = (float)mean;
+        rstd_out[b * GN_G + tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // single-launch path (defined below the two-pass kernels): returns 1 when it took the call
 static int gn_fused_fwd_try(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, float* y32, long ldy32,
                             void* y16, long ldy16, float* mean, float* rstd, float* workspace, int* sync, int B, int HW, int C,
@@ -312,6 +348,30 @@ extern "C" int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const fl
                            rpc, y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd);
     }
     return adap_check_launch("groupnorm_fwd");
+}
+
+extern "C" int adap_groupnorm_fwd_stats(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta,
+                                        float* y32, long ldy32, void* y16, long ldy16, float* mean, float* rstd,
+                                        const float* partial, int stats_chunks, int B, int HW, int C, float eps, int act,
+                                        void* stream) {
+    ADAP_REQUIRE(x && gamma && beta && mean && rstd && partial && (y32 || y16), ADAP_ERR_SHAPE, "groupnorm_fwd_stats: null pointer");
+    ADAP_REQUIRE(x_dtype == 0 || x_dtype == 1, ADAP_ERR_UNSUPPORTED, "groupnorm_fwd_stats: x_dtype %d", x_dtype);
+    ADAP_REQUIRE(C % GN_G == 0 && C % 8 == 0 && C <= 256 * 8 * GN_MAXSLOT, ADAP_ERR_SHAPE, "groupnorm_fwd_stats: C=%d", C);
+    ADAP_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0, ADAP_ERR_ALIGN, "groupnorm_fwd_stats: x alignment");
+    ADAP_REQUIRE(!y32 || (ldy32 % 4 == 0 && ((uintptr_t)y32 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd_stats: y32 alignment");
+    ADAP_REQUIRE(!y16 || (ldy16 % 8 == 0 && ((uintptr_t)y16 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd_stats: y16 alignment");
+    ADAP_REQUIRE(B > 0 && HW > 0 && stats_chunks > 0, ADAP_ERR_SHAPE, "groupnorm_fwd_stats: empty");
+    int n, rpc;
+    gn_chunks(HW, C, &n, &rpc);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(1024), 0, s, partial, stats_chunks, (double)(C / GN_G) * HW, eps, mean, rstd);
+    if (x_dtype == 1)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, gamma, beta, partial, 0, eps, act, rpc,
+                           y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(n, B), dim3(256), 0, s, x, ldx, HW, C, gamma, beta, partial, 0, eps, act, rpc,
+                           y32, ldy32, (uint16_t*)y16, ldy16, mean, rstd);
+    return adap_check_launch("groupnorm_fwd_stats");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 // points (adap_conv2d_nhwc, adap_groupnorm_fwd, ...), in the order and with the arguments of the Python mirror
 // (ldm/modules/diffusionmodules/model.py::Encoder.forward_nhwc), so the two produce the same bits.
 #include "common.h"
+#include <stdlib.h>
 
 #include <string.h>
 
@@ -38,7 +39,15 @@ struct Arena {                      // carves the caller's workspace; dry = size
 struct Ctx {
     int B; void* sync; hipStream_t s;
     float* gn_ws; float* mean; float* rstd; float* sk_ws;
+    float* partA; float* partB;       // GroupNorm statistics records out of conv1's / conv2's epilogue (resblock)
 };
+
+// a conv3x3's output this large gets its GroupNorm statistics from the conv's own epilogue (the Python mirror's rule:
+// model.py ResnetBlock.forward) -- below it the statistics pass is cheap and the two extra launches of the records' finish are not
+bool stats_from_epilogue(int B, int H, int W, int C) {
+    static const bool off = [] { const char* e = getenv("ADAP_GN_EPILOGUE_STATS"); return e && atoi(e) == 0; }();   // A/B switch
+    return !off && (long)B * H * W * C >= (1L << 24) && (H * W) % 256 == 0 && C % 32 == 0;
+}
 
 // y = conv(x) [+ bias] [+ residual]; f32 and / or bf16 output (ops.conv2d)
 int conv(const Ctx& c, const void* x, int x_bf16, int H, int W, int Cin, const ConvW& w, int Cout, int K, int stride, int pad,
@@ -46,6 +55,29 @@ int conv(const Ctx& c, const void* x, int x_bf16, int H, int W, int Cin, const C
     return adap_conv2d_nhwc(x, x_bf16 ? 1 : 0, Cin, w.w, w.b, nullptr, 0, residual, residual ? Cout : 0, y32, y32 ? Cout : 0, y16,
                             y16 ? Cout : 0, c.B, H, W, Cin, Ho, Wo, Cout, K, K, stride, pad, 0, 1.0f, 0, c.sk_ws, 1, 0, 0, 0, 0,
                             (void*)c.s);
+}
+
+// conv3x3 stride 1 whose output feeds a GroupNorm: asks for the statistics records; *chunks = records per image (0: none)
+int conv_stats_any(const Ctx& c, const void* x, int x_bf16, int H, int W, int Cin, const ConvW& w, int Cout, int stride, int pad,
+                   int Ho, int Wo, const float* residual, float* y32, void* y16, float* part, int* chunks) {
+    *chunks = 0;
+    const bool want = stats_from_epilogue(c.B, Ho, Wo, Cout);
+    int rc;
+    if (want && (rc = adap_conv2d_next_gn_partial(part, Cout / 32))) return rc;
+    if ((rc = conv(c, x, x_bf16, H, W, Cin, w, Cout, 3, stride, pad, Ho, Wo, residual, y32, y16))) return rc;
+    if (want) *chunks = adap_conv2d_last_gn_chunks();
+    return ADAP_OK;
+}
+
+int conv_stats(const Ctx& c, const void* x, int H, int W, int Cin, const ConvW& w, int Cout, const float* residual, float* y32,
+               void* y16, float* part, int* chunks) {
+    return conv_stats_any(c, x, 1, H, W, Cin, w, Cout, 1, 1, H, W, residual, y32, y16, part, chunks);
+}
+
+int gn_stats(const Ctx& c, const void* x, int x_bf16, int HW, int C, const NormW& n, int act, void* y16, const float* part,
+             int chunks) {
+    return adap_groupnorm_fwd_stats(x, x_bf16 ? 1 : 0, C, n.g, n.b, nullptr, 0, y16, C, c.mean, c.rstd, part, chunks, c.B, HW, C,
+                                    1e-6f, act, (void*)c.s);
 }
 
 int gn(const Ctx& c, const void* x, int x_bf16, int HW, int C, const NormW& n, int act, void* y16) {
@@ -64,18 +96,23 @@ ResW res_w(Cursor& cur, int cin, int cout) {
 }
 
 // ResnetBlock.forward (model.py:108-142): x f32 [B,H,W,cin] -> y f32 [B,H,W,cout]; a16 / h16 bf16 scratch, skip f32 scratch
+// *xc: statistics records per image that the producer of x left in c.partB (0: none); on return, those of y
 int resblock(const Ctx& c, const ResW& w, const float* x, int H, int W, int cin, int cout, void* a16, void* h16, float* skip,
-             float* y) {
-    int rc;
-    if ((rc = gn(c, x, 0, H * W, cin, w.n1, 1, a16))) return rc;
-    if ((rc = conv(c, a16, 1, H, W, cin, w.c1, cout, 3, 1, 1, H, W, nullptr, nullptr, h16))) return rc;     // block-internal: bf16
-    if ((rc = gn(c, h16, 1, H * W, cout, w.n2, 1, a16))) return rc;
+             float* y, int* xc) {
+    int rc, hc = 0;
+    if (*xc > 0) rc = gn_stats(c, x, 0, H * W, cin, w.n1, 1, a16, c.partB, *xc);
+    else rc = gn(c, x, 0, H * W, cin, w.n1, 1, a16);
+    if (rc) return rc;
+    if ((rc = conv_stats(c, a16, H, W, cin, w.c1, cout, nullptr, nullptr, h16, c.partA, &hc))) return rc;   // block-internal: bf16
+    if (hc > 0) rc = gn_stats(c, h16, 1, H * W, cout, w.n2, 1, a16, c.partA, hc);
+    else rc = gn(c, h16, 1, H * W, cout, w.n2, 1, a16);
+    if (rc) return rc;
     const float* sk = x;
     if (w.has_nin) {
         if ((rc = conv(c, x, 0, H, W, cin, w.nin, cout, 1, 1, 0, H, W, nullptr, skip, nullptr))) return rc;
         sk = skip;
     }
-    return conv(c, a16, 1, H, W, cout, w.c2, cout, 3, 1, 1, H, W, sk, y, nullptr);
+    return conv_stats(c, a16, H, W, cout, w.c2, cout, sk, y, nullptr, c.partB, xc);
 }
 
 struct Plan {                       // what the configuration implies
@@ -154,6 +191,8 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
     void* h16 = ar.take((size_t)b16_max * 2);
     c.gn_ws = (float*)ar.take((size_t)(gn_ws > 0 ? gn_ws : 1) * 4);
     c.sk_ws = (float*)ar.take((size_t)(sk_ws > 0 ? sk_ws : 1) * 4);
+    c.partA = (float*)ar.take(((size_t)px0 / 64 + 1) * 64 * 4);           // [B][H * W / 64][32][2]: the full-resolution level
+    c.partB = (float*)ar.take(((size_t)px0 / 64 + 1) * 64 * 4);
     c.mean = (float*)ar.take((size_t)B * 32 * 4);
     c.rstd = (float*)ar.take((size_t)B * 32 * 4);
     const int hl = H >> (p.levels - 1), wl = W >> (p.levels - 1);
@@ -173,7 +212,8 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
     // ---- conv_in on the 3 -> 8 channel padded bf16 image (model.py:426, 468)
     ConvW cin_w = conv_w(cur);
     if ((rc = adap_pad_cast_bf16(x_hwc, 3, 3, x16, 8, 8, px0, (void*)s))) return rc;
-    if ((rc = conv(c, x16, 1, H, W, 8, cin_w, p.ch, 3, 1, 1, H, W, nullptr, hA, nullptr))) return rc;
+    int xc = 0;                    // statistics records per image the producer of h left in c.partB (0: none)
+    if ((rc = conv_stats_any(c, x16, 1, H, W, 8, cin_w, p.ch, 1, 1, H, W, nullptr, hA, nullptr, c.partB, &xc))) return rc;
     float* h = hA;
     float* other = hB;
     int hh = H, ww = W, cin = p.ch;
@@ -181,13 +221,14 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
         int cout = p.ch * p.mult[l];
         for (int r = 0; r < p.nres; ++r) {
             ResW w = res_w(cur, cin, cout);
-            if ((rc = resblock(c, w, h, hh, ww, cin, cout, a16, h16, hS, other))) return rc;
+            if ((rc = resblock(c, w, h, hh, ww, cin, cout, a16, h16, hS, other, &xc))) return rc;
             float* t = h; h = other; other = t;
             cin = cout;
         }
         if (l != p.levels - 1) {       // Downsample: F.pad(0,1,0,1) + conv3x3 stride 2 pad 0 (model.py:151-178)
             ConvW dw = conv_w(cur);
-            if ((rc = conv(c, h, 0, hh, ww, cin, dw, cin, 3, 2, 0, hh / 2, ww / 2, nullptr, other, nullptr))) return rc;
+            if ((rc = conv_stats_any(c, h, 0, hh, ww, cin, dw, cin, 2, 0, hh / 2, ww / 2, nullptr, other, nullptr, c.partB, &xc)))
+                return rc;
             float* t = h; h = other; other = t;
             hh /= 2; ww /= 2;
         }
@@ -195,14 +236,17 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
     // ---- mid: block_1, AttnBlock (model.py:179-242), block_2
     {
         ResW w = res_w(cur, cin, cin);
-        if ((rc = resblock(c, w, h, hh, ww, cin, cin, a16, h16, hS, other))) return rc;
+        if ((rc = resblock(c, w, h, hh, ww, cin, cin, a16, h16, hS, other, &xc))) return rc;
         float* t = h; h = other; other = t;
     }
     {
         const int C = cin;
         NormW an = norm_w(cur);
         ConvW wqkv = conv_w(cur), wproj = conv_w(cur);
-        if ((rc = gn(c, h, 0, (int)N, C, an, 0, a16))) return rc;
+        if (xc > 0) rc = gn_stats(c, h, 0, (int)N, C, an, 0, a16, c.partB, xc);
+        else rc = gn(c, h, 0, (int)N, C, an, 0, a16);
+        if (rc) return rc;
+        xc = 0;                    // block_2's input comes out of proj_out: no records
         // (the 1x1 contractions see [1, B*N, 1, C])
         if ((rc = adap_conv2d_nhwc(a16, 1, C, wqkv.w, wqkv.b, nullptr, 0, nullptr, 0, nullptr, 0, qkv, 3 * C, 1, (int)(B * N), 1, C,
                                    (int)(B * N), 1, 3 * C, 1, 1, 1, 0, 0, 1.0f, 0, c.sk_ws, 1, 0, 0, 0, 0, (void*)s))) return rc;
@@ -224,13 +268,15 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
     }
     {
         ResW w = res_w(cur, cin, cin);
-        if ((rc = resblock(c, w, h, hh, ww, cin, cin, a16, h16, hS, other))) return rc;
+        if ((rc = resblock(c, w, h, hh, ww, cin, cin, a16, h16, hS, other, &xc))) return rc;
         float* t = h; h = other; other = t;
     }
     // ---- norm_out + SiLU, conv_out, quant_conv (1x1), posterior sample
     NormW no = norm_w(cur);
     ConvW co = conv_w(cur), qcw = conv_w(cur);
-    if ((rc = gn(c, h, 0, (int)N, cin, no, 1, a16))) return rc;
+    if (xc > 0) rc = gn_stats(c, h, 0, (int)N, cin, no, 1, a16, c.partB, xc);
+    else rc = gn(c, h, 0, (int)N, cin, no, 1, a16);
+    if (rc) return rc;
     if ((rc = conv(c, a16, 1, hh, ww, cin, co, p.zc2, 3, 1, 1, hh, ww, nullptr, hout, nullptr))) return rc;
     if ((rc = adap_conv2d_nhwc(hout, 0, p.zc2, qcw.w, qcw.b, nullptr, 0, nullptr, 0, moments, p.emb2, nullptr, 0, 1, (int)(B * N), 1, p.zc2,
                                (int)(B * N), 1, p.emb2, 1, 1, 1, 0, 0, 1.0f, 0, c.sk_ws, 1, 0, 0, 0, 0, (void*)s))) return rc;

@@ -33,8 +33,18 @@ class Downsample(nn.Module):
     def forward(self, x):
         B, H, W, C = x.shape
         pk = self._wc.get("conv", self.conv.weight, self.conv.bias)
-        y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 2, 0, out_hw=(H // 2, W // 2), bias=pk.bias)
+        # (its output is the next level's first GroupNorm input: statistics from the epilogue when it is large, as in ResnetBlock)
+        y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 2, 0, out_hw=(H // 2, W // 2), bias=pk.bias,
+                          gn_stats=gn_stats_from_epilogue(B, H // 2, W // 2, C))
         return y
+
+
+def gn_stats_from_epilogue(B, H, W, C):
+    """A conv output this large (the 128^2 ... 512^2 levels: 64-537 MB) gets its GroupNorm statistics from the conv's own epilogue
+    (``ops.conv2d(gn_stats=True)``: the records ride on the output tensor and ``groupnorm_fwd`` skips its statistics pass); below it
+    the pass is cheap and the records' finish launch is not.  The same rule as csrc/vae.hip ``stats_from_epilogue``, so that
+    ``adap_vae_encode`` and this mirror stay bit-identical."""
+    return B * H * W * C >= (1 << 24) and (H * W) % 256 == 0 and C % 32 == 0
 
 
 class ResnetBlock(nn.Module):
@@ -58,16 +68,18 @@ class ResnetBlock(nn.Module):
         wc = self._wc
         c1 = wc.get("conv1", self.conv1.weight, self.conv1.bias)
         c2 = wc.get("conv2", self.conv2.weight, self.conv2.bias)
+        B, H, W, _ = x.shape
+        big = gn_stats_from_epilogue(B, H, W, self.out_channels)
         _, a1, _, _ = ops.groupnorm_fwd(x, self.norm1.weight, self.norm1.bias, 1e-6, 1)
         # the tensor between conv1 and norm2 is block-internal: bf16
-        _, h = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, out_f32=False, out_bf16=True)
+        _, h = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, out_f32=False, out_bf16=True, gn_stats=big)
         _, a2, _, _ = ops.groupnorm_fwd(h, self.norm2.weight, self.norm2.bias, 1e-6, 1)
         if self.in_channels != self.out_channels:
             sk = wc.get("nin", self.nin_shortcut.weight, self.nin_shortcut.bias)
             skip, _ = ops.conv2d(x, sk.fwd, sk.O4, 1, bias=sk.bias)
         else:
             skip = x
-        y, _ = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip)
+        y, _ = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip, gn_stats=big)
         return y
 
 
@@ -164,7 +176,7 @@ class Encoder(nn.Module):
         wc = self._wc
         cin = wc.get("conv_in", self.conv_in.weight, self.conv_in.bias)
         x16 = ops.pad_cast_bf16(x_hwc.contiguous().float(), cin.I8)
-        h, _ = ops.conv2d(x16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias)
+        h, _ = ops.conv2d(x16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias, gn_stats=gn_stats_from_epilogue(*x16.shape[:3], cin.O4))
         for i_level in range(self.num_resolutions):
             for blk in self.down[i_level].block:
                 h = blk(h)
@@ -196,7 +208,8 @@ class Upsample(nn.Module):
 
     def forward(self, x):
         pk = self._wc.get("conv", self.conv.weight, self.conv.bias)
-        y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias)
+        B, H, W, C = x.shape
+        y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias, gn_stats=gn_stats_from_epilogue(B, 2 * H, 2 * W, C))
         return y
 
 

@@ -138,10 +138,16 @@ class PackedConv:
         self.w_f32 = None
 
 
+GN_STATS_ATTR = "_adap_gn_stats"          # (partial records, records per image) a contraction's epilogue left on its output
+
+
 def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=None, chan_add=None, residual=None,
-           out_f32=True, out_bf16=False, alpha=1.0, ksplit=0, y32=None, y16=None):
+           out_f32=True, out_bf16=False, alpha=1.0, ksplit=0, y32=None, y16=None, gn_stats=False):
     """x [B,H,W,Cin] (f32 / bf16) * w_packed [KH*KH][Cout][Cin] -> (y32, y16), each [B,Ho,Wo,Cout] or None.
-    Linear layers: pass x as [B, N, 1, Cin]."""
+    Linear layers: pass x as [B, N, 1, Cin].
+    ``gn_stats``: the output feeds a GroupNorm(32): ask the epilogue for its group statistics (``adap_conv2d_next_gn_partial``);
+    if the kernel the call dispatches to has that epilogue, the outputs carry them (``GN_STATS_ATTR``) and ``groupnorm_fwd``
+    skips its statistics pass."""
     assert x.dim() == 4
     B, H, W, Cin = x.shape
     _, ldx = _rows_ld(x)
@@ -181,9 +187,19 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
     if bias is not None:
         assert bias.dtype == F32 and bias.numel() >= Cout
     e0 = TIMER.start() if TIMER is not None else None
+    part = None
+    if gn_stats and Cout % 32 == 0 and (Ho * Wo) % 256 == 0:
+        part = torch.empty(B, Ho * Wo // 64, 32, 2, device=dev, dtype=F32)            # one record per 64 pixels and group
+        _lib.call("adap_conv2d_next_gn_partial", part.data_ptr(), Cout // 32)
     _lib.call("adap_conv2d_nhwc", x.data_ptr(), _dt(x), ldx, w_packed.data_ptr(), _ptr(bias), _ptr(chan_add), ld_ca,
               _ptr(residual), ldr, _ptr(y32), ldy32, _ptr(y16), ldy16, B, H, W, Cin, Ho, Wo, Cout, KH, KH, stride, pad,
               up, float(alpha), ksplit, _ptr(ws), 1, 0, 0, 0, 0, _stream())
+    if part is not None:
+        chunks = _lib.call_long("adap_conv2d_last_gn_chunks")
+        if chunks > 0:
+            for y in (y32, y16):
+                if y is not None:
+                    setattr(y, GN_STATS_ATTR, (part, chunks))
     if e0 is not None:
         # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
         v = _lib.call_long("adap_conv2d_last_variant")
@@ -316,9 +332,16 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     y32 = torch.empty(x.shape, device=x.device, dtype=F32) if out_f32 else None
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     e0 = TIMER.start() if TIMER is not None else None
-    _lib.call("adap_groupnorm_fwd", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
-              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), gn_sync_buffer(x.device), B, HW, C, float(eps),
-              int(act), _stream())
+    stats = getattr(x, GN_STATS_ATTR, None)          # left by the producing contraction's epilogue (conv2d(gn_stats=True))
+    if stats is not None:
+        part, chunks = stats
+        _lib.call("adap_groupnorm_fwd_stats", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C,
+                  _ptr(y16), C, mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), chunks, B, HW, C, float(eps), int(act),
+                  _stream())
+    else:
+        _lib.call("adap_groupnorm_fwd", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C, _ptr(y16), C,
+                  mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), gn_sync_buffer(x.device), B, HW, C, float(eps),
+                  int(act), _stream())
     if e0 is not None:
         # algorithmic bytes: read x once (4 B) + write y (2 B bf16 / 4 B f32) per element
         TIMER.stop("groupnorm_fwd", float(x.numel()) * (x.element_size() + (4 if out_f32 else 0) + (2 if out_bf16 else 0)), e0)

@@ -86,6 +86,17 @@ int adap_conv2d_set_clock_probe(void* buf);
  * kind 0 = automatic (production), 1 = conv_gemm_kernel, 2 = conv_gemm_ring_kernel<256,.,3>, 3 = conv_gemm_ring_kernel<128,.,4>;
  * bn 0 = automatic, else the channel tile (64 / 128 / 160).  A combination the problem does not admit is ignored. */
 int adap_conv2d_debug_force(int kind, int bn);
+/* GroupNorm statistics of a contraction's OUTPUT from its epilogue (model.py:34-40 GroupNorm(32) after a conv3x3, openaimodel.py
+ * normalization(): the statistics pass over the tensor -- 4 or 2 bytes per element of HBM reads on the VAE's 134-537 MB
+ * tensors -- disappears).  adap_conv2d_next_gn_partial arms the calling thread's NEXT adap_conv2d_nhwc call (one shot):
+ * partial f32 [B][Hout * Wout / 64][32][2] (one record per 64 output pixels -- a wave's share of a tile -- and group),
+ * channels_per_group = Cout / 32 in {4, 8, 16}.  After that call adap_conv2d_last_gn_chunks() is the number of records per image
+ * it wrote (Hout * Wout / 64), or 0 if the call could not provide them (split-K, a 64- or 160-wide channel tile, Cout % 128 != 0,
+ * an image that is not a whole number of pixel tiles) -- the caller then runs adap_groupnorm_fwd as usual.  Records hold (sum,
+ * sum of squares) of the values the epilogue stores, accumulated in a fixed order (bit-reproducible); for a bf16-only output they
+ * are those of the f32 values before the rounding. */
+int adap_conv2d_next_gn_partial(float* partial, int channels_per_group);
+int adap_conv2d_last_gn_chunks(void);
 
 /* FeedForward with its GEGLU fused into the two contractions (attention.py:32-59: proj -> chunk -> a * gelu(gate) -> Linear).
  * The 8C pre-activation h is stored in a PERMUTED channel order -- 16 value channels, then their 16 gate channels, then the next
@@ -126,6 +137,12 @@ int adap_groupnorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma,
                        float* y32, long ldy32, void* y16, long ldy16,
                        float* mean, float* rstd, float* workspace, void* sync,
                        int B, int HW, int C, float eps, int act, void* stream);
+/* The same normalisation from statistics records a contraction's epilogue left (adap_conv2d_next_gn_partial): one small
+ * launch finishes the stats_chunks records per sample into mean / rstd (fp64, fixed order), then the apply pass of the
+ * two-launch form runs; no statistics pass over x. */
+int adap_groupnorm_fwd_stats(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta,
+                             float* y32, long ldy32, void* y16, long ldy16, float* mean, float* rstd,
+                             const float* partial, int stats_chunks, int B, int HW, int C, float eps, int act, void* stream);
 /* dx (f32 and/or bf16) from dy (f32 or bf16).  accumulate: dx32 = dx + add_src (the residual-stream gradient
  * coming down the skip path); add_src NULL = dx32 itself (in place), otherwise any f32 tensor of the same shape,
  * so the block's incoming gradient need not be cloned first.  dx16 is the bf16 copy of what dx32 receives. */

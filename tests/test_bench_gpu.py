@@ -27,7 +27,7 @@ def run_bench(*args, timeout=600):
 
 
 def test_bench_line_live_one_gpu():
-    d = run_bench("--steps", "3", "--warmup", "2", *LEGS_OFF)
+    d = run_bench("--steps", "3", "--warmup", "2", "--no-cpu-k8", *LEGS_OFF)
     check_bench_line(d, n_gpus=1)
     assert "roofline" in d and "cpu_baseline" in d
     assert d["steps"] == 3 and d["warmup"] == 2 and d["value"] > 20

@@ -225,6 +225,54 @@ def test_groupnorm_single_launch_path(B, C, H, rows_fwd, rows_bwd):
     assert not ops.gn_sync_poisoned()
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,bf16_out,kind", [
+    (2, 64, 64, 128, 128, True, False, "halo"), (3, 32, 64, 64, 256, False, True, "halo"),
+    (4, 64, 64, 256, 512, True, False, "halo"), (4, 128, 128, 128, 128, False, True, "halo"),
+    (4, 256, 256, 128, 128, False, False, "down"),        # f32 operand, stride 2: conv_gemm_kernel<128, true>
+    (4, 256, 256, 8, 128, False, False, "cin8"),          # the VAE's conv_in: the 256-row ring kernel
+    (4, 64, 64, 128, 128, False, False, "up")])           # nearest x2 + conv (the decoder's Upsample)
+def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, Cin, Cout, res, bf16_out, kind):
+    """``conv2d(gn_stats=True)``: the contraction's epilogue leaves (sum, sum of squares) records per tile and group, and
+    ``groupnorm_fwd`` on that output takes mean / rstd from them instead of reading the tensor a second time.  The conv's own
+    output must not change by a bit; the statistics must be those of the two-pass kernels up to summation order (for a bf16-only
+    output: up to the rounding the records do not see); the records are bit-reproducible."""
+    from adaprompt_amd import _lib
+    x = bf(rnd(B, H, W, Cin, seed=1))
+    x = x if kind == "down" else x.to(torch.bfloat16)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    bias = rnd(Cout, seed=3)
+    Ho, Wo = (H // 2, W // 2) if kind == "down" else ((2 * H, 2 * W) if kind == "up" else (H, W))
+    r = (rnd(B, Ho, Wo, Cout, seed=4) + 3.0) if res else None        # a mean well away from 0: sq/n - mean^2 must survive it
+    pk = ops.PackedConv(w, bias)
+    gw, gb = rnd(Cout, seed=5) + 1.0, rnd(Cout, seed=6)
+    geo = {"halo": dict(stride=1, pad=1), "cin8": dict(stride=1, pad=1), "down": dict(stride=2, pad=0, out_hw=(Ho, Wo)),
+           "up": dict(stride=1, pad=1, up=1)}[kind]
+
+    def run(stats):
+        y32, y16 = ops.conv2d(x, pk.fwd, pk.O4, 3, bias=pk.bias, residual=r, out_f32=not bf16_out, out_bf16=bf16_out,
+                              gn_stats=stats, **geo)
+        y = y16 if bf16_out else y32
+        _, a16, mean, rstd = ops.groupnorm_fwd(y, gw, gb, 1e-6, 1)
+        return y, a16, mean, rstd, getattr(y, ops.GN_STATS_ATTR, None)
+    y0, a0, m0, r0, s0 = run(False)
+    y1, a1, m1, r1, s1 = run(True)
+    variant = _lib.call_long("adap_conv2d_last_variant")
+    assert variant == {"halo": 4128, "down": 128, "cin8": 2128, "up": 1128}[kind], variant
+    assert s0 is None and s1 is not None and s1[1] == Ho * Wo // 64
+    assert torch.equal(y0, y1)
+    tol = 2e-3 if bf16_out else 2e-5
+    assert float((m1 - m0).abs().max()) < tol * float(m0.abs().max() + 1) and rel(r1, r0) < tol, (m0, m1, r0, r1)
+    assert rel(a1.float(), a0.float()) < (4e-3 if bf16_out else 1e-4)
+    _, _, m2, r2, s2 = run(True)
+    assert torch.equal(s1[0], s2[0]) and torch.equal(m1, m2) and torch.equal(r1, r2)
+    for _ in range(4):                    # (the output itself stays bit-reproducible with the statistics epilogue in place)
+        assert torch.equal(run(True)[0], y0)
+    # a kernel without that epilogue (a 160-wide channel tile) leaves no records and the normalisation falls back to its own pass
+    pk1 = ops.PackedConv(rnd(320, Cin, 1, 1, seed=7, scale=Cin ** -0.5), None)
+    y32, _ = ops.conv2d(x.to(torch.bfloat16), pk1.fwd, pk1.O4, 1, gn_stats=True)
+    assert getattr(y32, ops.GN_STATS_ATTR, None) is None and _lib.call_long("adap_conv2d_last_gn_chunks") == 0
+
+
 def test_groupnorm_single_launch_only_on_one_stream():
     """the workgroups of a single-launch GroupNorm wait for each other, so only ONE stream per device may issue them (two
     such kernels in flight could each hold part of the chip and wait for the rest): the default stream takes that path, a

@@ -548,8 +548,8 @@ def test_arc2face_distill_step_vs_oracle():
     assert abs(float(loss) - float(loss_s)) / float(loss_s) < LOSS_TOL / 5
     assert rel_err(ctx_hip.grad, ctx_seq.grad) < 5e-3
     for a, b in zip(aux["model_outputs_per_step"], outs_s):
-        assert rel_err(a.detach(), b.detach()) < EPS_TOL / 4          # (measured 5.1e-3: the batch of 6 takes the ping-pong
-        #                                                                 attention kernel at 64x64, the batches of 2 do not)
+        assert rel_err(a.detach(), b.detach()) < 8e-3                 # (measured 4.6e-3 ... 5.1e-3: the batch of 6 and the batches of
+        #                                                                 2 get different tile / split-K plans and attention kernels)
     lr_seq = float(loss_s)
     outs = aux["model_outputs_per_step"]
     npred, px0, nz, ts = aux["teacher"]
@@ -697,18 +697,19 @@ def test_cpu_tensor_fails_loudly():
              extra_info={"use_layerwise_context": True, "use_conv_attn_kernel_size": -1})
 
 
-def test_vae_encode_single_c_entry_equals_the_python_sequencing():
+@pytest.mark.parametrize("ch,B,H", [(32, 3, 128), (128, 2, 256)])
+def test_vae_encode_single_c_entry_equals_the_python_sequencing(ch, B, H):
     """``adap_vae_encode`` (vae_encode(x, masks, weights*, noise, z)) issues the launches of the first stage's
     encode from host code inside the library: bit-identical to the Python mirror issuing them one by one, with the fg / bg
-    mask of the mid attention, and the scaled posterior sample."""
+    mask of the mid attention, and the scaled posterior sample.  The second case (full channel widths, 16.8 M-element level-0
+    tensors) takes the GroupNorm statistics of the first level from the conv epilogues on both sides (``stats_from_epilogue``)."""
     from adaprompt_amd import ops
     from adaprompt_amd.ldm.util import instantiate_from_config
-    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=128)
+    vdd = dict(synth.SD15_VAE_DD, ch=ch, resolution=H)
     ae = instantiate_from_config({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}})
     sd = {k[len("first_stage_model."):]: v for k, v in synth.synthetic_vae_state_dict(vdd).items()}
     ae.load_state_dict(sd, strict=False)
     ae = ae.to(dev())
-    B, H = 3, 128
     x = synth.synthetic_input("vaec.x", (B, H, H, 3), 0, 0.5).clamp(-1, 1).to(dev())
     fg = ellipse_mask(B, H, H).to(dev())
     aug = border_mask(B, H, H, 9).to(dev())

@@ -57,7 +57,7 @@ def test_context_gradient_bf16_storage_vs_f32_storage(cfg, tag, gname, subs):
     assert abs(g0 - g1) < 3e-3 and abs(e0 - e1) < 2e-3            # storage format is not where the error comes from
 
 
-def test_training_trajectory_12_optimizer_steps_vs_oracle():
+def test_training_trajectory_6_optimizer_steps_vs_oracle():
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from adaprompt_amd.ldm.prodigy import Prodigy
     from adaprompt_amd.ldm.util import prodigy_linear_schedule
@@ -65,7 +65,7 @@ def test_training_trajectory_12_optimizer_steps_vs_oracle():
     from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
     from oracle import ldm_oracle as O
     from oracle.prodigy_oracle import ProdigyOracle, clip_grad_norm, linear_schedule_lrs
-    STEPS, ACC = 12, 1                # (accumulation over two micro-batches is covered by test_training_loop_prodigy_two_optimizer_steps_vs_oracle)
+    STEPS, ACC = 6, 1                # (accumulation over two micro-batches is covered by test_training_loop_prodigy_two_optimizer_steps_vs_oracle)
     ucfg = dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
     torch.manual_seed(3)
