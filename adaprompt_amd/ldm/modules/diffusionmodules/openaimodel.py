@@ -234,7 +234,10 @@ class UNetModel(nn.Module):
 
     # ---- flag plumbing kept from the reference (openaimodel.py:722-824) --------------------------------
     def _ca_modules(self):
-        """[(layer_idx, SpatialTransformer)] in layer order (input 0-11, middle 12, output 13-24)."""
+        """[(layer_idx, SpatialTransformer)] in layer order (input 0-11, middle 12, output 13-24); listed once."""
+        cached = self.__dict__.get("_ca_module_list")
+        if cached is not None:
+            return cached
         out, idx = [], 0
         for m in self.input_blocks:
             if len(m) > 1 and isinstance(m[1], SpatialTransformer):
@@ -246,6 +249,7 @@ class UNetModel(nn.Module):
             if len(m) > 1 and isinstance(m[1], SpatialTransformer):
                 out.append((idx, m[1]))
             idx += 1
+        self.__dict__["_ca_module_list"] = out
         return out
 
     def set_cross_attn_flags(self, ca_flag_dict=None, ca_layer_indices=None, trans_flag_dict=None,
@@ -278,12 +282,23 @@ class UNetModel(nn.Module):
 
         return apply(ca_flag_dict, ca_layer_indices, True), apply(trans_flag_dict, trans_layer_indices, False)
 
+    def _attn2_modules(self):
+        """the cross-attention modules of every SpatialTransformer, listed once (walking ``self.modules()`` -- ~1500 modules -- on
+        every forward cost 1 ms of host time per training step)."""
+        lst = self.__dict__.get("_attn2_list")
+        if lst is None:
+            lst = [m_.transformer_blocks[0].attn2 for m_ in self.modules() if isinstance(m_, SpatialTransformer)]
+            self.__dict__["_attn2_list"] = lst
+        return lst
+
     # ---- all ResBlock time-embedding projections in one launch -------------------------------------------
     def _resblocks(self):
-        for seq in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
-            for m in seq:
-                if isinstance(m, ResBlock):
-                    yield m
+        lst = self.__dict__.get("_resblock_list")
+        if lst is None:
+            lst = [m for seq in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks) for m in seq
+                   if isinstance(m, ResBlock)]
+            self.__dict__["_resblock_list"] = lst
+        return lst
 
     def _emb_projections(self, emb):
         blocks = list(self._resblocks())
@@ -368,10 +383,9 @@ class UNetModel(nn.Module):
         # ``capture_token_maps_only``: the caller will read the distillation layers through their token maps alone (the
         # recon iteration's fused regularisers): the dense attnscore / attn / q side outputs are then shape-only stand-ins
         tm_only = bool(ei.get("capture_token_maps_only")) and tok_w is not None
-        for m_ in self.modules():
-            if isinstance(m_, SpatialTransformer):
-                m_.transformer_blocks[0].attn2.token_weights = tok_w
-                m_.transformer_blocks[0].attn2.tokmap_only = tm_only
+        for a2 in self._attn2_modules():
+            a2.token_weights = tok_w
+            a2.tokmap_only = tm_only
 
         t_emb = timestep_embedding(timesteps, self.model_channels)
         te = self.time_embed

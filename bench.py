@@ -449,11 +449,24 @@ def main():
             finally:
                 ops.set_gn_single_launch_stream(device, torch.cuda.default_stream(device).cuda_stream)
             return e0.elapsed_time(e1) / (5 * n) * 1e-3
-        t_gn = graph_timed(lambda: ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1))
         dy16 = go.to(torch.bfloat16)
         _, _, gm_, gr_ = ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1)
-        t_gnb = graph_timed(lambda: ops.groupnorm_bwd(dy16, xr, gw, gb_, gm_, gr_, 1, out_f32=False, out_bf16=True))
         gn_bytes_f, gn_bytes_b = xr.numel() * (4 + 2), xr.numel() * (4 + 2 + 2)       # algorithmic: x once + y / x, dy once + dx
+
+        def gn_aggregate(xr=xr, dy16=dy16, gm_=gm_, gr_=gr_):
+            """The two graph-timed GroupNorm numbers.  Run AFTER every other leg: a hipGraph capture in the process (torch empties its
+            allocator cache and re-registers the generator for it) left config 2's mix 15 % slower when it came first (64 vs 75
+            img/s, bisected leg by leg)."""
+            t_gn = graph_timed(lambda: ops.groupnorm_fwd(xr, gw, gb_, 1e-5, 1))
+            t_gnb = graph_timed(lambda: ops.groupnorm_bwd(dy16, xr, gw, gb_, gm_, gr_, 1, out_f32=False, out_bf16=True))
+            return {"fwd_us": round(t_gn * 1e6, 1), "bwd_us": round(t_gnb * 1e6, 1),
+                    "algorithmic_bytes_fwd": int(gn_bytes_f), "algorithmic_bytes_bwd": int(gn_bytes_b),
+                    "fwd_GBps": round(gn_bytes_f / t_gn / 1e9, 1), "bwd_GBps": round(gn_bytes_b / t_gnb / 1e9, 1),
+                    "fwd_frac_of_hbm_peak": round(gn_bytes_f / t_gn / 8e12, 4),
+                    "bwd_frac_of_hbm_peak": round(gn_bytes_b / t_gnb / 8e12, 4),
+                    "note": "ONE launch each (norms.hip gn_fused_*: x read once, the sample's workgroups exchange their "
+                            "group partials through tagged 8-byte records inside the launch); in-kernel stamps: ~3 us load, "
+                            "~4 us hand-off (publish + sweep = memory-side round trips), ~1.2 us finish, ~1.2 us store issue"}
         aggregates = {
             "attention_self_64x64": {"shape": f"B{B} h8 N{N} d40", "fwd_us": round(t_f * 1e6, 1), "bwd_us": round(t_b * 1e6, 1),
                                      "fwd_tflops": round(fl / t_f / 1e12, 1), "bwd_tflops": round(2.5 * fl / t_b / 1e12, 1),
@@ -464,14 +477,7 @@ def main():
                                    "fwd_frac_of_hbm_peak": round(rb_bytes / t_rf / 8e12, 4),
                                    "fwd_tflops": round(rb_flops / t_rf / 1e12, 1),
                                    "fwd_frac_of_bf16_mfma_peak": round(rb_flops / t_rf / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
-            "groupnorm_silu_320_64x64": {"fwd_us": round(t_gn * 1e6, 1), "bwd_us": round(t_gnb * 1e6, 1),
-                                         "algorithmic_bytes_fwd": int(gn_bytes_f), "algorithmic_bytes_bwd": int(gn_bytes_b),
-                                         "fwd_GBps": round(gn_bytes_f / t_gn / 1e9, 1), "bwd_GBps": round(gn_bytes_b / t_gnb / 1e9, 1),
-                                         "fwd_frac_of_hbm_peak": round(gn_bytes_f / t_gn / 8e12, 4),
-                                         "bwd_frac_of_hbm_peak": round(gn_bytes_b / t_gnb / 8e12, 4),
-                                         "note": "ONE launch each (norms.hip gn_fused_*: x read once, the sample's workgroups exchange their "
-                                                 "group partials through tagged 8-byte records inside the launch); in-kernel stamps: ~3 us load, "
-                                                 "~4 us hand-off (publish + sweep = memory-side round trips), ~1.2 us finish, ~1.2 us store issue"},
+            "groupnorm_silu_320_64x64": gn_aggregate,          # (measured last, see gn_aggregate)
         }
         del qkv, o_, lse_, do_, xr, er, xg, go, dy16
 
@@ -704,6 +710,7 @@ def main():
         if cpu is not None:
             res["cpu_baseline"] = cpu
         if aggregates is not None:
+            aggregates["groupnorm_silu_320_64x64"] = aggregates["groupnorm_silu_320_64x64"]()
             res["north_star_aggregates"] = aggregates
         if distill is not None:
             res["config2_distill_mix"] = distill
