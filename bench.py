@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-batch", type=int, default=1, help="batch of the cpu_baseline sample (BASELINE.md section 3 unit: 4)")
     ap.add_argument("--no-cpu-k8", action="store_true", help="skip the second, 8-thread cpu_baseline sample")
+    ap.add_argument("--no-aggregates", action="store_true",
+                    help="skip the north star's isolated aggregates (tools/measure_round.sh: the rocprofv3 statistics of the "
+                         "dominant kernel then cover the training step's launches only, like the roofline's HIP events)")
     ap.add_argument("--no-ddim", action="store_true",
                     help="skip the extra leg that times config 5 (50-step DDIM at bs=8 with guidance + VAE decode)")
     ap.add_argument("--no-clock-probe", action="store_true",
@@ -386,7 +389,7 @@ def main():
     # north star asks for it; with 60 GFLOP per 49 MB the block sits far on the compute side of the ridge, so its
     # HBM fraction is structurally tiny (DESIGN.md section 3 / SURVEY 7 "roofline honesty").
     aggregates = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.no_aggregates:
         def timed(fn, n=50):
             for _ in range(20):          # past the first launches' clock ramp: the rate the kernel holds inside the step
                 fn()

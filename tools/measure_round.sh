@@ -4,7 +4,9 @@
 # -> gpurun_out/<tag>_stats/  rocprofv3 --kernel-trace --stats of the default bench command
 #    gpurun_out/<tag>_pmcF|W/ separate --pmc FETCH_SIZE / WRITE_SIZE passes (3 timed steps)
 #    gpurun_out/<tag>_bench_line.json  the plain bench line
-# Copy what is to be judged into profiles/ afterwards (tools/pmc_summary.py writes the traffic summary).
+# Copy what is to be judged into profiles/ afterwards; the traffic summary:
+#   python tools/pmc_summary.py --fetch gpurun_out/<tag>_pmcF --write gpurun_out/<tag>_pmcW --calib sumsq_partial_kernel:596353024 \
+#          -o profiles/<tag>_pmc_traffic.json
 set -e -o pipefail
 TAG=${1:-r01}
 ROOT=$(pwd)
@@ -13,7 +15,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-distill-mix --no-ddim --no-unfrozen --no-compos --no-zs-frontend"   # the profiled legs: the main step only
 echo "[measure] stats pass"; date
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_stats" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-clock-probe $COMMON > "$OUT/${TAG}_stats.log" 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_stats" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-clock-probe --no-aggregates $COMMON > "$OUT/${TAG}_stats.log" 2>&1
 echo "[measure] pmc FETCH_SIZE pass"; date
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$OUT/${TAG}_pmcF" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-roofline $COMMON > "$OUT/${TAG}_pmcF.log" 2>&1
 echo "[measure] pmc WRITE_SIZE pass"; date
