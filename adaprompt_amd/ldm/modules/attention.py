@@ -123,6 +123,18 @@ class SpatialTransformer(nn.Module):
         self._wc = HF.WeightCache()
 
     def _packs(self, same_ctx):
+        key = None
+        if HF.MODEL_STAMP is not None:       # inside UNetModel.forward: one dict per (model state, grad mode, context form)
+            key = (HF.MODEL_STAMP, same_ctx, torch.is_grad_enabled(), HF.PRESCALE_Q)
+            hit = self.__dict__.get("_P_cache")
+            if hit is not None and hit[0] == key:
+                return hit[1]
+        P = self._build_packs(same_ctx)
+        if key is not None:
+            self.__dict__["_P_cache"] = (key, P)
+        return P
+
+    def _build_packs(self, same_ctx):
         wc, b = self._wc, self.transformer_blocks[0]
         P = {
             "norm": (self.norm.weight, self.norm.bias),

@@ -106,6 +106,12 @@ class ResBlock(TimestepBlock):
                 emb_out = F.linear(F.silu(emb), lin.weight, lin.bias)
             else:
                 emb_out = ops.linear_small(emb, lin.weight, lin.bias, pre_silu=True)
+        key = None
+        if HF.MODEL_STAMP is not None:       # inside UNetModel.forward: one dict per (model state, grad mode) -- see functional.MODEL_STAMP
+            key = (HF.MODEL_STAMP, torch.is_grad_enabled())
+            hit = self.__dict__.get("_P_cache")
+            if hit is not None and hit[0] == key:
+                return HF.ResBlockFn.apply(x, emb_out.float().contiguous() if emb_out.dtype != torch.float32 else emb_out, hit[1])
         wc = self._wc
         sk = None
         identity = isinstance(self.skip_connection, nn.Identity)
@@ -119,6 +125,8 @@ class ResBlock(TimestepBlock):
              "train": HF.train_of(gn1=self.in_layers[0], conv1=self.in_layers[2], gn2=self.out_layers[0],
                                 conv2=self.out_layers[3], skip=None if identity else self.skip_connection)
              if torch.is_grad_enabled() else None}
+        if key is not None:
+            self.__dict__["_P_cache"] = (key, P)
         return HF.ResBlockFn.apply(x, emb_out.float().contiguous() if emb_out.dtype != torch.float32 else emb_out, P)
 
 
@@ -319,6 +327,16 @@ class UNetModel(nn.Module):
 
     def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
         assert y is None, "the SD-1.5 UNet is not class-conditional"
+        plist = self.__dict__.get("_param_list")
+        if plist is None:
+            plist = self.__dict__["_param_list"] = list(self.parameters())
+        prev_stamp, HF.MODEL_STAMP = HF.MODEL_STAMP, (id(self),) + HF.model_stamp(plist)
+        try:
+            return self._forward(x, timesteps, context, context_in, extra_info, **kwargs)
+        finally:
+            HF.MODEL_STAMP = prev_stamp
+
+    def _forward(self, x, timesteps=None, context=None, context_in=None, extra_info=None, **kwargs):
         HF.clear_grad_copies()          # bf16 gradient side copies of a finished backward (functional._GRAD16)
         ei = extra_info if extra_info is not None else {}
         use_layerwise_context = ei.get("use_layerwise_context", False)
