@@ -634,6 +634,56 @@ extern "C" int adap_cosine_rows(const float* x, long ldx, const float* r, long l
 }
 
 // ---------------------------------------------------------------------------------------------
+// ortho_subtract (ldm/util.py:280): per row of a, b [R][D]  out = a - c b,  c = <a,b> / (<b,b> + 1e-6)  -- the component of a
+// orthogonal to b.  Stage 2's prompt-mix and elastic-matching losses call it ~60 times per micro-batch; as torch expressions it
+// is 8 element-wise / reduction launches forward and ~15 in autograd's backward.  One workgroup per row, one launch each way.
+//   backward, g = d L / d out:   da = g - s b,   db = -c g - s (a - 2 c b),   s = <g,b> / (<b,b> + 1e-6)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ortho_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                         long ldb, const float* __restrict__ g, long ldg, float* __restrict__ out,
+                                                         long ldo, float* __restrict__ da, long ldda, float* __restrict__ db,
+                                                         long lddb, int D) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const float* ar = a + row * lda;
+    const float* br = b + row * ldb;
+    const int t = threadIdx.x;
+    float ab = 0.f, bb = 0.f, gb = 0.f;
+    if (g) {
+        const float* gr = g + row * ldg;
+        for (int i = t; i < D; i += 256) { const float bv = br[i]; ab += ar[i] * bv; bb += bv * bv; gb += gr[i] * bv; }
+        gb = block_sum_256(gb, red);
+    } else {
+        for (int i = t; i < D; i += 256) { const float bv = br[i]; ab += ar[i] * bv; bb += bv * bv; }
+    }
+    ab = block_sum_256(ab, red);
+    bb = block_sum_256(bb, red) + 1e-6f;
+    const float c = ab / bb;
+    if (!g) {
+        for (int i = t; i < D; i += 256) out[row * ldo + i] = ar[i] - c * br[i];
+        return;
+    }
+    const float s = gb / bb;
+    const float* gr = g + row * ldg;
+    for (int i = t; i < D; i += 256) {
+        const float bv = br[i], gv = gr[i];
+        if (da) da[row * ldda + i] = gv - s * bv;
+        if (db) db[row * lddb + i] = -c * gv - s * (ar[i] - 2.0f * c * bv);
+    }
+}
+
+// g == NULL: forward, out <- a - c b.  g != NULL: backward for g = d L / d out: da and / or db.
+extern "C" int adap_ortho_rows(const float* a, long lda, const float* b, long ldb, const float* g, long ldg, float* out, long ldo,
+                               float* da, long ldda, float* db, long lddb, long R, int D, void* stream) {
+    ADAP_REQUIRE(a && b && ((!g && out) || (g && (da || db))), ADAP_ERR_SHAPE, "ortho_rows: null pointer");
+    ADAP_REQUIRE(R >= 0 && D >= 1 && lda >= D && ldb >= D, ADAP_ERR_SHAPE, "ortho_rows: shape");
+    if (R == 0) return ADAP_OK;
+    hipLaunchKernelGGL(ortho_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, g, ldg, out, ldo, da,
+                       ldda, db, lddb, D);
+    return adap_check_launch("ortho_rows");
+}
+
+// ---------------------------------------------------------------------------------------------
 // The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for a stack of same-resolution
 // layers, forward and analytic backward.  S = subject score map, G = background-token score map, [L][B][H][N]
 // (read with an element stride: the two are columns of the token-map tensor), f = foreground mask [B][N] in {0,1}.

@@ -783,6 +783,26 @@ class CosineRowsFn(torch.autograd.Function):
         return (None if dx is None else dx.reshape(xs)), (None if dr is None else dr.reshape(rs)), None, None, None, None
 
 
+class OrthoRowsFn(torch.autograd.Function):
+    """``ortho_subtract`` over the last dim (ldm/util.py:280): one HIP launch forward and one backward instead of ~8 + ~15
+    element-wise / reduction torch launches (Stage 2 calls it ~60 times per micro-batch)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a2 = a.reshape(-1, a.shape[-1]).float().contiguous()
+        b2 = b.reshape(-1, b.shape[-1]).float().contiguous()
+        ctx.save_for_backward(a2, b2)
+        ctx.shapes = (a.shape, b.shape)
+        return ops.ortho_rows(a2, b2).reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        sa, sb = ctx.shapes
+        da, db = ops.ortho_rows(a2, b2, g.reshape(a2.shape).float().contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (None if da is None else da.reshape(sa)), (None if db is None else db.reshape(sb))
+
+
 class MaskHingesFn(torch.autograd.Function):
     """the four mask hinge terms of the fg/bg complementary loss (ddpm.py:4143-4238) for a stack of same-resolution
     token maps [L, B, heads, N, groups]: three launches forward, one backward (ops.mask_hinges)."""

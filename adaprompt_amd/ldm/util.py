@@ -114,6 +114,10 @@ def prodigy_linear_schedule(opt, max_steps, warm_up_steps, scheduler_cycles=1):
 def ortho_subtract(a, b, on_last_n_dims=1, return_align_coeffs=False):
     """the component of ``a`` orthogonal to ``b`` over the last ``on_last_n_dims`` dims (w = <a,b> / (<b,b> + 1e-6))."""
     assert a.ndim == b.ndim, "Tensors a and b must have the same number of dimensions"
+    if (a.is_cuda and on_last_n_dims == 1 and not return_align_coeffs and a.shape == b.shape and a.dtype == torch.float32
+            and b.dtype == torch.float32):
+        from .. import functional as HF            # the fused HIP kernel (forward + analytic backward)
+        return HF.OrthoRowsFn.apply(a, b)
     shape = None
     if on_last_n_dims > 1:
         full = torch.broadcast_shapes(a.shape, b.shape)

@@ -785,6 +785,24 @@ def cosine_rows(x, r, demean, align, ref_grad_scale=1.0, gl=None, want_dx=True, 
     return dx, dr
 
 
+def ortho_rows(a, b, g=None, want_da=True, want_db=True):
+    """a, b f32 [R, D] (rows contiguous).  g None: -> a - <a,b>/(<b,b>+1e-6) b per row (ldm/util.py:280 ortho_subtract).
+    g f32 [R, D] = the gradient of the result: -> (da, db)."""
+    assert a.dtype == F32 and b.dtype == F32 and a.dim() == 2 and a.shape == b.shape and a.stride(1) == 1 and b.stride(1) == 1
+    R, D = a.shape
+    if g is None:
+        out = torch.empty(R, D, device=a.device, dtype=F32)
+        _lib.call("adap_ortho_rows", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 0, 0, out.data_ptr(), D, 0, 0, 0, 0,
+                  R, D, _stream())
+        return out
+    assert g.dtype == F32 and g.shape == a.shape and g.stride(1) == 1
+    da = torch.empty(R, D, device=a.device, dtype=F32) if want_da else None
+    db = torch.empty(R, D, device=a.device, dtype=F32) if want_db else None
+    _lib.call("adap_ortho_rows", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), g.data_ptr(), g.stride(0), 0, 0, _ptr(da), D,
+              _ptr(db), D, R, D, _stream())
+    return da, db
+
+
 def mask_hinges(maps, fmask, iw, margin, margin_bg_at_mf, have_bg, gout=None, ws=None):
     """maps f32 [L, B, H, N, G] contiguous (column 0 subject, column 1 background); fmask f32 [B, N] in {0,1}.
     gout None -> (out [4, L], workspace);  gout [4, L] + the forward's workspace -> d maps [L, B, H, N, G]."""

@@ -413,6 +413,11 @@ int adap_norm_affine_bwd(const void* dy, int dy_dtype, long lddy, const void* x,
 int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const float* gl, float* loss, float* dx,
                      long lddx, float* dr, long lddr, long R, int D, int demean, int align, float ref_grad_scale,
                      int exponent, void* stream);
+/* ortho_subtract (ldm/util.py:280): per row of a, b f32 [R][D] (rows contiguous, leading dims lda / ldb):
+ * out = a - c b with c = <a,b> / (<b,b> + 1e-6).  g NULL: forward (out).  g = d L / d out [R][D]: backward, da and / or db
+ * (NULL = not wanted):  da = g - s b,  db = -c g - s (a - 2 c b),  s = <g,b> / (<b,b> + 1e-6). */
+int adap_ortho_rows(const float* a, long lda, const float* b, long ldb, const float* g, long ldg, float* out, long ldo,
+                    float* da, long ldda, float* db, long lddb, long R, int D, void* stream);
 
 /* The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for L same-resolution layers:
  * S / G f32 [L][B][H][N] = per-head score maps of the subject / background tokens (element stride `estride`: they

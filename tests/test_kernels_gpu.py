@@ -273,6 +273,30 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, Cin, Cout, res, bf
     assert getattr(y32, ops.GN_STATS_ATTR, None) is None and _lib.call_long("adap_conv2d_last_gn_chunks") == 0
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 4096), (4, 11520), (2, 16, 77, 768), (1, 5, 33)])
+def test_ortho_subtract_fused_rows(shape):
+    """``ortho_subtract`` over the last dim (ldm/util.py:280) as one launch each way (``OrthoRowsFn``) against the torch
+    expressions and their autograd: a - <a,b>/(<b,b>+1e-6) b, gradients into both operands."""
+    from adaprompt_amd.ldm.util import ortho_subtract
+    a0, b0, g = rnd(*shape, seed=1), rnd(*shape, seed=2) + 0.3, rnd(*shape, seed=3)
+
+    def torch_form(a, b):
+        coeff = (a * b).sum(dim=-1) / ((b * b).sum(dim=-1) + 1e-6)
+        return a - coeff[..., None] * b
+    a1, b1 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    out = ortho_subtract(a1, b1)
+    assert type(out.grad_fn).__name__ == "OrthoRowsFnBackward"
+    out.backward(g)
+    a2, b2 = a0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    ref = torch_form(a2, b2)
+    ref.backward(g.double())
+    assert rel(out, ref) < 1e-6 and rel(a1.grad, a2.grad) < 1e-5 and rel(b1.grad, b2.grad) < 1e-5
+    # only one operand differentiable (gradient scalers / detached references)
+    a3 = a0.clone().requires_grad_(True)
+    ortho_subtract(a3, b0).backward(g)
+    assert rel(a3.grad, a2.grad) < 1e-5
+
+
 def test_groupnorm_single_launch_only_on_one_stream():
     """the workgroups of a single-launch GroupNorm wait for each other, so only ONE stream per device may issue them (two
     such kernels in flight could each hold part of the chip and wait for the rest): the default stream takes that path, a
