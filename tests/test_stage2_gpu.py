@@ -60,9 +60,11 @@ def _score_fn(prompts, images):
 @pytest.mark.gpu
 @pytest.mark.parametrize("size,B", [("narrow", 3), ("sd15", 1)])
 def test_compositional_micro_batch_vs_oracle(size, B):
-    """``narrow``: BASELINE config 4's bs = 3 at model_channels 64.  ``sd15``: the same micro-batch at the FULL SD-1.5 sizes
-    (859.5 M UNet, 768-wide context, full VAE decoder) with one instance and one teacher candidate -- 4 prompt types with
-    gradient, a guided teacher-filter pass -- so that the fp32 oracle's autograd fits a test box (~2 min of CPU)."""
+    """``narrow``: BASELINE config 4's bs = 3 at model_channels 64, with the CLIP-scored teacher filter over two candidates.
+    ``sd15``: the micro-batch at the FULL SD-1.5 sizes (859.5 M UNet, 768-wide context, full VAE decoder) with one instance and
+    ``do_clip_teacher_filtering`` off -- the guided with-grad pass under the four mixed contexts, the decode of the two comp
+    images for the score, the stage-2 losses and the gradient into the subject vectors -- so that the fp32 oracle's autograd fits
+    the suite's time budget (~1.5 min of CPU; the filter's extra no-grad passes are the narrow case's business)."""
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from oracle import ldm_oracle as O
     dev = torch.device("cuda:0")
@@ -86,6 +88,8 @@ def test_compositional_micro_batch_vs_oracle(size, B):
         missing, unexpected = ld.load_state_dict({**usd, **vsd}, strict=False)
         assert not unexpected
         ld = ld.to(device)
+        if size == "sd15":
+            ld.do_clip_teacher_filtering = False
         ld.embedding_manager.vectors["z"].data.mul_(VEC_SCALE)
         ld.embedding_manager.vectors["y"].data.mul_(VEC_SCALE)
         if oracle:
@@ -112,19 +116,23 @@ def test_compositional_micro_batch_vs_oracle(size, B):
     lh, ph, gh, fh, ch, cache_h = run(dev, oracle=False)
     lo, po, go, fo, co, cache_o = run(torch.device("cpu"), oracle=True)
     # same decisions
-    assert fh["is_teachable"] and fo["is_teachable"] and ph["best_cand_idx"] == po["best_cand_idx"] == NT - 1
-    assert fh["do_teacher_filter"] and fh["use_background_token"] == fo["use_background_token"]
-    assert ch == co == ["alice"]
-    assert torch.equal(cache_h["alice"]["t"].cpu(), cache_o["alice"]["t"])
-    report = {"x_start_cache": rel_err(cache_h["alice"]["x_start"].cpu(), cache_o["alice"]["x_start"]),
-              "grad_z": rel_err(gh["z"], go["z"]), "grad_y": rel_err(gh["y"], go["y"]), "loss": abs(lh - lo) / abs(lo)}
+    filtered = size == "narrow"
+    assert fh["is_teachable"] and fo["is_teachable"] and ph["best_cand_idx"] == po["best_cand_idx"] == (NT - 1 if filtered else 0)
+    assert fh["do_teacher_filter"] == fo["do_teacher_filter"] == filtered and fh["use_background_token"] == fo["use_background_token"]
+    report = {"grad_z": rel_err(gh["z"], go["z"]), "grad_y": rel_err(gh["y"], go["y"]), "loss": abs(lh - lo) / abs(lo)}
+    if filtered:                  # the selected candidate's x0 prediction is cached for the reuse iteration
+        assert ch == co == ["alice"]
+        assert torch.equal(cache_h["alice"]["t"].cpu(), cache_o["alice"]["t"])
+        report["x_start_cache"] = rel_err(cache_h["alice"]["x_start"].cpu(), cache_o["alice"]["x_start"])
+    else:
+        assert ch == co == []
     for k in po:
         if k != "best_cand_idx":
             report[k] = abs(ph[k] - po[k]) / (abs(po[k]) + 1e-12)
     print(f"stage-2 micro-batch [{size}], HIP vs oracle (relative):", {k: round(v, 5) for k, v in report.items()})
     # the x0 prediction cached for the reuse iteration: guided noise prediction (scale ~3) of the selected candidate, divided by
     # sqrt(alphas_cumprod[t]) ~ 0.07 at t ~ 900 -- the bf16 path's ~1 % noise-prediction error is amplified ~10x
-    assert report["x_start_cache"] < X0_TOL
+    assert report.get("x_start_cache", 0.0) < X0_TOL
     for k in ("loss_clip_subj_comp", "loss_clip_cls_comp"):
         assert abs(ph[k] - po[k]) < 2e-3, (k, ph[k], po[k])
     for k in po:
