@@ -132,3 +132,33 @@ def test_groupnorm_beside_a_resident_collective_kernel():
             assert t1 * 8 < RESIDENT_US / 4, (blocks, t1)
     print("GroupNorm 4x64x64x320 forward per call -- " + "; ".join(line))
     assert not ops.gn_sync_poisoned()
+    # every single-launch variant, forward and backward (6 / 11 / 16 / 8 pixel rows per thread: the larger ones fill most of a CU's
+    # register file), beside 64 and 128 resident workgroups -- the footprint of a collective with 64-128 channels.  Measured:
+    # 21-38 us forward, 32-35 us backward.  (With one resident workgroup on EVERY CU the larger variants cannot start beside it
+    # and a call waits for the resident kernel to end -- 4 ms once; a communicator that wide would need the hold.)
+    table = []
+    for (H, C) in [(64, 640), (64, 960), (32, 1920), (32, 1280)]:
+        x = torch.randn(4, H, H, C, device=dev, generator=g)
+        gw, gb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        dy = torch.randn(4, H, H, C, device=dev, generator=g).to(torch.bfloat16)
+        _, _, m, r = ops.groupnorm_fwd(x, gw, gb, 1e-5, 1)
+        for blocks in (64, 128):
+            for which in ("fwd", "bwd"):
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    _lib.call("adap_debug_occupy", blocks, 512, RESIDENT_US, sink.data_ptr(), _lib.current_stream())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(8):
+                    if which == "fwd":
+                        ops.groupnorm_fwd(x, gw, gb, 1e-5, 1)
+                    else:
+                        ops.groupnorm_bwd(dy, x, gw, gb, m, r, 1, out_f32=False, out_bf16=True)
+                variant = _lib.call_long("adap_groupnorm_last_variant")
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 8
+                table.append(f"{H}x{H}x{C} {which} (variant {variant}) beside {blocks}: {us:.0f} us")
+                assert us * 8 < RESIDENT_US / 4, table[-1]          # not held up for anything like the resident kernel's 4 ms
+    print("; ".join(table))
+    assert not ops.gn_sync_poisoned()
