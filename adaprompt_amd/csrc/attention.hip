@@ -1300,49 +1300,58 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
             tile_load(rDO, mapDO, dob + (size_t)q1 * p.lddo, min(64, p.N - q1));
             row_stats_load(q1);
         }
+        // Three passes over the tile's two 32-query halves -- all S / dP products, then both halves' exponent / dS chains, then
+        // all dV / dK products -- instead of one half after the other: the matrix pipe gets 12 and 16 back-to-back MFMAs and the
+        // vector unit two independent chains at a time (the two waves of a SIMD then overlap phases of different kinds more often)
+        f32x16 S[2], dP[2], nl[2];
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             // rows of S / dP are queries 32qi + 8g + 4h + e, the column (lane) is this wave's key
-            f32x16 S, dP, nl;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
                 float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
-                nl[4 * g] = lv.x; nl[4 * g + 1] = lv.y; nl[4 * g + 2] = lv.z; nl[4 * g + 3] = lv.w;
-                if (pre) { S[4 * g] = lv.x; S[4 * g + 1] = lv.y; S[4 * g + 2] = lv.z; S[4 * g + 3] = lv.w; }
-                else { S[4 * g] = 0.f; S[4 * g + 1] = 0.f; S[4 * g + 2] = 0.f; S[4 * g + 3] = 0.f; }
-                dP[4 * g] = dv.x; dP[4 * g + 1] = dv.y; dP[4 * g + 2] = dv.z; dP[4 * g + 3] = dv.w;
+                nl[qi][4 * g] = lv.x; nl[qi][4 * g + 1] = lv.y; nl[qi][4 * g + 2] = lv.z; nl[qi][4 * g + 3] = lv.w;
+                if (pre) { S[qi][4 * g] = lv.x; S[qi][4 * g + 1] = lv.y; S[qi][4 * g + 2] = lv.z; S[qi][4 * g + 3] = lv.w; }
+                else { S[qi][4 * g] = 0.f; S[qi][4 * g + 1] = 0.f; S[qi][4 * g + 2] = 0.f; S[qi][4 * g + 3] = 0.f; }
+                dP[qi][4 * g] = dv.x; dP[qi][4 * g + 1] = dv.y; dP[qi][4 * g + 2] = dv.z; dP[qi][4 * g + 3] = dv.w;
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 qrow = *(const bf16x8*)(sQ + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow, kf[s], S, 0, 0, 0);
+                S[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow, kf[s], S[qi], 0, 0, 0);
                 bf16x8 drow = *(const bf16x8*)(sDO + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
-                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP, 0, 0, 0);
+                dP[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP[qi], 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
             if (biased) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[r] += bias;
+                for (int r = 0; r < 16; ++r) S[qi][r] += bias;
             }
             if (pre) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(S[r]);
-                    S[r] = pv;                 // P
-                    dP[r] = pv * dP[r];        // dS
+                    float pv = __builtin_amdgcn_exp2f(S[qi][r]);
+                    S[qi][r] = pv;                 // P
+                    dP[qi][r] = pv * dP[qi][r];    // dS
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(S[r], cs, nl[r]));
-                    S[r] = pv;                 // P
-                    dP[r] = pv * dP[r];        // dS
+                    float pv = __builtin_amdgcn_exp2f(fmaf(S[qi][r], cs, nl[qi][r]));
+                    S[qi][r] = pv;                 // P
+                    dP[qi][r] = pv * dP[qi][r];    // dS
                 }
             }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
-                bf16x8 pf = acc_to_frag(S, sh);
-                bf16x8 dsf = acc_to_frag(dP, sh);
+                bf16x8 pf = acc_to_frag(S[qi], sh);
+                bf16x8 dsf = acc_to_frag(dP[qi], sh);
 #pragma unroll
                 for (int vt = 0; vt < VT; ++vt) {
                     bf16x8 dotr = lds_tr_frag(sDO, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
