@@ -222,6 +222,7 @@ def main():
     st_t = torch.zeros(B, device=device, dtype=torch.int64)
     st_noise = torch.zeros(B, 4, 64, 64, device=device)
     st_pn = torch.zeros(B, 4, 64, 64, device=device)
+    st_x = torch.zeros(B, 4, 64, 64, device=device)          # --graph with the prefetch stream: the encoded latent of this step
     graphs = None
 
     def draw(i):
@@ -232,13 +233,15 @@ def main():
         st_noise.copy_(torch.randn(B, 4, 64, 64, device=device, generator=gen))
         st_pn.copy_(torch.randn(B, 4, 64, 64, device=device, generator=gen))
 
-    def fwd():
+    def fwd(latent_from_prefetch=False):
         # the all-reduce issued by the previous micro-batch overlaps this VAE encode + UNet forward and is
         # awaited just before this micro-batch's backward writes into the gradient buffer
+        if latent_from_prefetch:        # (--graph: the VAE encode stays eager on the prefetch stream and hands its latent over here)
+            return ld.shared_step(static, t=st_t, noise=st_noise, x_start=st_x)
         return ld.shared_step(static, t=st_t, noise=st_noise, post_noise=st_pn)
 
     # ---- default mode: eager launches, the next micro-batch's VAE encode prefetched on a second stream ----------
-    prefetch = None if (args.graph or args.no_prefetch) else ld.make_prefetcher()
+    prefetch = None if args.no_prefetch else ld.make_prefetcher()
     pf_state = {"next": 0}
 
     def pf_submit():
@@ -256,16 +259,22 @@ def main():
         with torch.cuda.stream(side):
             for i in range(2):                    # warm-up on the capture stream (weight packs, workspaces, BLAS handles)
                 draw(i)
-                loss, grad, out, aux = fwd()
+                loss, grad, out, aux = fwd(prefetch is not None)
                 ld.manual_backward(out, grad, aux)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         reducer.zero()
         g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_f):
-            loss, grad, out, aux = fwd()
-        with torch.cuda.graph(g_b, pool=g_f.pool()):
-            ld.manual_backward(out, grad, aux)
+        # the capture stream owns the single-launch GroupNorm path while the graphs are recorded (the decision is taken on the
+        # host at capture time; the replayed kernels use the same exchange buffer on whatever stream replays them)
+        ops.set_gn_single_launch_stream(device, side.cuda_stream)
+        try:
+            with torch.cuda.graph(g_f, stream=side):
+                loss, grad, out, aux = fwd(prefetch is not None)
+            with torch.cuda.graph(g_b, pool=g_f.pool(), stream=side):
+                ld.manual_backward(out, grad, aux)
+        finally:
+            ops.set_gn_single_launch_stream(device, torch.cuda.default_stream(device).cuda_stream)
         torch.cuda.synchronize()
         reducer.zero()
         return g_f, g_b, loss
@@ -301,12 +310,16 @@ def main():
         return loss
 
     def step(i):
-        if prefetch is not None and ops.TIMER is None:
+        if prefetch is not None and ops.TIMER is None and graphs is None:
             return step_prefetch(i)
         draw(i)
         if graphs is not None:
             g_f, g_b, loss = graphs
+            if prefetch is not None:
+                st_x.copy_(prefetch.get())              # encoded on the prefetch stream while the previous replay ran
             g_f.replay()
+            if prefetch is not None:
+                pf_submit()
             reducer.wait()
             g_b.replay()
         else:
@@ -334,8 +347,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    t_issued = time.perf_counter()               # the host has queued every step; the GPU is still working them off
     sync()
     dt = time.perf_counter() - t0
+    host_issue_ms = 1e3 * (t_issued - t0) / args.steps
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -707,6 +722,9 @@ def main():
             "model_tflops_per_step": round(GFLOP_PER_IMAGE * B / 1e3, 2),
             "achieved_model_tflops_per_gpu": round(GFLOP_PER_IMAGE * B / 1e3 / (ms * 1e-3), 1),
             "final_loss": round(loss_val, 5),
+            # diagnostic: how long the host needed to ISSUE a step (no synchronisation inside the timed loop).  Well below
+            # ms_per_step: the GPU is the bottleneck; close to it: this run was bound by the host's single-thread speed
+            "host_issue_ms_per_step": round(host_issue_ms, 3),
         }
         if roofline is not None:
             res["roofline"] = roofline
