@@ -310,6 +310,23 @@ def _lin_bwd(g, pk, out_f32=True, out_bf16=False):
 # ---------------------------------------------------------------------------------------------
 # ResBlock (openaimodel.py:259-279)
 # ---------------------------------------------------------------------------------------------
+RESBLOCK_C = os.environ.get("ADAP_RESBLOCK_C", "1") != "0"      # the frozen ResBlock issued from one C call (csrc/blocks.hip)
+_RB_WS = {}
+
+
+def _resblock_ws(B, H, W, Cin, Cout, has_skip):
+    """(GroupNorm workspace floats, split-K workspace floats) of a ResBlock's forward and backward calls: the largest each."""
+    key = (B, H, W, Cin, Cout, has_skip)
+    v = _RB_WS.get(key)
+    if v is None:
+        q = ops._lib.size_query
+        gn = max(q("adap_groupnorm_workspace_floats", B, H * W, Cin), q("adap_groupnorm_workspace_floats", B, H * W, Cout))
+        convs = [(Cin, Cout, 3), (Cout, Cout, 3), (Cout, Cin, 3)] + ([(Cin, Cout, 1), (Cout, Cin, 1)] if has_skip else [])
+        sk = max(q("adap_conv2d_workspace_floats", B, H, W, ci, co, k, k) for ci, co, k in convs)
+        v = _RB_WS[key] = (gn, sk)
+    return v
+
+
 class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, emb_out, P):
@@ -318,6 +335,29 @@ class ResBlockFn(torch.autograd.Function):
         g1w, g1b = P["gn1"]
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
+        if (RESBLOCK_C and not F32_STORAGE and P.get("train") is None and ops.TIMER is None and x.dtype == torch.float32
+                and x.is_contiguous() and emb_out.is_contiguous() and c1.O4 == c1.O and c1.I8 == c1.I):
+            # one C call issues the block's five launches (host time: ~100 us of wrappers and allocations -> ~30)
+            B, H, W, Cin = x.shape
+            Cout = c1.O
+            dev = x.device
+            gn_n, sk_n = _resblock_ws(B, H, W, Cin, Cout, sk is not None)
+            a1 = torch.empty(B, H, W, Cin, device=dev, dtype=BF16)
+            hh = torch.empty(2, B, H, W, Cout, device=dev, dtype=BF16)          # h1 (kept for the backward) | a2
+            out = torch.empty(B, H, W, Cout, device=dev, dtype=torch.float32)
+            skip = torch.empty(B, H, W, Cout, device=dev, dtype=torch.float32) if sk is not None else None
+            stats = torch.empty(4, B, 32, device=dev, dtype=torch.float32)
+            ws = torch.empty(gn_n + sk_n, device=dev, dtype=torch.float32)
+            ops._lib.call("adap_resblock_fwd", x.data_ptr(), emb_out.data_ptr(), g1w.data_ptr(), g1b.data_ptr(), g2w.data_ptr(),
+                          g2b.data_ptr(), c1.fwd.data_ptr(), ops._ptr(c1.bias), c2.fwd.data_ptr(), ops._ptr(c2.bias),
+                          0 if sk is None else sk.fwd.data_ptr(), 0 if sk is None else ops._ptr(sk.bias), a1.data_ptr(),
+                          hh[0].data_ptr(), hh[1].data_ptr(), ops._ptr(skip), out.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                          (ws.data_ptr() + 4 * gn_n) if sk_n else 0, ops.gn_sync_buffer(dev), B, H, W, Cin, Cout, ops._stream())
+            ctx.P = P
+            ctx.fast = True
+            ctx.save_for_backward(x, hh[0], stats)
+            return out
+        ctx.fast = False
         _, a1, m1, r1 = ops.groupnorm_fwd(x, g1w, g1b, 1e-5, 1)
         # h1 is block-internal (read only by the second norm and its backward): kept in bf16
         h1_32, h1 = ops.conv2d(a1, c1.fwd, c1.O4, 3, 1, 1, bias=c1.bias, chan_add=emb_out, out_f32=F32_STORAGE,
@@ -337,8 +377,34 @@ class ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        x, h1, m1, r1, m2, r2, a1, a2 = ctx.saved_tensors
         P = ctx.P
+        if ctx.fast and not ctx.needs_input_grad[1] and ops.TIMER is None:
+            x, h1, stats = ctx.saved_tensors
+            g1w, g1b = P["gn1"]
+            g2w, g2b = P["gn2"]
+            c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
+            B, H, W, Cin = x.shape
+            Cout = c1.O
+            dev = x.device
+            g = g.contiguous()
+            gop = _operand(g)
+            gn_n, sk_n = _resblock_ws(B, H, W, Cin, Cout, sk is not None)
+            sc = torch.empty(2, B, H, W, Cout, device=dev, dtype=BF16)            # ga2 | gh1
+            ga1 = torch.empty(2, B, H, W, Cin, device=dev, dtype=BF16)           # ga1 | gx16
+            gx = torch.empty(B, H, W, Cin, device=dev, dtype=torch.float32)
+            ws = torch.empty(gn_n + sk_n, device=dev, dtype=torch.float32)
+            ops._lib.call("adap_resblock_bwd", gop.data_ptr(), 0 if gop.dtype == torch.float32 else 1, g.data_ptr(), x.data_ptr(),
+                          h1.data_ptr(), stats.data_ptr(), g1w.data_ptr(), g1b.data_ptr(), g2w.data_ptr(), g2b.data_ptr(),
+                          c1.bwd.data_ptr(), c2.bwd.data_ptr(), 0 if sk is None else sk.bwd.data_ptr(), sc[0].data_ptr(),
+                          sc[1].data_ptr(), ga1[0].data_ptr(), gx.data_ptr(), ga1[1].data_ptr(), ws.data_ptr(),
+                          (ws.data_ptr() + 4 * gn_n) if sk_n else 0, ops.gn_sync_buffer(dev), B, H, W, Cin, Cout, ops._stream())
+            return _stash16(gx, ga1[1]), None, None
+        if ctx.fast:          # (saved in the compact form; the general path below wants the per-tensor one)
+            x, h1, stats = ctx.saved_tensors
+            m1, r1, m2, r2 = stats[0], stats[1], stats[2], stats[3]
+            a1 = a2 = None
+        else:
+            x, h1, m1, r1, m2, r2, a1, a2 = ctx.saved_tensors
         T = P.get("train")
         g1w, g1b = P["gn1"]
         g2w, g2b = P["gn2"]

@@ -98,6 +98,25 @@ int adap_conv2d_debug_force(int kind, int bn);
 int adap_conv2d_next_gn_partial(float* partial, int channels_per_group);
 int adap_conv2d_last_gn_chunks(void);
 
+/* One UNet ResBlock (openaimodel.py:259-279: GroupNorm+SiLU -> conv3x3 + emb -> GroupNorm+SiLU -> conv3x3 + skip) issued from
+ * ONE call, forward and data gradient: the launches of adap_groupnorm_fwd/bwd and adap_conv2d_nhwc in the order and with the
+ * arguments of the per-op sequence, so the numbers are bit-identical to it -- what changes is the host: one call instead of 5-6
+ * and their wrappers (csrc/blocks.hip).  Frozen weights (no weight gradients).
+ * fwd: x f32 [B,H,W,Cin], emb_out f32 [B,Cout], forward packs (sk* NULL = identity skip, Cin == Cout) -> a1 bf16 [..,Cin],
+ * h1 bf16 [..,Cout], a2 bf16 [..,Cout], skip f32 [..,Cout] (with sk only), out f32 [..,Cout], stats f32 [4][B][32] = mean1,
+ * rstd1, mean2, rstd2.  gn_ws / sk_ws: the largest adap_groupnorm_workspace_floats / adap_conv2d_workspace_floats of the
+ * block's calls (sk_ws may be NULL when all are 0); gn_sync as for adap_groupnorm_fwd.
+ * bwd: g = d out as f32 (g_dtype 0) or its bf16 copy (1), g32 = the f32 gradient (added to dx by an identity skip), data-gradient
+ * packs -> gx f32 [..,Cin] and gx16 its bf16 copy; ga2 / gh1 bf16 [..,Cout] and ga1 bf16 [..,Cin] are scratch. */
+int adap_resblock_fwd(const float* x, const float* emb_out, const float* g1w, const float* g1b, const float* g2w,
+                      const float* g2b, const void* c1w, const float* c1b, const void* c2w, const float* c2b, const void* skw,
+                      const float* skb, void* a1, void* h1, void* a2, float* skip, float* out, float* stats, float* gn_ws,
+                      float* sk_ws, void* gn_sync, int B, int H, int W, int Cin, int Cout, void* stream);
+int adap_resblock_bwd(const void* g, int g_dtype, const float* g32, const float* x, const void* h1, const float* stats,
+                      const float* g1w, const float* g1b, const float* g2w, const float* g2b, const void* c1wb,
+                      const void* c2wb, const void* skwb, void* ga2, void* gh1, void* ga1, float* gx, void* gx16,
+                      float* gn_ws, float* sk_ws, void* gn_sync, int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* FeedForward with its GEGLU fused into the two contractions (attention.py:32-59: proj -> chunk -> a * gelu(gate) -> Linear).
  * The 8C pre-activation h is stored in a PERMUTED channel order -- 16 value channels, then their 16 gate channels, then the next
  * 16 values ... (new row 32 k + j <- value channel 16 k + j, new row 32 k + 16 + j <- gate channel 16 k + j) -- and w_packed /

@@ -297,6 +297,38 @@ def test_ortho_subtract_fused_rows(shape):
     assert rel(a3.grad, a2.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(4, 64, 320, 320), (2, 32, 320, 640), (4, 16, 1280, 1280), (3, 8, 2560, 1280),
+                                           (1, 32, 960, 640)])
+def test_resblock_one_c_call_equals_the_per_op_sequence(B, H, Cin, Cout):
+    """``adap_resblock_fwd`` / ``_bwd`` (csrc/blocks.hip: the frozen ResBlock's launches issued from one C call) against the same
+    block issued op by op from Python (``functional.RESBLOCK_C`` off): output, saved statistics and the data gradient must be
+    bit-identical -- the same kernels with the same arguments, only the host side differs."""
+    from adaprompt_amd import functional as HF
+    x = rnd(B, H, H, Cin, seed=1)
+    emb = rnd(B, Cout, seed=2)
+    g = rnd(B, H, H, Cout, seed=3)
+    P = {"gn1": (rnd(Cin, seed=4) + 1, rnd(Cin, seed=5)), "gn2": (rnd(Cout, seed=6) + 1, rnd(Cout, seed=7)),
+         "conv1": ops.PackedConv(rnd(Cout, Cin, 3, 3, seed=8, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=9)),
+         "conv2": ops.PackedConv(rnd(Cout, Cout, 3, 3, seed=10, scale=(9 * Cout) ** -0.5), rnd(Cout, seed=11)),
+         "skip": None if Cin == Cout else ops.PackedConv(rnd(Cout, Cin, 1, 1, seed=12, scale=Cin ** -0.5), rnd(Cout, seed=13)),
+         "train": None}
+
+    def run(c_call):
+        old = HF.RESBLOCK_C
+        HF.RESBLOCK_C = c_call
+        try:
+            xi = x.clone().requires_grad_(True)
+            out = HF.ResBlockFn.apply(xi, emb, P)
+            out.backward(g)
+            return out.detach(), xi.grad.detach()
+        finally:
+            HF.RESBLOCK_C = old
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1) and torch.equal(g0, g1)
+    assert rel(o1, o0) == 0.0 and torch.isfinite(g1).all()
+
+
 def test_groupnorm_single_launch_only_on_one_stream():
     """the workgroups of a single-launch GroupNorm wait for each other, so only ONE stream per device may issue them (two
     such kernels in flight could each hold part of the chip and wait for the rest): the default stream takes that path, a

@@ -71,6 +71,20 @@ print(f"{N} steps: host issue {1e3 * (t1 - t0) / N:.2f} ms/step, issue + drain {
       f"(drain after the last issue: {1e3 * (t2 - t1):.2f} ms)")
 print("host ms/step by phase:", {k: round(1e3 * v / N, 2) for k, v in marks.items()})
 
+# the host's own work per step: with an empty launch queue (a synchronisation first) and only a step or two issued, the host
+# never waits for the GPU; over ten steps the queue fills (it holds ~55 ms of this workload) and "issue" time becomes
+# (GPU time - queue depth) / steps, whatever the host could do
+for n in (1, 2):
+    ts = []
+    for rep in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i)
+        ts.append((time.perf_counter() - t0) / n)
+    torch.cuda.synchronize()
+    print(f"host work per step, {n} step(s) issued into an empty queue: {1e3 * sorted(ts)[len(ts) // 2]:.2f} ms (median of 5)")
+
 if os.environ.get("HOST_PROFILE"):
     import cProfile
     import pstats
