@@ -586,20 +586,33 @@ def main():
         ld.set_arc2face_teacher(None)
         del teacher
 
+    def leg_reset():
+        """between the extra legs (never inside a timed region): hand the caching allocator's blocks back.  The legs build
+        further models (teacher UNet, VAE decoder, optimiser state for 1.13 B values) with allocation patterns of their own;
+        carried over, the earlier legs' cached blocks left the last leg 15 % slower (50 vs 59 img/s unfrozen, and only when every
+        leg had run before it)."""
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
     # ---- extra leg: config 4 (SURVEY 8f-1) -- Stage-2 compositional distillation micro-batches at bs=3
     compos = None
     if world == 1 and not args.no_compos:
+        leg_reset()
         compos = compos_leg(device, gen)
 
     # ---- extra leg: the zero-shot feature front end's image encoder (SURVEY 8 f-4), which runs in every zero-shot iteration
     zs_front = None
     if world == 1 and not args.no_zs_frontend:
+        leg_reset()
         zs_front = zs_frontend_leg(device, gen)
 
     # ---- extra leg: config 5 (SURVEY 8d) -- 50 DDIM steps at bs=8 (UNet batch 16 under classifier-free guidance,
     # context [256,77,768]) and the VAE decode of the 8 latents
     ddim = None
     if world == 1 and not args.no_ddim:
+        leg_reset()
         from adaprompt_amd import synth
         from adaprompt_amd.ldm.models.diffusion.ddim import DDIMSampler
         dec = ld.first_stage_model.build_decoder()
@@ -638,6 +651,7 @@ def main():
     # per-micro-batch all-reduce carries all of it (~4.5 GB).  Runs last: it moves the UNet's weights.
     unfrozen = None
     if not args.no_unfrozen:
+        leg_reset()
         for p_ in ld.model.parameters():
             p_.requires_grad_(True)
         clip_standin = torch.nn.Parameter(torch.zeros(123_060_480, device=device))
