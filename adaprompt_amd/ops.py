@@ -236,6 +236,30 @@ def linear(x, w_packed, Cout, bias=None, residual=None, out_f32=True, out_bf16=F
     """x [..., Cin] -> [..., Cout] through the 1x1 path."""
     shp = x.shape
     rows, ld = _rows_ld(x)
+    if (TIMER is None and w_packed.shape[0] == 1 and w_packed.shape[2] == shp[-1] and w_packed.shape[1] == Cout
+            and w_packed.dtype == BF16 and w_packed.is_contiguous()):
+        # straight to the C entry ([1, rows, 1, Cin] problem): ~250 calls per training step, and the generic conv2d wrapper
+        # (strided views of x / residual / outputs, shape algebra) is several microseconds of host time each
+        Cin = shp[-1]
+        dev = x.device
+        out_shape = tuple(shp[:-1]) + (Cout,)
+        y32 = torch.empty(out_shape, device=dev, dtype=F32) if out_f32 else None
+        y16 = torch.empty(out_shape, device=dev, dtype=BF16) if out_bf16 else None
+        rl = 0
+        if residual is not None:
+            assert residual.dtype == F32 and residual.shape[-1] == Cout
+            rr, rl = _rows_ld(residual)
+            assert rr == rows
+        nws = _lib.size_query("adap_conv2d_workspace_floats", 1, rows, 1, Cin, Cout, 1, 1)
+        ws = torch.empty(nws, device=dev, dtype=F32) if nws else None
+        rc = _conv2d_entry()(x.data_ptr(), _dt(x), ld, w_packed.data_ptr(), 0 if bias is None else bias.data_ptr(), 0, 0,
+                             0 if residual is None else residual.data_ptr(), rl, 0 if y32 is None else y32.data_ptr(),
+                             Cout if y32 is not None else 0, 0 if y16 is None else y16.data_ptr(), Cout if y16 is not None else 0,
+                             1, rows, 1, Cin, rows, 1, Cout, 1, 1, 1, 0, 0, float(alpha), 0, 0 if ws is None else ws.data_ptr(),
+                             1, 0, 0, 0, 0, _stream())
+        if rc != 0:
+            raise _lib.HipError(f"adap_conv2d_nhwc failed ({rc}): {_lib.load().adap_last_error().decode()}")
+        return y32, y16
     x4 = x.as_strided((1, rows, 1, shp[-1]), (rows * ld, ld, ld, 1))
     r4 = None
     if residual is not None:
