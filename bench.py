@@ -191,6 +191,10 @@ def main():
     from adaprompt_amd.parallel import GradReducer, init_distributed
 
     rank, world, local = init_distributed()
+    if world > 1:
+        # N ranks share the node's host cores: torch's CPU pool per rank at its share (the step's host side is one thread)
+        from adaprompt_amd import hostinfo
+        hostinfo.limit_torch_threads(cap=max(1, hostinfo.cpu_share() // world))
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -715,7 +719,8 @@ def main():
         raise SystemExit(f"rank {rank}: the single-launch GroupNorm's exchange timed out (ops.gn_sync_poisoned): results invalid")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU a 16-core CPU share; more torch threads than that only oversubscribe
-        threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+        from adaprompt_amd import hostinfo
+        threads = args.cpu_threads or min(16, hostinfo.cpu_share())
         del ld, hook, reducer, opt, sched
         torch.cuda.empty_cache()
         cpu = cpu_baseline(threads, batch=args.cpu_batch)

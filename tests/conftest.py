@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the CPU oracle runs on torch's intra-op pool: keep it at this process's CPU share (a GPU box shows 256 logical CPUs
+    # and allows 16; at torch's default of 128 threads the full-size oracle cases ran 2.7x slower, hostinfo.py)
+    from adaprompt_amd import hostinfo
+    hostinfo.limit_torch_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: full-size CPU oracle cases (tens of seconds)")
 

@@ -11,6 +11,8 @@ import sys
 import pytest
 import torch
 
+from adaprompt_amd import hostinfo
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -31,7 +33,8 @@ def test_training_step_two_ranks_matches_hand_averaged_step(reducer_backend):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   ADAP_DIST_BACKEND="nccl" if ndev >= 2 else "gloo")
+                   ADAP_DIST_BACKEND="nccl" if ndev >= 2 else "gloo",
+                   OMP_NUM_THREADS=str(max(1, hostinfo.cpu_share() // 2)))      # two ranks share this box's CPU quota
         if ndev < 2:          # two processes on one device: two-pass GroupNorm (two single-launch grids cannot both be resident)
             env["ADAP_GN_TWO_PASS"] = "1"
         if reducer_backend == "c_abi":
