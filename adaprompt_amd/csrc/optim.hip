@@ -189,6 +189,47 @@ __global__ __launch_bounds__(OPT_THREADS) void prodigy_update_kernel(float* __re
     }
 }
 
+// ---- Adam family (torch.optim.AdamW / torch.optim.NAdam, the reference's other `optimizer_type`s, ddpm.py:5134-5142,
+// 5188-5196).  One elementwise pass over a parameter group's range; every step-dependent scalar (bias corrections, NAdam's
+// momentum schedule) depends on the step count only, so the host computes it in fp64 and no state crosses the PCIe bus:
+//   g' = clip * g + wd_coupled * p;  p *= 1 - decay;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2
+//   p -= (cg * g' + cm * m) / (sqrt(v * inv_bc2) + eps)
+// AdamW: decay = lr * wd, cg = 0, cm = lr / (1 - b1^t).  NAdam: cg = lr (1 - mu_t) / (1 - prod mu), cm = lr mu_{t+1} / (1 -
+// prod mu * mu_{t+1}).  28 bytes per element (read p, g, m, v; write p, m, v): HBM-bound.
+struct AdamHyper { float b1, b2, eps, decay, wdc, inv_bc2, cg, cm; };
+
+__device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V, const AdamHyper& h, float clip) {
+    G *= clip;
+    if (h.wdc != 0.f) G = fmaf(h.wdc, P, G);
+    if (h.decay != 0.f) P = fmaf(-h.decay, P, P);
+    M = fmaf(h.b1, M, (1.f - h.b1) * G);
+    V = fmaf(h.b2, V, (1.f - h.b2) * G * G);
+    const float den = sqrtf(V * h.inv_bc2) + h.eps;
+    P -= fmaf(h.cg, G, h.cm * M) / den;
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adam_update_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                  float* __restrict__ m, float* __restrict__ v, long n,
+                                                                  const double* __restrict__ st, AdamHyper h) {
+    const float clip = (float)st[ST_CLIP];
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 P = ((float4*)p)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+        const float4 G = ((const float4*)g)[i];
+        adam_elem(P.x, G.x, M.x, V.x, h, clip);
+        adam_elem(P.y, G.y, M.y, V.y, h, clip);
+        adam_elem(P.z, G.z, M.z, V.z, h, clip);
+        adam_elem(P.w, G.w, M.w, V.w, h, clip);
+        ((float4*)p)[i] = P;
+        ((float4*)m)[i] = M;
+        ((float4*)v)[i] = V;
+    }
+    if (blockIdx.x == 0) {
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < n) adam_elem(p[i], g[i], m[i], v[i], h, clip);
+    }
+}
+
 __global__ void optim_state_init_kernel(double* st, double d0) {
     if (threadIdx.x < ST_COUNT) st[threadIdx.x] = 0.0;
     __syncthreads();
@@ -265,4 +306,22 @@ extern "C" int adap_prodigy_update(float* p, const float* m, const float* v, lon
     hipLaunchKernelGGL(prodigy_update_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, p, m,
                        v, n, state, eps, weight_decay_decoupled);
     return adap_check_launch("prodigy_update");
+}
+
+extern "C" int adap_adam_update(float* p, const float* g, float* m, float* v, long n, const double* state, double beta1,
+                                double beta2, double eps, double decay, double weight_decay_coupled,
+                                double inv_bias_correction2, double coef_grad, double coef_moment, void* stream) {
+    ADAP_REQUIRE(p && g && m && v && state && n >= 0, ADAP_ERR_SHAPE, "adam_update: null pointer or n < 0");
+    ADAP_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), ADAP_ERR_ALIGN,
+                 "adam_update: buffers must be 16-byte aligned");
+    ADAP_REQUIRE(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0 && inv_bias_correction2 > 0,
+                 ADAP_ERR_SHAPE, "adam_update: betas must be in [0,1), eps >= 0, inv_bias_correction2 > 0");
+    AdamHyper h{(float)beta1, (float)beta2, (float)eps, (float)decay, (float)weight_decay_coupled,
+                (float)inv_bias_correction2, (float)coef_grad, (float)coef_moment};
+    long blocks = ((n >> 2) + OPT_THREADS - 1) / OPT_THREADS;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, (hipStream_t)stream, p, g, m, v,
+                       n, state, h);
+    return adap_check_launch("adam_update");
 }

@@ -1295,8 +1295,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         (v1-finetune-ada.yaml:59,74-84).  ``optimized_parameters``: what ``EmbeddingManager.optimized_parameters()``
         returns -- a list of {'params', 'lr_ratio', 'excluded_from_prodigy'} (embedding_manager.py:2078-2095).  As in the
         reference, Prodigy gets ONE flat list (lr = 1) of the requires-grad parameters of every group that is not
-        ``excluded_from_prodigy`` -- the groups' learning-rate ratios (and ``model_lr``) only matter to the Adam variants,
-        which are not built here; ``unfreeze_model`` appends the UNet's (and ``extra_model_parameters``', e.g. the text
+        ``excluded_from_prodigy`` -- the groups' learning-rate ratios (and ``model_lr``) only matter to the Adam variants
+        (``optimizer_type: AdamW | NAdam`` -> ``_configure_adam``); ``unfreeze_model`` appends the UNet's (and ``extra_model_parameters``', e.g. the text
         encoder's) parameters (ddpm.py:5176-5181).  -> Lightning's [{'optimizer', 'frequency', 'lr_scheduler': {...}}]."""
         from ...prodigy import Prodigy
         from ...util import prodigy_linear_schedule
@@ -1313,9 +1313,14 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             unfreeze_model = bool(getattr(self, "unfreeze_model", False))
             if unfreeze_model and not extra_model_parameters and self.cond_stage_model is not None:
                 extra_model_parameters = list(self.cond_stage_model.parameters())      # ddpm.py:5179
-        if getattr(self, "optimizer_type", "Prodigy") != "Prodigy":
-            raise NotImplementedError("only optimizer_type 'Prodigy' (the shipped config) is built; AdamW / NAdam / "
-                                      "ProdigyAdamW are out of scope (DESIGN.md 7)")
+        otype = getattr(self, "optimizer_type", "Prodigy")
+        if otype in ("AdamW", "NAdam"):
+            return LatentDiffusion._configure_adam(self, otype, optimized_parameters, max_steps, weight_decay, unfreeze_model,
+                                        extra_model_parameters)
+        if otype != "Prodigy":
+            raise NotImplementedError(f"optimizer_type {otype!r}: 'Prodigy' (the shipped config), 'AdamW' and 'NAdam' are "
+                                      "built; 'ProdigyAdamW' (a second AdamW over the same parameters in the last cycle, "
+                                      "ddpm.py:5274-5302) is not")
         cfg = {"zs_betas": (0.9, 0.999), "betas": (0.985, 0.993), "d_coef": 2.0, "warm_up_steps": 500, "scheduler_cycles": 1,
                "scheduler_type": "Linear"}
         cfg.update(dict(prodigy_config or {}))
@@ -1332,6 +1337,38 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                       safeguard_warmup=cfg["scheduler_cycles"] > 1, use_bias_correction=True)
         sched = prodigy_linear_schedule(opt, max_steps=max_steps, warm_up_steps=cfg["warm_up_steps"],
                                         scheduler_cycles=cfg["scheduler_cycles"])
+        return [{"optimizer": opt, "frequency": 1, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}]
+
+    def _configure_adam(self, otype, optimized_parameters, max_steps, weight_decay, unfreeze_model, extra_model_parameters):
+        """``optimizer_type: AdamW | NAdam`` (ddpm.py:5134-5142, 5157-5196): one parameter group per embedding-manager
+        group at ``learning_rate * lr_ratio`` (requires-grad parameters only), with ``unfreeze_model`` one more at
+        ``model_lr`` holding the text encoder's and the UNet's parameters; betas from ``adam_config``; the LR multiplier
+        of ``adam_config.scheduler_config`` (yaml:65-72, ``max_decay_steps`` <- ``trainer.max_steps``) through a
+        ``LambdaLR``.  The optimisers are the flat-buffer HIP ones of ``ldm.adam`` (same arguments and state keys as
+        torch's)."""
+        from ...adam import AdamW, NAdam
+        from ...util import instantiate_from_config
+        from torch.optim.lr_scheduler import LambdaLR
+        lr = getattr(self, "learning_rate", None)
+        if lr is None:
+            raise AttributeError("configure_optimizers: `learning_rate` is not set on the model (main.py:1169-1172 sets "
+                                 "model.learning_rate and model.weight_decay before trainer.fit)")
+        acfg = self.adam_config
+        if acfg is None or "scheduler_config" not in acfg or "target" not in acfg["scheduler_config"]:
+            raise ValueError(f"optimizer_type {otype!r} needs adam_config.betas and adam_config.scheduler_config.target "
+                             "(yaml:63-72)")
+        groups = []
+        for g in optimized_parameters:
+            if len(g["params"]) > 0:
+                groups.append({"params": [q for q in g["params"] if q.requires_grad], "lr": lr * g["lr_ratio"],
+                               "excluded_from_prodigy": g.get("excluded_from_prodigy", False)})
+        if unfreeze_model:
+            groups.append({"params": list(extra_model_parameters) + list(self.model.parameters()), "lr": self.model_lr,
+                           "excluded_from_prodigy": False})
+        opt = (AdamW if otype == "AdamW" else NAdam)(groups, weight_decay=weight_decay, betas=tuple(acfg["betas"]))
+        scfg = {"target": acfg["scheduler_config"]["target"], "params": dict(acfg["scheduler_config"].get("params", {}))}
+        scfg["params"]["max_decay_steps"] = max_steps
+        sched = LambdaLR(opt, lr_lambda=instantiate_from_config(scfg).schedule)
         return [{"optimizer": opt, "frequency": 1, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}]
 
     def draw_iteration_flags(self, global_step, composition_regs_iter_gap=0, arc2face_distill_iter_prob=0.0,
@@ -1413,11 +1450,11 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if optimizer is not None and self.batch_idx % self.manual_accumulate_grad_batches == 0:
             if reducer is not None:
                 reducer.wait()
-            from ...prodigy import Prodigy
+            from ...flatopt import FlatParams
             # sync-free: raises if a single-launch GroupNorm's exchange timed out since the previous optimiser step (its
             # outputs were NaN then, so the loss already is; this names the cause)
             ops.gn_poison_poll()
-            if isinstance(optimizer, Prodigy):                 # clip fused into the flat-buffer step
+            if isinstance(optimizer, FlatParams):              # Prodigy / AdamW / NAdam: clip fused into the flat-buffer step
                 optimizer.step(clip_norm=self.grad_clip if self.grad_clip else None)
             else:
                 params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]

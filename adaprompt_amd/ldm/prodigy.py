@@ -2,11 +2,11 @@
 param-group keys, same ``state[p]`` keys (``step, s, p0, exp_avg, exp_avg_sq``) -- but the arithmetic runs in the
 flat-buffer HIP kernels of csrc/optim.hip.
 
-Layout: every parameter of every group is re-pointed (``p.data``) into ONE flat fp32 buffer, group ranges padded to
-16 bytes; ``p.grad`` are views of a second flat buffer (share it with ``adaprompt_amd.parallel.GradReducer`` through
-``grad_buffer``), and ``p0 / exp_avg / exp_avg_sq / s`` are three more.  d, d_max, d_numerator, k ... live in a
-16-double device array, so ``step()`` issues five kernel launches and never synchronises with the host (the
-reference calls ``.item()`` twice per parameter).  ``sync_group_state()`` copies them into ``param_groups`` on demand
+Layout (``flatopt.FlatParams``, shared with ``ldm.adam``): every parameter of every group is re-pointed (``p.data``)
+into ONE flat fp32 buffer, group ranges padded to 16 bytes; ``p.grad`` are views of a second flat buffer (share it with
+``adaprompt_amd.parallel.GradReducer`` through ``grad_buffer``), and ``p0 / exp_avg / exp_avg_sq / s`` are four more.
+d, d_max, d_numerator, k ... live in a 16-double device array, so ``step()`` issues five kernel launches and never
+synchronises with the host (the reference calls ``.item()`` twice per parameter).  ``sync_group_state()`` copies them into ``param_groups`` on demand
 (checkpointing, logging).
 
 Differences a caller can observe, all deliberate:
@@ -22,6 +22,7 @@ import math
 import torch
 
 from .. import _lib
+from .flatopt import FlatParams
 
 _ST_KEYS = ("d", "d_max", "d_numerator", "d_denom", "d_hat", "k")
 
@@ -29,7 +30,9 @@ _ST_KEYS = ("d", "d_max", "d_numerator", "d_denom", "d_hat", "k")
 _stream = _lib.current_stream
 
 
-class Prodigy(torch.optim.Optimizer):
+class Prodigy(FlatParams, torch.optim.Optimizer):
+    _name = "Prodigy"
+
     def __init__(self, params, lr=1.0, betas=(0.9, 0.999), beta3=None, eps=1e-8, weight_decay=0, decouple=True,
                  use_bias_correction=False, safeguard_warmup=False, d0=1e-6, d_coef=1.0, growth_rate=float("inf"),
                  fsdp_in_use=False):
@@ -64,59 +67,17 @@ class Prodigy(torch.optim.Optimizer):
     def supports_flat_params(self):
         return True
 
-    # ------------------------------------------------------------------ flat storage
-    def _build_flat(self):
-        groups = self.param_groups
-        plist = [p for g in groups for p in g["params"]]
-        if not plist:
-            raise ValueError("Prodigy: no parameters")
-        dev = plist[0].device
-        if dev.type != "cuda":
-            raise RuntimeError("Prodigy (MI355X): parameters must live on the GPU -- there is no CPU path")
+    # ------------------------------------------------------------------ flat storage (flatopt.FlatParams)
+    def _check_groups(self, groups):
         if any(g["d0"] != self.d0 for g in groups):
             raise RuntimeError("Prodigy (MI355X): d0 must be the same in every parameter group")
-        self._ranges, self._views, off = [], [], 0
-        for g in groups:
-            start = off
-            for p in g["params"]:
-                if p.dtype != torch.float32 or p.device != dev:
-                    raise TypeError("Prodigy (MI355X): parameters must be fp32 on one device")
-                self._views.append((p, off, p.numel()))
-                off += p.numel()
-            off = (off + 3) // 4 * 4                      # next group starts 16-byte aligned
-            self._ranges.append((start, off - start))
-        n = off
-        f32 = dict(device=dev, dtype=torch.float32)
-        self._flat = torch.zeros(n, **f32)
-        old_grads = []
-        for p, o, k in self._views:
-            self._flat[o:o + k].copy_(p.detach().reshape(-1))
-            p.data = self._flat[o:o + k].view(p.shape)
-            old_grads.append(p.grad)
-        self._grad = torch.zeros(n, **f32)
-        for (p, o, k), g in zip(self._views, old_grads):
-            if g is not None:
-                self._grad[o:o + k].copy_(g.reshape(-1))
-            p.grad = self._grad[o:o + k].view(p.shape)
+
+    def _state_d0(self):
+        return self.d0
+
+    def _build_flat(self):
+        super()._build_flat()
         self._p0 = self._m = self._v = self._s = None
-        self._state = torch.zeros(16, device=dev, dtype=torch.float64)
-        _lib.call("adap_prodigy_state_init", self._state.data_ptr(), float(self.d0), _stream())
-        self._ws = torch.zeros(_lib.call_long("adap_optim_workspace_doubles", len(groups)), device=dev,
-                               dtype=torch.float64)
-        self._n = n
-
-    @property
-    def grad_buffer(self):
-        """the flat fp32 gradient buffer all ``p.grad`` are views of (hand it to GradReducer(flat=...))."""
-        if self._flat is None:
-            self._build_flat()
-        return self._grad
-
-    @property
-    def param_buffer(self):
-        if self._flat is None:
-            self._build_flat()
-        return self._flat
 
     def _init_moments(self):
         # prodigy.py:166-173: state is created at the first step, p0 = the parameters at that moment
@@ -131,18 +92,6 @@ class Prodigy(torch.optim.Optimizer):
             st["p0"] = self._p0[o:o + k].view(p.shape)
             st["exp_avg"] = self._m[o:o + k].view(p.shape)
             st["exp_avg_sq"] = self._v[o:o + k].view(p.shape)
-
-    def _gather_stray_grads(self):
-        """a caller (or autograd after set_to_none) may have replaced p.grad: fold it back into the flat buffer."""
-        for p, o, k in self._views:
-            g = p.grad
-            want = self._grad[o:o + k]
-            if g is None:
-                want.zero_()
-                p.grad = want.view(p.shape)
-            elif g.data_ptr() != want.data_ptr():
-                want.copy_(g.reshape(-1))
-                p.grad = want.view(p.shape)
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
@@ -166,10 +115,7 @@ class Prodigy(torch.optim.Optimizer):
                 raise RuntimeError("Setting different lr values in different parameter groups is only supported for "
                                    "values of 0")
         st, ws, s = self._state.data_ptr(), self._ws.data_ptr(), _stream()
-        if clip_norm is not None and clip_norm > 0:
-            _lib.call("adap_grad_clip_coef", self._grad.data_ptr(), self._n, float(clip_norm), st, ws, s)
-        else:
-            self._state[6] = 1.0
+        self._clip(clip_norm)
         active = [i for i, g in enumerate(self.param_groups) if g["lr"] > 0.0 and self._ranges[i][1] > 0]
         if not active:                               # every d_denom term is absent: prodigy.py:200-201
             return loss
@@ -191,16 +137,8 @@ class Prodigy(torch.optim.Optimizer):
             dec = float(g["weight_decay"]) if (g["weight_decay"] != 0 and g0["decouple"]) else 0.0
             _lib.call("adap_prodigy_update", self._flat[o:].data_ptr(), self._m[o:].data_ptr(),
                       self._v[o:].data_ptr(), k, st, float(g["eps"]), dec, s)
-        # the kernels wrote the parameters through raw pointers: tell torch, so that anything keyed on Tensor._version
-        # (the bf16 weight packs of a training UNet, functional.WeightCache) is rebuilt
-        torch.autograd.graph.increment_version([p for p, _, _ in self._views])
+        self._touched()
         return loss
-
-    def zero_grad(self, set_to_none=False):
-        if self._flat is None:
-            return super().zero_grad(set_to_none=set_to_none)
-        self._gather_stray_grads()
-        self._grad.zero_()
 
     # ------------------------------------------------------------------ host view of the device state
     def device_state(self):

@@ -394,6 +394,16 @@ int adap_prodigy_finish(double* state, const double* workspace, int nslots, doub
 /* prodigy.py:231-248: p -= dlr * m / (sqrt(v) + d_new * eps), after p *= 1 - weight_decay_decoupled * dlr. */
 int adap_prodigy_update(float* p, const float* m, const float* v, long n, const double* state, double eps,
                         double weight_decay_decoupled, void* stream);
+/* The reference's other optimizer_type values, torch.optim.AdamW / torch.optim.NAdam (ddpm.py:5134-5142, 5188-5196), as one
+ * pass over a parameter group's range of the flat buffers (state = the 16-double array above: only [6], the clip
+ * coefficient, is read).  The step-dependent scalars depend on the step count alone and come from the host:
+ *   g' = state[6] * g + weight_decay_coupled * p;  p *= 1 - decay;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   p -= (coef_grad * g' + coef_moment * m) / (sqrt(v * inv_bias_correction2) + eps)
+ * AdamW: decay = lr * weight_decay, coef_grad = 0, coef_moment = lr / (1 - b1^t), inv_bias_correction2 = 1 / (1 - b2^t).
+ * NAdam: coef_grad = lr (1 - mu_t) / (1 - prod_i mu_i), coef_moment = lr mu_{t+1} / (1 - mu_{t+1} prod_i mu_i). */
+int adap_adam_update(float* p, const float* g, float* m, float* v, long n, const double* state, double beta1,
+                     double beta2, double eps, double decay, double weight_decay_coupled, double inv_bias_correction2,
+                     double coef_grad, double coef_moment, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Weight gradients (`unfreeze_model: True`, ddpm.py:775-786: the UNet's own parameters train; what torch autograd's
