@@ -6,7 +6,7 @@ Resolution order for ``ldm.<name>`` (this repo AHEAD of the reference checkout o
   1. ``adaprompt_amd.ldm.<name>`` when this repo mirrors the module -- the SAME module object is
      returned (no second copy of the classes), its own ``__spec__`` / ``__name__`` left untouched;
   2. otherwise the reference's own ``ldm/<name>`` (``ldm.modules.embedding_manager``,
-     ``ldm.modules.encoders.modules``, ``ldm.lr_scheduler``, ``ldm.data.*``, ``ldm.modules.x_transformer`` ...):
+     ``ldm.modules.encoders.modules``, ``ldm.data.*``, ``ldm.modules.x_transformer`` ...):
      every later ``sys.path`` entry (and ``$ADAPROMPT_REFERENCE_ROOT``) holding an ``ldm/`` directory is a
      fall-through root, so the un-mirrored boundary callees keep importing as they always did.
 The finder answers for every ``ldm.*`` name whatever ``sys.modules['ldm']`` currently is -- the reference's
