@@ -196,14 +196,14 @@ __global__ __launch_bounds__(OPT_THREADS) void prodigy_update_kernel(float* __re
 //   p -= (cg * g' + cm * m) / (sqrt(v * inv_bc2) + eps)
 // AdamW: decay = lr * wd, cg = 0, cm = lr / (1 - b1^t).  NAdam: cg = lr (1 - mu_t) / (1 - prod mu), cm = lr mu_{t+1} / (1 -
 // prod mu * mu_{t+1}).  28 bytes per element (read p, g, m, v; write p, m, v): HBM-bound.
-struct AdamHyper { float b1, b2, eps, decay, wdc, inv_bc2, cg, cm; };
+struct AdamHyper { float b1, b2, omb1, omb2, eps, decay, wdc, inv_bc2, cg, cm; };   // omb = 1 - beta, rounded from fp64
 
 __device__ __forceinline__ void adam_elem(float& P, float G, float& M, float& V, const AdamHyper& h, float clip) {
     G *= clip;
     if (h.wdc != 0.f) G = fmaf(h.wdc, P, G);
     if (h.decay != 0.f) P = fmaf(-h.decay, P, P);
-    M = fmaf(h.b1, M, (1.f - h.b1) * G);
-    V = fmaf(h.b2, V, (1.f - h.b2) * G * G);
+    M = fmaf(h.b1, M, h.omb1 * G);
+    V = fmaf(h.b2, V, h.omb2 * G * G);
     const float den = sqrtf(V * h.inv_bc2) + h.eps;
     P -= fmaf(h.cg, G, h.cm * M) / den;
 }
@@ -316,7 +316,7 @@ extern "C" int adap_adam_update(float* p, const float* g, float* m, float* v, lo
                  "adam_update: buffers must be 16-byte aligned");
     ADAP_REQUIRE(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0 && inv_bias_correction2 > 0,
                  ADAP_ERR_SHAPE, "adam_update: betas must be in [0,1), eps >= 0, inv_bias_correction2 > 0");
-    AdamHyper h{(float)beta1, (float)beta2, (float)eps, (float)decay, (float)weight_decay_coupled,
+    AdamHyper h{(float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)decay, (float)weight_decay_coupled,
                 (float)inv_bias_correction2, (float)coef_grad, (float)coef_moment};
     long blocks = ((n >> 2) + OPT_THREADS - 1) / OPT_THREADS;
     if (blocks < 1) blocks = 1;

@@ -87,3 +87,76 @@ def test_flat_adam_shares_its_gradient_buffer_with_the_reducer_and_counts_versio
     ps[0].grad = None                                                   # a stray None gradient counts as zero
     opt.step()
     assert ps[0].grad is not None and float(ps[0].grad.abs().sum()) == 0.0
+
+
+def test_training_step_under_adamw_replays_on_torch_optim():
+    """a1 with ``optimizer_type: AdamW``: four micro-batches through ``LatentDiffusion.training_step`` with what
+    ``configure_optimizers`` returns (flat-buffer AdamW + LambdaLR over the yaml's schedule) and the GradReducer on the
+    optimiser's buffer -- accumulate two micro-batches, clip 0.5, step, zero, scheduler (ddpm.py:583-633).  The accumulated
+    gradient is captured right before each optimiser step and replayed through ``clip_grad_norm_`` + ``torch.optim.AdamW`` +
+    the same LambdaLR on the CPU: the parameters must agree, i.e. nothing was stepped twice, left unclipped or read stale."""
+    from adaprompt_amd import synth
+    from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
+    from adaprompt_amd.ldm.lr_scheduler import LambdaWarmUpCosineScheduler
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.parallel import GradReducer
+    from conftest import border_mask, ellipse_mask
+    dev = torch.device("cuda:0")
+    ucfg = dict(synth.SD15_UNET, model_channels=64, context_dim=128)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    torch.manual_seed(3)
+    hook = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
+    with torch.no_grad():
+        hook.bases.mul_(20.0)
+    init = [p.detach().clone() for p in hook.parameters()]
+    hook = hook.to(dev)
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                                  {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
+                                  cond_fn=make_cond_fn(hook, capture=False))
+    ld.load_state_dict(synth.synthetic_unet_state_dict(ucfg), strict=False)
+    ld = ld.to(dev)
+    ld.freeze_unet()
+    sparams = {"verbosity_interval": 0, "warm_up_steps": 2, "lr_start": 0.01, "lr_max": 1.0, "lr_min": 0.1}
+    ld.optimizer_type, ld.learning_rate = "AdamW", 1e-3
+    ld.adam_config = {"betas": [0.9, 0.993], "scheduler_config": {"target": "ldm.lr_scheduler.LambdaWarmUpCosineScheduler",
+                                                                  "params": sparams}}
+    params = list(hook.parameters())
+    split = max(1, len(params) // 2)
+    groups = [{"params": params[:split], "lr_ratio": 1.0, "excluded_from_prodigy": False},
+              {"params": params[split:], "lr_ratio": 0.25, "excluded_from_prodigy": True}]
+    groups = [g for g in groups if g["params"]]
+    conf = ld.configure_optimizers(groups, max_steps=4, weight_decay=0.01, unfreeze_model=False)[0]
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    red = GradReducer(params, flat=opt.grad_buffer)
+    snaps = []
+    opt.register_step_pre_hook(lambda o, a, k: snaps.append([p.grad.detach().cpu().clone() for p in params]))
+    B = 2
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+    for mb in range(4):
+        x0 = synth.synthetic_input(f"loop.x0.{mb}", (B, 4, 64, 64))
+        noise = synth.synthetic_input(f"loop.noise.{mb}", (B, 4, 64, 64))
+        ids = synth.synthetic_input(f"loop.ids.{mb}", (B, 32))
+        t = torch.tensor([150 + 200 * mb, 900 - 100 * mb])
+        batch = {"zs_id_embs": ids.to(dev), "fg_mask": fg64[:, 0].to(dev), "aug_mask": im64[:, 0].to(dev)}
+        loss, _aux = ld.training_step(batch, optimizer=opt, reducer=red, scheduler=sched, t=t.to(dev), noise=noise.to(dev),
+                                      x_start=x0.to(dev))
+        assert torch.isfinite(loss)
+    assert len(snaps) == 2 and all(float(torch.cat([g.flatten() for g in s]).norm()) > 0 for s in snaps)
+    assert float(opt.grad_buffer.abs().max()) == 0.0                    # zeroed after the step
+    # ---- the same two optimiser steps on the CPU with torch's own AdamW
+    ref = [torch.nn.Parameter(p.clone()) for p in init]
+    rgroups = [{"params": ref[:split], "lr": 1e-3}, {"params": ref[split:], "lr": 0.25e-3}]
+    ropt = torch.optim.AdamW([g for g in rgroups if g["params"]], betas=(0.9, 0.993), weight_decay=0.01, foreach=False)
+    rsched = torch.optim.lr_scheduler.LambdaLR(ropt, lr_lambda=LambdaWarmUpCosineScheduler(max_decay_steps=4, **sparams).schedule)
+    for s in snaps:
+        for p, g in zip(ref, s):
+            p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        ropt.step()
+        rsched.step()
+    for g, rg in zip(opt.param_groups, ropt.param_groups):
+        assert abs(g["lr"] - rg["lr"]) < 1e-15
+    for p, r, p0 in zip(params, ref, init):
+        d_hip, d_ref = p.detach().cpu() - p0, r.detach() - p0
+        assert float(d_ref.abs().max()) > 0
+        assert rel_err(d_hip, d_ref) < 1e-4, rel_err(d_hip, d_ref)

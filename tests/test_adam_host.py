@@ -88,8 +88,8 @@ def adam_update_formula(p, g, m, v, b1, b2, eps, decay, wdc, inv_bc2, cg, cm, cl
     f = lambda x: torch.tensor(x, dtype=torch.float32)               # noqa: E731
     g = g * f(clip) + f(wdc) * p
     p = p - f(decay) * p
-    m = f(b1) * m + (1 - f(b1)) * g
-    v = f(b2) * v + (1 - f(b2)) * g * g
+    m = f(b1) * m + f(1 - b1) * g
+    v = f(b2) * v + f(1 - b2) * g * g
     den = torch.sqrt(v * f(inv_bc2)) + f(eps)
     return p - (f(cg) * g + f(cm) * m) / den, m, v
 
