@@ -159,4 +159,6 @@ def test_training_step_under_adamw_replays_on_torch_optim():
     for p, r, p0 in zip(params, ref, init):
         d_hip, d_ref = p.detach().cpu() - p0, r.detach() - p0
         assert float(d_ref.abs().max()) > 0
-        assert rel_err(d_hip, d_ref) < 1e-4, rel_err(d_hip, d_ref)
+        # the update is ~5e-4 on parameters of magnitude up to ~1: one fp32 ulp of the parameter (6e-8) is 1.2e-4 of the
+        # update, and the two sides round differently (fused multiply-adds) -- measured 1.3e-4; plumbing mistakes are O(1)
+        assert rel_err(d_hip, d_ref) < 1e-3, rel_err(d_hip, d_ref)
