@@ -1291,15 +1291,15 @@ class LatentDiffusion(ConditioningMixin, DDPM):
 
     def configure_optimizers(self, optimized_parameters=None, max_steps=None, prodigy_config=None, weight_decay=None,
                              unfreeze_model=None, extra_model_parameters=()):
-        """The Prodigy branch of the reference's ``configure_optimizers`` (ddpm.py:5134-5345) with the 'Linear' schedule
-        (v1-finetune-ada.yaml:59,74-84).  ``optimized_parameters``: what ``EmbeddingManager.optimized_parameters()``
+        """The reference's ``configure_optimizers`` (ddpm.py:5134-5345): the Prodigy branch with its three schedule types
+        (the shipped config: 'Linear', v1-finetune-ada.yaml:59,74-84) and, through ``_configure_adam``, AdamW / NAdam.  ``optimized_parameters``: what ``EmbeddingManager.optimized_parameters()``
         returns -- a list of {'params', 'lr_ratio', 'excluded_from_prodigy'} (embedding_manager.py:2078-2095).  As in the
         reference, Prodigy gets ONE flat list (lr = 1) of the requires-grad parameters of every group that is not
         ``excluded_from_prodigy`` -- the groups' learning-rate ratios (and ``model_lr``) only matter to the Adam variants
-        (``optimizer_type: AdamW | NAdam`` -> ``_configure_adam``); ``unfreeze_model`` appends the UNet's (and ``extra_model_parameters``', e.g. the text
-        encoder's) parameters (ddpm.py:5176-5181).  -> Lightning's [{'optimizer', 'frequency', 'lr_scheduler': {...}}]."""
+        (``optimizer_type: AdamW | NAdam`` -> ``_configure_adam``); ``unfreeze_model`` appends the UNet's (and
+        ``extra_model_parameters``', e.g. the text encoder's) parameters (ddpm.py:5176-5181).  -> Lightning's [{'optimizer', 'frequency', 'lr_scheduler': {...}}]."""
         from ...prodigy import Prodigy
-        from ...util import prodigy_linear_schedule
+        from ...util import prodigy_schedule
         # Lightning's no-argument call: everything comes from the model and its trainer, as in the reference
         if optimized_parameters is None:
             optimized_parameters = self.embedding_manager.optimized_parameters()
@@ -1324,8 +1324,6 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         cfg = {"zs_betas": (0.9, 0.999), "betas": (0.985, 0.993), "d_coef": 2.0, "warm_up_steps": 500, "scheduler_cycles": 1,
                "scheduler_type": "Linear"}
         cfg.update(dict(prodigy_config or {}))
-        if cfg["scheduler_type"] != "Linear":
-            raise NotImplementedError(f"Prodigy scheduler_type {cfg['scheduler_type']!r}: only 'Linear' is built")
         groups = [{"params": [q for q in g["params"] if q.requires_grad],
                    "excluded_from_prodigy": g.get("excluded_from_prodigy", False)} for g in optimized_parameters]
         if unfreeze_model:
@@ -1335,8 +1333,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         opt = Prodigy(params, lr=1.0, weight_decay=weight_decay,
                       betas=tuple(cfg["zs_betas"] if self.do_zero_shot else cfg["betas"]), d_coef=cfg["d_coef"],
                       safeguard_warmup=cfg["scheduler_cycles"] > 1, use_bias_correction=True)
-        sched = prodigy_linear_schedule(opt, max_steps=max_steps, warm_up_steps=cfg["warm_up_steps"],
-                                        scheduler_cycles=cfg["scheduler_cycles"])
+        sched = prodigy_schedule(opt, max_steps=max_steps, warm_up_steps=cfg["warm_up_steps"],
+                                 scheduler_cycles=cfg["scheduler_cycles"], scheduler_type=cfg["scheduler_type"])
         return [{"optimizer": opt, "frequency": 1, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}]
 
     def _configure_adam(self, otype, optimized_parameters, max_steps, weight_decay, unfreeze_model, extra_model_parameters):

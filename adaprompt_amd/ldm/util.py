@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.optim.lr_scheduler import ConstantLR, PolynomialLR, SequentialLR
+from torch.optim.lr_scheduler import ConstantLR, CosineAnnealingWarmRestarts, CyclicLR, PolynomialLR, SequentialLR
 
 _PREFIX = "adaprompt_amd."
 
@@ -85,22 +85,42 @@ class SequentialLR2(SequentialLR):
         self._last_lr = scheduler.get_last_lr()
 
 
-def prodigy_linear_schedule(opt, max_steps, warm_up_steps, scheduler_cycles=1):
-    """The 'Linear' Prodigy LR schedule of ``configure_optimizers`` (reference ddpm.py:5219-5247, 5290-5296):
-    ConstantLR(factor 1) for ``warm_up_steps``, then ``scheduler_cycles`` linear decays, each to 0.1/1.1 of the base
-    LR (PolynomialLR power 1 over 1.1 x the cycle length), chained by SequentialLR2."""
+def prodigy_schedule(opt, max_steps, warm_up_steps, scheduler_cycles=1, scheduler_type="Linear"):
+    """The Prodigy LR schedules of ``configure_optimizers`` (reference ddpm.py:5215-5272), chained by SequentialLR2 after a
+    ConstantLR(factor 1) warm-up of ``warm_up_steps``:
+      'Linear'  ``scheduler_cycles`` linear decays, each to 0.1/1.1 of the base LR (PolynomialLR power 1 over 1.1 x the
+                cycle length), every cycle restarting at the base LR;
+      'CosineAnnealingWarmRestarts'  T_0 = int(cycle length), eta_min 0.1;
+      'CyclicLR'  triangular 0.1 <-> 1 with half-cycles of cycle length / 2, entered at its peak (``last_epoch`` = half a
+                cycle, and the hand-over does not reset it: ``start_from_epoch_0 = False``); as the first half-cycle runs
+                downwards, ``scheduler_cycles`` counts half a cycle less."""
     total_cycle_steps = max_steps - warm_up_steps
-    ncyc = int(scheduler_cycles)
-    single = total_cycle_steps / scheduler_cycles
-    last = total_cycle_steps - single * (scheduler_cycles - 1)
+    ncyc = scheduler_cycles - 0.5 if scheduler_type == "CyclicLR" else scheduler_cycles
+    single = total_cycle_steps / ncyc
+    last = total_cycle_steps - single * (ncyc - 1)
     milestones = [warm_up_steps]
     schedulers = [ConstantLR(opt, factor=1.0, total_iters=warm_up_steps)]
-    for c in range(ncyc):
-        steps = last if c == ncyc - 1 else single
-        if c != ncyc - 1:
-            milestones.append(milestones[-1] + steps)
-        schedulers.append(PolynomialLR(opt, power=1, total_iters=steps * 1.1))
+    if scheduler_type == "Linear":
+        ncyc = int(ncyc)
+        for c in range(ncyc):
+            steps = last if c == ncyc - 1 else single
+            if c != ncyc - 1:
+                milestones.append(milestones[-1] + steps)
+            schedulers.append(PolynomialLR(opt, power=1, total_iters=steps * 1.1))
+    elif scheduler_type == "CosineAnnealingWarmRestarts":
+        schedulers.append(CosineAnnealingWarmRestarts(opt, T_0=int(single), T_mult=1, eta_min=0.1, last_epoch=-1))
+    elif scheduler_type == "CyclicLR":
+        schedulers.append(CyclicLR(opt, base_lr=0.1, max_lr=1, step_size_up=single / 2, last_epoch=single / 2 - 1,
+                                   cycle_momentum=False))
+        schedulers[-1].start_from_epoch_0 = False
+    else:
+        raise NotImplementedError(f"Prodigy scheduler_type {scheduler_type!r} (ddpm.py:5268-5269 raises as well)")
     return SequentialLR2(opt, schedulers=schedulers, milestones=milestones)
+
+
+def prodigy_linear_schedule(opt, max_steps, warm_up_steps, scheduler_cycles=1):
+    """the shipped config's schedule (yaml:80-84): ``prodigy_schedule(..., scheduler_type='Linear')``."""
+    return prodigy_schedule(opt, max_steps, warm_up_steps, scheduler_cycles, "Linear")
 
 
 # ----------------------------------------------------------------------------------------------------------------

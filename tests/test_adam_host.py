@@ -173,3 +173,49 @@ def test_flat_adam_refuses_what_it_does_not_build():
     p[0].grad = torch.ones(3)
     with pytest.raises(RuntimeError, match="no CPU path"):          # the product never computes on the CPU
         opt.step()
+
+
+def _sched_cases():
+    g = load_golden("optim_schedules")
+    return g, json.loads(str(g["cases"]))
+
+
+@pytest.mark.parametrize("name", ["prodigy_linear_c1", "prodigy_linear_c2", "prodigy_cosine_c1", "prodigy_cosine_c2",
+                                  "prodigy_cyclic_c2", "adamw", "nadam_unfrozen"])
+def test_configure_optimizers_lr_sequences_match_the_reference(name):
+    """every optimizer_type / scheduler_type the mirror builds, against the reference's own ``configure_optimizers``
+    (tests/golden/make_golden_sched.py): optimiser and scheduler class, the parameter groups' sizes, and the learning rate of
+    every group before each of 40 optimiser steps."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    g, cases = _sched_cases()
+    case = cases[name]
+    sizes, ratios, excluded = g["group_sizes"].tolist(), g["lr_ratios"].tolist(), g["excluded"].tolist()
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    groups = [{"params": [p] + ([frozen] if i == 0 else []), "lr_ratio": r, "excluded_from_prodigy": bool(e)}
+              for i, (p, r, e) in enumerate(zip(params, ratios, excluded))]
+
+    class Stub:
+        optimizer_type, do_zero_shot = case["optimizer_type"], True
+        learning_rate, model_lr = 4e-4, 1e-6
+        model = torch.nn.Linear(3, 2)
+        adam_config = json.loads(str(g["adam_config"]))
+
+    text = list(torch.nn.Linear(2, 1).parameters())
+    max_steps = int(g["max_steps"])
+    conf = LatentDiffusion.configure_optimizers(
+        Stub(), groups, max_steps=max_steps, weight_decay=0.0, unfreeze_model=case.get("unfreeze_model", False),
+        extra_model_parameters=text,
+        prodigy_config={"zs_betas": [0.9, 0.999], "betas": [0.985, 0.993], "d_coef": 2, "warm_up_steps": 10,
+                        "scheduler_cycles": case.get("scheduler_cycles", 1),
+                        "scheduler_type": case.get("scheduler_type", "Linear")})
+    opt, sched = conf[0]["optimizer"], conf[0]["lr_scheduler"]["scheduler"]
+    assert type(opt).__name__ == str(g[name + "/opt_class"]) and type(sched).__name__ == str(g[name + "/sched_class"])
+    assert [sum(p.numel() for p in gr["params"]) for gr in opt.param_groups] == g[name + "/group_numel"].tolist()
+    assert list(opt.param_groups[0]["betas"]) == g[name + "/betas"].tolist()
+    want = g[name + "/lrs"].numpy()
+    for t in range(max_steps):
+        got = [gr["lr"] for gr in opt.param_groups]
+        np.testing.assert_allclose(got, want[t], rtol=1e-12, atol=1e-15, err_msg=f"step {t}")
+        opt._step_count = t + 1
+        sched.step()
