@@ -1320,7 +1320,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if otype != "Prodigy":
             raise NotImplementedError(f"optimizer_type {otype!r}: 'Prodigy' (the shipped config), 'AdamW' and 'NAdam' are "
                                       "built; 'ProdigyAdamW' (a second AdamW over the same parameters in the last cycle, "
-                                      "ddpm.py:5274-5302) is not")
+                                      "ddpm.py:5274-5302) is not -- the reference's own branch cannot run either: it hands "
+                                      "OneCycleLR a float total_steps (ddpm.py:5298-5300), which torch refuses")
         cfg = {"zs_betas": (0.9, 0.999), "betas": (0.985, 0.993), "d_coef": 2.0, "warm_up_steps": 500, "scheduler_cycles": 1,
                "scheduler_type": "Linear"}
         cfg.update(dict(prodigy_config or {}))
