@@ -194,7 +194,8 @@ def main():
     if world > 1:
         # N ranks share the node's host cores: torch's CPU pool per rank at its share (the step's host side is one thread)
         from adaprompt_amd import hostinfo
-        hostinfo.limit_torch_threads(cap=max(1, hostinfo.cpu_share() // world))
+        if os.environ.get("ADAP_BENCH_KEEP_TORCH_THREADS") != "1":
+            hostinfo.limit_torch_threads(cap=max(1, hostinfo.cpu_share() // world))
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
