@@ -191,11 +191,12 @@ def main():
     from adaprompt_amd.parallel import GradReducer, init_distributed
 
     rank, world, local = init_distributed()
-    if world > 1:
-        # N ranks share the node's host cores: torch's CPU pool per rank at its share (the step's host side is one thread)
+    if os.environ.get("ADAP_BENCH_KEEP_TORCH_THREADS") != "1":
+        # torch's CPU pool at this rank's share of the host cores (N ranks share the node's; a one-GPU box shows 256 CPUs and
+        # allows 16).  The step's host side is one thread, but an oversubscribed pool costs: two ranks on one box measured
+        # 281 vs 786 ms/step with / without the cap
         from adaprompt_amd import hostinfo
-        if os.environ.get("ADAP_BENCH_KEEP_TORCH_THREADS") != "1":
-            hostinfo.limit_torch_threads(cap=max(1, hostinfo.cpu_share() // world))
+        hostinfo.limit_torch_threads(cap=max(1, hostinfo.cpu_share() // world))
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
