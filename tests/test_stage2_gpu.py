@@ -141,8 +141,9 @@ def test_compositional_micro_batch_vs_oracle(size, B):
             # ~(2^-9 |feat|)^2 ~ 2e-5 under it, whatever its value
             # comp_single_map_align (~4e-4) sums what is left after a HARD elastic matching of query positions: a handful of
             # matches flip with the bf16 noise -- and from run to run with the summation order of the torch / rocBLAS products
-            # in that loss (measured over 6 runs: 1.3e-2 ... 1.2e-1 of it, i.e. up to 4.8e-5) -- so it gets an absolute floor as well
-            floor = {"feat_delta_align": 4e-5, "comp_single_map_align": 6e-5}.get(k, 2e-6)
+            # in that loss (measured over 6 runs: 1.3e-2 ... 1.2e-1 of it, i.e. up to 4.8e-5) -- so it gets an absolute floor as
+            # well, at 2.5x the worst run: the quantity is a count of flipped matches, heavy-tailed, and one failure ends a suite
+            floor = {"feat_delta_align": 4e-5, "comp_single_map_align": 1.2e-4}.get(k, 2e-6)
             assert abs(ph[k] - po[k]) < PART_TOL * abs(po[k]) + floor, (k, ph[k], po[k])
     assert report["loss"] < PART_TOL
     assert float(go["z"].norm()) > 0
