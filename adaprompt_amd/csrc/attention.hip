@@ -1820,6 +1820,50 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
     }
 }
 
+// Token maps alone (what the recon iteration's regularisers read of a layer, `dense=False` in ops.attention_capture):
+// T[n][g] = sum_m score[n][m] w[m][g] is linear in the pre-softmax scores, so T[n][g] = <q[n], scale * kw[g]> with
+// kw[g] = sum_m w[m][g] k[m] -- the factorisation the backward already uses (attn_tokmap_kw_kernel below).  No score row is
+// formed: a workgroup builds the G x d vectors of its (batch, head) in LDS from the <= 192 keys (keys no group lists are
+// skipped), then one thread per query row reads its d bf16 values and writes G floats.  HBM: q once (10 MB at 64 x 64, bs 4).
+#define TOKF_ROWS 256
+__global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __restrict__ q, long ldq,
+                                                              const uint16_t* __restrict__ k, long ldk,
+                                                              const float* __restrict__ tok_w, float* __restrict__ tokmap,
+                                                              int G, int H, int N, int M, int d, float scale) {
+    __shared__ float sKW[4 * 160];                  // [G <= 4][d <= 160]
+    const int tid = threadIdx.x;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    for (int idx = tid; idx < G * d; idx += 256) {
+        const int g = idx / d, c = idx - g * d;
+        float a = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float wv = tok_w[((size_t)b * M + m) * G + g];
+            if (wv != 0.f) a += wv * bf16_to_f32(k[((size_t)b * M + m) * ldk + head * d + c]);
+        }
+        sKW[idx] = a * scale;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * TOKF_ROWS + tid;
+    if (n >= N) return;
+    const uint16_t* qr = q + ((size_t)b * N + n) * ldq + head * d;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < d; c += 4) {                // d % 4 == 0 and 8-byte aligned rows: checked by the caller
+        const uint2 raw = *(const uint2*)(qr + c);
+        const float x0 = __builtin_bit_cast(float, raw.x << 16), x1 = __builtin_bit_cast(float, raw.x & 0xffff0000u);
+        const float x2 = __builtin_bit_cast(float, raw.y << 16), x3 = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (g < G) {
+                const float* kw = sKW + g * d + c;  // the same address in every lane: an LDS broadcast
+                acc[g] += (x0 * kw[0] + x1 * kw[1]) + (x2 * kw[2] + x3 * kw[3]);
+            }
+    }
+    float* out = tokmap + ((size_t)bh * N + n) * G;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (g < G) out[g] = acc[g];
+}
+
 extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
                                       float* q_scaled, const float* tok_w, float* tokmap, int G, int B, int H, int N, int M,
                                       int d, float scale, void* stream) {
@@ -1828,6 +1872,12 @@ extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, lo
     ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture: M=%d (cross-attention only, <= 192)", M);
     ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture: d=%d", d);
     ADAP_REQUIRE(d % 4 == 0, ADAP_ERR_UNSUPPORTED, "attention_capture: d must be a multiple of 4");
+    if (tokmap && !attnscore && !attn && !q_scaled && ldq % 4 == 0 && ((uintptr_t)q & 7) == 0 && (long)B * H <= 65535) {
+        hipLaunchKernelGGL(attn_tokmap_fwd_kernel, dim3((N + TOKF_ROWS - 1) / TOKF_ROWS, B * H), dim3(256), 0,
+                           (hipStream_t)stream, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, tok_w, tokmap, G, H, N, M, d,
+                           scale);
+        return adap_check_launch("attention_capture");
+    }
     size_t lds = ((size_t)M * (d + 4) + 4 * d + (tokmap ? (size_t)M * G : 0)) * 4;
     static bool attr = false;
     if (!attr) {

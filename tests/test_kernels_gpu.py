@@ -741,6 +741,10 @@ def test_attention_token_maps_fwd_bwd(B, N, M, d, G):
     sc, pr, qs, tm = ops.attention_capture(q.to(dev), k.to(dev), H, tok_w=w.to(dev))
     assert rel(tm.cpu(), t_ref.float()) < 1e-5
     assert rel(sc.cpu(), score.float()) < 1e-5
+    # the maps alone (what the recon iteration asks for): formed as <q, scale * sum_m w k> without any score row
+    none_sc, none_pr, none_qs, tm_only = ops.attention_capture(q.to(dev), k.to(dev), H, tok_w=w.to(dev), dense=False)
+    assert none_sc is None and none_pr is None and none_qs is None
+    assert rel(tm_only.cpu(), t_ref.float()) < 1e-5 and rel(tm_only.cpu(), tm.cpu()) < 1e-5
     dq, dk = dq0.to(dev).clone(), dk0.to(dev).clone()
     ops.attention_tokmap_bwd(dt.to(dev), w.to(dev), q.to(dev), k.to(dev), dq, dk, H)
     assert rel(dq.float().cpu(), dq_ref.float()) < 3e-3
