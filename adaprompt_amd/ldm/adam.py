@@ -41,6 +41,10 @@ class _FlatAdam(FlatParams, torch.optim.Optimizer):
         self._m = self._v = None
         self._steps = [0] * len(self.param_groups)
 
+    def _build_flat(self):
+        super()._build_flat()
+        self._steps += [0] * (len(self.param_groups) - len(self._steps))        # groups added after construction
+
     def _init_moments(self):
         self._m = torch.zeros_like(self._flat)
         self._v = torch.zeros_like(self._flat)
@@ -146,6 +150,10 @@ class NAdam(_FlatAdam):
         super().__init__(params, defaults, maximize=maximize, capturable=capturable, differentiable=differentiable)
         self._mu_product = [1.0] * len(self.param_groups)
         self._mu_t = {}
+
+    def _build_flat(self):
+        super()._build_flat()
+        self._mu_product += [1.0] * (len(self.param_groups) - len(self._mu_product))
 
     def _init_param_state(self, st, gi):
         if gi not in self._mu_t:

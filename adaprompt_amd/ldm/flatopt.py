@@ -54,6 +54,13 @@ class FlatParams:
                                dtype=torch.float64)
         self._n = n
 
+    def add_param_group(self, param_group):
+        """torch calls this for every group at construction; once the flat buffers exist the layout is fixed."""
+        if self._flat is not None:
+            raise RuntimeError(f"{self._name} (MI355X): parameter groups cannot be added once the flat buffers exist "
+                               "(every parameter's storage and gradient already live in them)")
+        super().add_param_group(param_group)
+
     def _check_groups(self, groups):
         pass
 

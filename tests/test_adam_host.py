@@ -219,3 +219,19 @@ def test_configure_optimizers_lr_sequences_match_the_reference(name):
         np.testing.assert_allclose(got, want[t], rtol=1e-12, atol=1e-15, err_msg=f"step {t}")
         opt._step_count = t + 1
         sched.step()
+
+
+def test_flat_optimisers_fix_their_groups_once_the_buffers_exist():
+    """``add_param_group`` works as in torch until the flat buffers are built (they hold every parameter's storage and
+    gradient, so the layout cannot grow afterwards)."""
+    from adaprompt_amd.ldm.adam import NAdam
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    for cls in (NAdam, Prodigy):
+        a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(5))
+        opt = cls([a], lr=1e-3 if cls is NAdam else 1.0)
+        opt.add_param_group({"params": [b]})
+        assert len(opt.param_groups) == 2 and opt.param_groups[1]["params"][0] is b
+        assert opt.param_groups[1]["betas"] == opt.param_groups[0]["betas"]          # defaults filled in, as torch does
+        opt._flat = torch.zeros(8)                   # what _build_flat leaves behind (it needs the GPU)
+        with pytest.raises(RuntimeError, match="cannot be added"):
+            opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))]})
