@@ -7,18 +7,19 @@ the GPU path depends on it."""
 import os
 
 
-def cpu_share():
+def cpu_share(cgroup_root="/sys/fs/cgroup"):
+    """CPUs this process may keep busy: scheduler affinity, cut by the cgroup's quota (v2 ``cpu.max``, v1 ``cpu/cpu.cfs_*``)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(os.path.join(cgroup_root, "cpu.max")) as f:
             quota, period = f.read().split()[:2]
         if quota != "max":
             n = min(n, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")) as f:
                 q = int(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            with open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")) as f:
                 p = int(f.read())
             if q > 0:
                 n = min(n, max(1, q // p))

@@ -442,3 +442,30 @@ def test_training_step_auto_iteration_dispatch():
     with pytest.raises(NotImplementedError):
         st.batch_idx = 12                                             # global step 6, a multiple of the gap
         LatentDiffusion.training_step(st, {}, auto_iteration={"max_steps": 100, "composition_regs_iter_gap": 3})
+
+
+def test_hostinfo_cpu_share_reads_the_cgroup_quota(tmp_path):
+    """the CPU oracle's thread count on a GPU box: 256 logical CPUs, cgroup quota 16 (profiles/r03_cpu_threads_probe.log)."""
+    import os
+    import torch
+    from adaprompt_amd import hostinfo
+    aff = len(os.sched_getaffinity(0))
+    assert hostinfo.cpu_share(str(tmp_path)) == aff                       # no cgroup files: the affinity
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert hostinfo.cpu_share(str(tmp_path)) == aff                       # v2, unlimited
+    (tmp_path / "cpu.max").write_text("200000 100000\n")
+    assert hostinfo.cpu_share(str(tmp_path)) == min(aff, 2)               # v2 quota
+    (tmp_path / "cpu.max").write_text("50000 100000\n")
+    assert hostinfo.cpu_share(str(tmp_path)) == 1                         # never below one
+    (tmp_path / "cpu.max").unlink()
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert hostinfo.cpu_share(str(tmp_path)) == min(aff, 3)               # v1 quota
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert hostinfo.cpu_share(str(tmp_path)) == aff                       # v1, unlimited
+    before = torch.get_num_threads()
+    try:
+        assert hostinfo.limit_torch_threads(cap=1) == 1 and torch.get_num_threads() == 1
+    finally:
+        torch.set_num_threads(before)
