@@ -235,3 +235,28 @@ def test_flat_optimisers_fix_their_groups_once_the_buffers_exist():
         opt._flat = torch.zeros(8)                   # what _build_flat leaves behind (it needs the GPU)
         with pytest.raises(RuntimeError, match="cannot be added"):
             opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))]})
+
+
+@pytest.mark.parametrize("clip", [0.0, 0.5])
+@pytest.mark.parametrize("case", list(ADAM_CASES))
+def test_adam_oracle_matches_torch_optim(case, clip):
+    """oracle/adam_oracle.py (the documented update rules, restated) against the third-party classes the reference
+    instantiates -- the same seeded two-group trajectories under a LambdaLR the HIP optimisers are held to on the GPU."""
+    from oracle.adam_oracle import AdamOracle, clip_grad_norm
+    nsteps = 8
+    want, _ = torch_optim_trajectory(case, nsteps, clip)
+    cls, kw = ADAM_CASES[case]
+    p0, gs = adam_data(case, nsteps)
+    ps = [p.clone() for p in p0]
+    groups = [{"params": ps[:2], "lr": ADAM_LRS[0]}, {"params": ps[2:], "lr": ADAM_LRS[1]}]
+    okw = {k: v for k, v in kw.items() if k in ("betas", "weight_decay", "momentum_decay", "decoupled_weight_decay")}
+    orc = AdamOracle(groups, variant="AdamW" if cls is torch.optim.AdamW else "NAdam", **okw)
+    for t in range(nsteps):
+        for g, base in zip(groups, ADAM_LRS):
+            g["lr"] = base * (0.5 + 0.1 * t)                          # the LambdaLR of torch_optim_trajectory
+        grads = [g.clone() for g in gs[t]]
+        if clip > 0:
+            clip_grad_norm(grads, clip)
+        orc.step(grads)
+        got = torch.cat([p.flatten() for p in ps])
+        assert rel_err(got, want[t]) < 1e-6, (t, rel_err(got, want[t]))
