@@ -1678,6 +1678,12 @@ extern "C" int adap_conv2d_nhwc(
     float alpha, int ksplit, float* splitk_ws,
     int nbatch, long bs_x, long bs_w, long bs_y32, long bs_y16,
     void* stream) {
+    // the one-shot GroupNorm-statistics request is consumed by THIS call whatever happens to it: were it left armed behind a
+    // failed argument check, a later conv of this thread would write its records into a buffer the caller has freed by then
+    float* const gn_next = g_gn_next;
+    const int gn_next_cpg = g_gn_next_cpg;
+    g_gn_next = nullptr;
+    g_gn_last_chunks = 0;
     ADAP_REQUIRE(x && w_packed && (y32 || y16), ADAP_ERR_SHAPE, "conv2d: null pointer");
     ADAP_REQUIRE(x_dtype == 0 || x_dtype == 1, ADAP_ERR_UNSUPPORTED, "conv2d: x_dtype %d", x_dtype);
     ADAP_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cin > 0 && Cout > 0,
@@ -1713,10 +1719,6 @@ extern "C" int adap_conv2d_nhwc(
     p.ktiles_per_tap = (Cin + BK - 1) / BK;
     p.ktiles_total = KH * KW * p.ktiles_per_tap;
     p.epi = g_epi_ext.epi; p.z16 = g_epi_ext.z16; p.ldz16 = g_epi_ext.ldz16; p.h16 = g_epi_ext.h16; p.ldh16 = g_epi_ext.ldh16;
-    float* const gn_next = g_gn_next;            // one shot: consumed by this call whatever kernel it dispatches to
-    const int gn_next_cpg = g_gn_next_cpg;
-    g_gn_next = nullptr;
-    g_gn_last_chunks = 0;
     p.gn_part = nullptr;
     p.gn_cpg = 0;
     const bool halo = choose_halo(Hin, Win, Hout, Wout, Cin, Cout, KH, KW, stride, pad, up, x_dtype, nbatch);

@@ -361,6 +361,8 @@ extern "C" int adap_groupnorm_fwd_stats(const void* x, int x_dtype, long ldx, co
     ADAP_REQUIRE(!y32 || (ldy32 % 4 == 0 && ((uintptr_t)y32 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd_stats: y32 alignment");
     ADAP_REQUIRE(!y16 || (ldy16 % 8 == 0 && ((uintptr_t)y16 % 16) == 0), ADAP_ERR_ALIGN, "groupnorm_fwd_stats: y16 alignment");
     ADAP_REQUIRE(B > 0 && HW > 0 && stats_chunks > 0, ADAP_ERR_SHAPE, "groupnorm_fwd_stats: empty");
+    ADAP_REQUIRE(HW % 64 == 0 && stats_chunks == HW / 64, ADAP_ERR_SHAPE,
+                 "groupnorm_fwd_stats: %d records per image for HW=%d (one per 64 pixels expected)", stats_chunks, HW);
     int n, rpc;
     gn_chunks(HW, C, &n, &rpc);
     hipStream_t s = (hipStream_t)stream;

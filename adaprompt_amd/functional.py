@@ -257,6 +257,29 @@ def train_of(**layers):
 GRAD_DONE = None
 
 
+# How often a block's backward will run before its parameters' gradients are final: a block Function invoked several times in
+# one graph (shared_step(batched_student=False, num_denoising_steps > 1): ND UNet passes under one autograd.backward) adds into
+# the same flat-buffer range once per invocation.  Every block forward that records a backward node counts here, per trainable
+# parameter; GradReducer.begin_backward() takes the counts and lets a chunk go out only after the LAST expected completion.
+FWD_PASSES = {}
+
+
+def _note_forward(ctx, T):
+    if T is None or not any(ctx.needs_input_grad):        # frozen block, or no backward node (no-grad pass)
+        return
+    for w, b in T.values():
+        for p_ in (w, b):
+            if p_ is not None and p_.requires_grad:
+                FWD_PASSES[id(p_)] = FWD_PASSES.get(id(p_), 0) + 1
+
+
+def take_forward_passes():
+    """{id(param): block invocations recorded since the last call}; resets the counters."""
+    out = dict(FWD_PASSES)
+    FWD_PASSES.clear()
+    return out
+
+
 def _grads_done(T):
     if GRAD_DONE is not None and T is not None:
         for w, b in T.values():
@@ -332,6 +355,7 @@ class ResBlockFn(torch.autograd.Function):
     def forward(ctx, x, emb_out, P):
         """x [B,H,W,Cin] f32; emb_out [B,Cout] f32 (= emb_layers(emb), added per (batch, channel));
         P: dict with gn1/gn2 (gamma, beta), conv1/conv2/skip PackedConv."""
+        _note_forward(ctx, P.get("train"))
         g1w, g1b = P["gn1"]
         g2w, g2b = P["gn2"]
         c1, c2, sk = P["conv1"], P["conv2"], P["skip"]
@@ -455,6 +479,7 @@ class ResBlockFn(torch.autograd.Function):
 class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None, tokmap_only=False):
+        _note_forward(ctx, P.get("train"))
         B, H, W, C = x.shape
         N = H * W
         same_ctx = ctx_k is ctx_v or (ctx_k.data_ptr() == ctx_v.data_ptr() and ctx_k.shape == ctx_v.shape)
@@ -716,6 +741,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pk, mode, train=None):
+        _note_forward(ctx, train)
         ctx.pk, ctx.mode, ctx.in_hw, ctx.train = pk, mode, (x.shape[1], x.shape[2]), train
         ctx.save_for_backward(x if train is not None else None)
         if mode == "down":
@@ -750,6 +776,7 @@ class OutHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, gn, pk, train=None):
+        _note_forward(ctx, train)
         _, a, m, r = ops.groupnorm_fwd(h, gn[0], gn[1], 1e-5, 1)
         y, _ = ops.conv2d(a, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
         ctx.gn, ctx.pk, ctx.train = gn, pk, train
@@ -778,6 +805,7 @@ class InConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pk, train, anchor):
+        _note_forward(ctx, train)
         x16 = ops.pad_cast_bf16(x, pk.I8)
         y, _ = ops.conv2d(x16, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
         ctx.train = train

@@ -8,8 +8,9 @@ step never reads the device.
 
 Differences a caller can observe, all deliberate (the same as ``ldm.prodigy.Prodigy``'s):
   * ``step(clip_norm=0.5)`` fuses ``clip_grad_norm_`` into the step; the clipped gradient is not written back.
-  * gradients are never ``None``: a parameter that received no gradient sees g = 0 (torch would skip it, leaving its
-    moments and step count untouched).
+  * gradients are never ``None``: a TRAINABLE parameter that received no gradient in a step sees g = 0 (torch would skip
+    it, leaving its moments and step count untouched).  ``requires_grad=False`` parameters of a group (as of the first
+    step) are laid out behind the group's trainable ones and never touched: no decay, no update, as in torch.
   * ``amsgrad``, ``maximize``, ``capturable``, ``differentiable`` and tensor learning rates raise.
 There is no CPU fallback: parameters must be CUDA tensors and the HIP library must load."""
 import torch
@@ -81,7 +82,7 @@ class _FlatAdam(FlatParams, torch.optim.Optimizer):
         self._clip(clip_norm)
         st, s = self._state.data_ptr(), _stream()
         for gi, g in enumerate(self.param_groups):
-            o, k = self._ranges[gi]
+            o, k = self._train_ranges[gi]               # the group's trainable span (flatopt: frozen tensors lie behind it)
             if k == 0:
                 continue
             self._steps[gi] += 1

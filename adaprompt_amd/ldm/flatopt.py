@@ -25,16 +25,24 @@ class FlatParams:
         if dev.type != "cuda":
             raise RuntimeError(f"{self._name} (MI355X): parameters must live on the GPU -- there is no CPU path")
         self._check_groups(groups)
-        self._ranges, self._views, off = [], [], 0
+        self._ranges, self._train_ranges, self._views, off = [], [], [], 0
         for g in groups:
             start = off
-            for p in g["params"]:
+            # a group's trainable parameters first, its requires_grad=False ones behind them: ``_train_ranges`` is the span an
+            # optimiser that must leave frozen tensors alone steps over (torch.optim skips parameters without a gradient;
+            # the reference's unfreeze group is list(model.parameters()), frozen buffers-as-parameters included)
+            ordered = [p for p in g["params"] if p.requires_grad] + [p for p in g["params"] if not p.requires_grad]
+            train_end = off
+            for p in ordered:
                 if p.dtype != torch.float32 or p.device != dev:
                     raise TypeError(f"{self._name} (MI355X): parameters must be fp32 on one device")
                 self._views.append((p, off, p.numel()))
                 off += p.numel()
+                if p.requires_grad:
+                    train_end = off
             off = (off + 3) // 4 * 4                      # next group starts 16-byte aligned
             self._ranges.append((start, off - start))
+            self._train_ranges.append((start, train_end - start))
         n = off
         f32 = dict(device=dev, dtype=torch.float32)
         self._flat = torch.zeros(n, **f32)

@@ -1417,56 +1417,180 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                                   "mix_prompt_distill_weight": self.mix_prompt_distill_weight,
                                   "max_num_denoising_steps": self.max_num_denoising_steps}
         if auto_iteration is not None:
-            cfg = auto_iteration
-            gstep = self.batch_idx // self.manual_accumulate_grad_batches            # Lightning's global_step
-            self.training_percent = min(1.0, gstep * self.manual_accumulate_grad_batches / max(1, cfg.get("max_steps", 1)))
-            flags = self.draw_iteration_flags(gstep, cfg.get("composition_regs_iter_gap", 0),
-                                              cfg.get("arc2face_distill_iter_prob", 0.0),
-                                              cfg.get("mix_prompt_distill_weight", 0.0))
-            if flags["is_compos_iter"] and not (flags["do_mix_prompt_distillation"] and self.embedding_manager is not None
-                                                and getattr(self, "clip_score_fn", None) is not None):
-                raise NotImplementedError("a compositional iteration needs mix_prompt_distill_weight > 0, the reference's "
-                                          "conditioning side (cond_stage_config + personalization_config) and a clip_score_fn; "
-                                          "the ada-delta-only ablation form is not built")
-            if flags["do_arc2face_distill"] and (self.cond_fn is not None or "cond" in step_kwargs):
-                # (with the reference's own conditioning side, shared_step's front decides use_arc2face_as_target / ND)
-                step_kwargs.update(use_arc2face_as_target=True, num_denoising_steps=self.draw_num_denoising_steps(
-                    cfg.get("max_num_denoising_steps", 7)))
-            step_kwargs.setdefault("anneal_t", True)       # every normal-recon iteration, distillation included (:2851-2861)
-            self.init_iteration_flags()
-            self.iter_flags.update(flags)
+            self._iteration_preamble(auto_iteration, step_kwargs)
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
-        if reducer is not None:
+        self._micro_batch_backward(model_output, grad, aux, reducer)
+        self.batch_idx += 1
+        if optimizer is not None and self.batch_idx % self.manual_accumulate_grad_batches == 0:
+            self._optimizer_step(optimizer, reducer, scheduler)
+        return loss, aux
+
+    def _iteration_preamble(self, auto_iteration, step_kwargs):
+        """the reference's ``training_step`` preamble (ddpm.py:516-572, 1839-1859): training_percent, the iteration type."""
+        cfg = auto_iteration
+        gstep = self.batch_idx // self.manual_accumulate_grad_batches            # Lightning's global_step
+        self.training_percent = min(1.0, gstep * self.manual_accumulate_grad_batches / max(1, cfg.get("max_steps", 1)))
+        flags = self.draw_iteration_flags(gstep, cfg.get("composition_regs_iter_gap", 0),
+                                          cfg.get("arc2face_distill_iter_prob", 0.0),
+                                          cfg.get("mix_prompt_distill_weight", 0.0))
+        if flags["is_compos_iter"] and not (flags["do_mix_prompt_distillation"] and self.embedding_manager is not None
+                                            and getattr(self, "clip_score_fn", None) is not None):
+            raise NotImplementedError("a compositional iteration needs mix_prompt_distill_weight > 0, the reference's "
+                                      "conditioning side (cond_stage_config + personalization_config) and a clip_score_fn; "
+                                      "the ada-delta-only ablation form is not built")
+        if flags["do_arc2face_distill"] and (self.cond_fn is not None or "cond" in step_kwargs):
+            # (with the reference's own conditioning side, shared_step's front decides use_arc2face_as_target / ND)
+            step_kwargs.update(use_arc2face_as_target=True, num_denoising_steps=self.draw_num_denoising_steps(
+                cfg.get("max_num_denoising_steps", 7)))
+        step_kwargs.setdefault("anneal_t", True)       # every normal-recon iteration, distillation included (:2851-2861)
+        self.init_iteration_flags()
+        self.iter_flags.update(flags)
+
+    def _micro_batch_backward(self, model_output, grad, aux, reducer, lanes=None):
+        if reducer is not None and lanes is None:
             # the previous micro-batch's all-reduce overlapped the forward above; it must have landed before this backward
             # adds into the same flat gradient buffer (AccumulateGrad and the weight-gradient kernels write it from the
             # very start of the backward)
             reducer.wait()
             reducer.begin_backward()         # chunks of the gradient buffer go out as the backward completes them
+        # (with lanes the wait sits in MicroBatchLanes' gate, in front of the accumulation into the shared buffer only, and
+        # the exchange is single-shot: a lane's backward starts while the previous lane's collective may still be in flight)
         self.manual_backward(model_output, grad, aux)                      # == manual_backward(loss), ddpm.py:595
         if reducer is not None:
             reducer.reduce()
-        self.batch_idx += 1
-        if optimizer is not None and self.batch_idx % self.manual_accumulate_grad_batches == 0:
-            if reducer is not None:
-                reducer.wait()
-            from ...flatopt import FlatParams
-            # sync-free: raises if a single-launch GroupNorm's exchange timed out since the previous optimiser step (its
-            # outputs were NaN then, so the loss already is; this names the cause)
-            ops.gn_poison_poll()
-            if isinstance(optimizer, FlatParams):              # Prodigy / AdamW / NAdam: clip fused into the flat-buffer step
-                optimizer.step(clip_norm=self.grad_clip if self.grad_clip else None)
-            else:
-                params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
-                if self.grad_clip and params:
-                    torch.nn.utils.clip_grad_norm_(params, self.grad_clip)
-                optimizer.step()
-            if reducer is not None:
-                reducer.zero()
-            else:
-                optimizer.zero_grad(set_to_none=False)
-            if scheduler is not None:
-                scheduler.step()                               # ddpm.py:629-633
-        return loss, aux
+
+    def _optimizer_step(self, optimizer, reducer, scheduler):
+        """clip 0.5 -> step -> zero_grad -> scheduler.step, every ``manual_accumulate_grad_batches``-th micro-batch
+        (ddpm.py:606-633)."""
+        if reducer is not None:
+            reducer.wait()
+        from ...flatopt import FlatParams
+        # sync-free: raises if a single-launch GroupNorm's exchange timed out since the previous optimiser step (its
+        # outputs were NaN then, so the loss already is; this names the cause)
+        ops.gn_poison_poll()
+        if isinstance(optimizer, FlatParams):              # Prodigy / AdamW / NAdam: clip fused into the flat-buffer step
+            optimizer.step(clip_norm=self.grad_clip if self.grad_clip else None)
+        else:
+            params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+            if self.grad_clip and params:
+                torch.nn.utils.clip_grad_norm_(params, self.grad_clip)
+            optimizer.step()
+        if reducer is not None:
+            reducer.zero()
+        else:
+            optimizer.zero_grad(set_to_none=False)
+        if scheduler is not None:
+            scheduler.step()                               # ddpm.py:629-633
+
+    def training_window(self, batches, optimizer, reducer=None, scheduler=None, lanes=None, auto_iteration=None,
+                        step_kwargs=None, after_forward=None):
+        """The micro-batches of ONE accumulation window (``manual_accumulate_grad_batches`` of them: ddpm.py:591-633
+        accumulates their gradients and steps once) issued forward-first -- F0 F1 .. B0 B1 .. step -- and, with ``lanes``
+        (``MicroBatchLanes``), each on its own HIP stream.  All of a window's micro-batches read the SAME weights, so they
+        are independent until their gradients meet in the shared buffer; on an MI355X one micro-batch leaves most CUs idle
+        most of the time (its launches are small and dependent), and a second one beside it fills them.  The host order of
+        the forward halves is the reference's (iteration flags and host RNG are drawn per micro-batch, in order; a backward
+        draws nothing), the accumulation order into ``.grad`` is micro-batch 0, 1, .. (the lanes' gate), so the numbers are
+        those of ``training_step`` called on the batches one after the other -- up to the summation order of the GroupNorm
+        statistics on the second lane (two-pass kernels there: the single-launch exchange belongs to one stream per device).
+        ``step_kwargs``: one dict per micro-batch, one for all, or a callable ``k -> dict`` evaluated on the micro-batch's
+        lane right before its forward (RNG draws, a prefetched latent); ``after_forward(k)``: called on the lane once the
+        forward is issued (e.g. to submit the next VAE encode to a ``LatentPrefetcher``).  -> [(loss, aux), ...]"""
+        n = len(batches)
+        assert n == self.manual_accumulate_grad_batches and self.batch_idx % n == 0, \
+            "training_window: one whole accumulation window, starting on a window border"
+        if lanes is not None and any(p.requires_grad for p in self.model.parameters()):
+            lanes = None               # the UNet's own gradients are written through raw pointers during the whole backward
+        import contextlib
+        if lanes is not None:
+            lanes.window_start()       # the weights (and whatever else lane 0 has queued so far) as the side lanes' starting point
+        fronts = []
+        for k, batch in enumerate(batches):
+            with (lanes.micro_batch(k) if lanes is not None else contextlib.nullcontext()):
+                kw = dict(step_kwargs(k) if callable(step_kwargs) else
+                          step_kwargs[k] if isinstance(step_kwargs, (list, tuple)) else (step_kwargs or {}))
+                if auto_iteration is not None:
+                    self._iteration_preamble(auto_iteration, kw)
+                fronts.append(self.shared_step(batch, **kw))
+                if after_forward is not None:
+                    after_forward(k)
+            self.batch_idx += 1
+        for k, (loss, grad, model_output, aux) in enumerate(fronts):
+            with (lanes.micro_batch(k, closing=True) if lanes is not None else contextlib.nullcontext()):
+                self._micro_batch_backward(model_output, grad, aux, reducer, lanes)
+        if lanes is not None:
+            lanes.join()
+        self._optimizer_step(optimizer, reducer, scheduler)
+        if lanes is not None:
+            lanes.window_start()
+        return [(f[0], f[3]) for f in fronts]
+
+
+class MicroBatchLanes:
+    """One HIP stream per micro-batch of an accumulation window (``LatentDiffusion.training_window``).
+
+    The window's micro-batches read the same weights (the optimiser steps once per window, ddpm.py:606-633) and meet only
+    in the trainable parameters' ``.grad``.  Lane 0 is the stream current at construction (the optimiser runs there), the
+    others are side streams that wait for the window's weights (``window_start``).  A tensor hook on every trainable
+    parameter -- it runs in front of autograd's accumulation into ``.grad``, on whatever stream that accumulation is issued --
+    makes that stream wait until the PREVIOUS micro-batch of the window has finished its backward (and, under data
+    parallelism, until its all-reduce has landed: ``GradReducer.wait``), so ``.grad`` receives micro-batch 0, 1, .. in order
+    exactly as in the sequential loop; everything before that point of a backward runs freely beside the other lane.
+    Not for ``unfreeze_model`` (the UNet's weight gradients are written through raw pointers from the start of a backward:
+    ``training_window`` falls back to one stream)."""
+
+    def __init__(self, params, n=2, reducer=None):
+        self.main = torch.cuda.current_stream()
+        self.streams = [self.main] + [torch.cuda.Stream() for _ in range(n - 1)]
+        self.reducer = reducer
+        self._prev_done = None
+        self._window = torch.cuda.Event()
+        self._window.record(self.main)
+        self._hooks = [p.register_hook(self._gate) for p in params if p.requires_grad]
+
+    def _gate(self, g):
+        ev = self._prev_done
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            if self.reducer is not None:
+                self.reducer.wait()
+        return g
+
+    def micro_batch(self, k, closing=False):
+        """context: the stream of the window's k-th micro-batch.  ``closing``: this context issues the micro-batch's backward;
+        on exit its end is the event the next micro-batch's accumulation waits for."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            s = self.streams[k % len(self.streams)]
+            if s is not self.main and not closing:
+                s.wait_event(self._window)
+            if closing and k == 0:
+                self._prev_done = None                 # (the optimiser step on lane 0 ordered everything before this window)
+            with torch.cuda.stream(s):
+                yield s
+                if closing:
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+                    self._prev_done = ev
+        return cm()
+
+    def join(self):
+        """lane 0 waits for the others (call before the optimiser step)."""
+        for s in self.streams[1:]:
+            self.main.wait_stream(s)
+        self._prev_done = None
+
+    def window_start(self):
+        """the weights of the next window are final at this point of lane 0 (call after the optimiser step / zero_grad)."""
+        self._window = torch.cuda.Event()
+        self._window.record(self.main)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 class LatentPrefetcher:
@@ -1482,7 +1606,19 @@ class LatentPrefetcher:
     def __init__(self, model):
         self.model = model
         self.stream = torch.cuda.Stream()
-        self._pending = None
+        self._queue = []                  # FIFO: with MicroBatchLanes a whole window's encodes are in flight
+
+    @property
+    def _pending(self):
+        return self._queue[0] if self._queue else None
+
+    @_pending.setter
+    def _pending(self, v):
+        if v is None:
+            if self._queue:
+                self._queue.pop(0)
+        else:
+            self._queue.append(v)
 
     def _hold(self, *tensors):
         """inputs allocated on the main stream are read LATER by side-stream kernels: tell the caching allocator, or a

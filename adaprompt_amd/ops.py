@@ -216,7 +216,8 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
         if chunks > 0:
             for y in (y32, y16):
                 if y is not None:
-                    setattr(y, GN_STATS_ATTR, (part, chunks))
+                    # valid for exactly this tensor content: the version and shape travel with the records
+                    setattr(y, GN_STATS_ATTR, (part, chunks, y._version, tuple(y.shape)))
     if e0 is not None:
         # algorithmic FLOPs = 2 * MACs of the convolution as the reference's nn.Conv2d / nn.Linear counts them
         v = _lib.call_long("adap_conv2d_last_variant")
@@ -374,8 +375,11 @@ def groupnorm_fwd(x, gamma, beta, eps, act, out_f32=False, out_bf16=True):
     y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if out_bf16 else None
     e0 = TIMER.start() if TIMER is not None else None
     stats = getattr(x, GN_STATS_ATTR, None)          # left by the producing contraction's epilogue (conv2d(gn_stats=True))
+    if stats is not None and (stats[2] != x._version or stats[3] != tuple(x.shape) or stats[1] != HW // 64
+                              or stats[0].shape[0] != B):
+        stats = None                                 # x was written since (or is another view): the statistics pass it is
     if stats is not None:
-        part, chunks = stats
+        part, chunks = stats[0], stats[1]
         _lib.call("adap_groupnorm_fwd_stats", x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(), _ptr(y32), C,
                   _ptr(y16), C, mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), chunks, B, HW, C, float(eps), int(act),
                   _stream())

@@ -139,6 +139,7 @@ class GradReducer:
             for c in cs:
                 self._need[c] += 1
         self._left = self._issued = self._ready = None
+        self._expect = {}
         self._hooks = []
 
     # ---- one chunk's collective ----------------------------------------------------------------------------------------
@@ -191,12 +192,23 @@ class GradReducer:
         self._left = list(self._need)
         self._issued = [False] * len(self.chunks)
         self._ready = set()
+        # a block Function that ran k times in the graph (k UNet passes under one autograd.backward) reports its parameters
+        # k times; only the last report makes them final (functional.FWD_PASSES counts the forwards that recorded a
+        # backward node since the previous begin_backward; an over-count only delays a chunk until reduce())
+        from . import functional
+        self._expect = functional.take_forward_passes()
 
     def grad_ready(self, param):
-        """``param.grad`` is final for this backward (idempotent within one backward)."""
-        if self._left is None or id(param) in self._ready or id(param) not in self._chunks_of:
+        """``param.grad`` is final for this backward once every expected report has come (autograd's post-accumulate hook
+        fires once per backward; a block Function reports once per invocation, see ``begin_backward``)."""
+        pid = id(param)
+        if self._left is None or pid in self._ready or pid not in self._chunks_of:
             return
-        self._ready.add(id(param))
+        n = self._expect.get(pid, 1) - 1
+        if n > 0:
+            self._expect[pid] = n
+            return
+        self._ready.add(pid)
         for c in self._chunks_of[id(param)]:
             self._left[c] -= 1
             if self._left[c] == 0 and not self._issued[c]:

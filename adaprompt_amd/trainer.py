@@ -10,10 +10,14 @@ from types import SimpleNamespace
 
 
 class Trainer:
-    def __init__(self, max_steps, ckpt_dir=None, every_n_train_steps=500, process_group=None):
+    def __init__(self, max_steps, ckpt_dir=None, every_n_train_steps=500, process_group=None, micro_batch_lanes=None):
         """``max_steps`` / ``every_n_train_steps``: yaml:178-180, 190 (``lightning.trainer.max_steps``,
-        ``modelcheckpoint.params.every_n_train_steps``), counted in optimiser steps (Lightning's ``global_step``)."""
+        ``modelcheckpoint.params.every_n_train_steps``), counted in optimiser steps (Lightning's ``global_step``).
+        ``micro_batch_lanes``: issue the micro-batches of an accumulation window on separate HIP streams
+        (``LatentDiffusion.training_window`` / ``MicroBatchLanes``); default: on a GPU, unless ``ADAP_MB_LANES=0``."""
         self.max_steps = int(max_steps)
+        self.micro_batch_lanes = (os.environ.get("ADAP_MB_LANES", "1") != "0") if micro_batch_lanes is None else micro_batch_lanes
+        self.lanes = None
         self.checkpoint_callback = SimpleNamespace(dirpath=ckpt_dir)
         self.every_n_train_steps = every_n_train_steps
         self.process_group = process_group
@@ -36,11 +40,36 @@ class Trainer:
         if self.optimizer is None:
             self.attach(model)
         last_saved = -1
-        for batch_idx, batch in enumerate(batches):
-            if model.global_step >= self.max_steps:
+        n = int(model.manual_accumulate_grad_batches)
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        windowed = (self.micro_batch_lanes and n > 1 and params and params[0].is_cuda and model.batch_idx % n == 0)
+        if windowed and self.lanes is None:
+            from .ldm.models.diffusion.ddpm import MicroBatchLanes
+            self.lanes = MicroBatchLanes(params, n=n, reducer=self.reducer)
+        auto = {"max_steps": self.max_steps, "composition_regs_iter_gap": model.composition_regs_iter_gap,
+                "arc2face_distill_iter_prob": model.arc2face_distill_iter_prob,
+                "mix_prompt_distill_weight": model.mix_prompt_distill_weight,
+                "max_num_denoising_steps": model.max_num_denoising_steps}
+        it = iter(enumerate(batches))
+        while model.global_step < self.max_steps:
+            # a whole window's batches are taken BEFORE any of its work is issued: whatever produced them on the current
+            # stream is then ahead of the window's first kernel, and the side lanes need not wait for lane 0's micro-batch
+            window = []
+            for batch_idx, batch in it:
+                window.append((batch_idx, batch))
+                if len(window) == (n if windowed else 1):
+                    break
+            if not window:
                 break
-            loss, _aux = model.training_step(batch, batch_idx)
-            self.logged.append(loss)
+            if windowed and len(window) == n:
+                self.lanes.window_start()
+                out = model.training_window([b for _, b in window], self.optimizer, self.reducer, self.scheduler, self.lanes,
+                                            auto_iteration=auto)
+                self.logged.extend(loss for loss, _aux in out)
+            else:
+                for batch_idx, batch in window:
+                    loss, _aux = model.training_step(batch, batch_idx)
+                    self.logged.append(loss)
             gs = model.global_step
             if self.every_n_train_steps and gs > 0 and gs % self.every_n_train_steps == 0 and gs != last_saved:
                 self.save_checkpoint(model)

@@ -178,6 +178,8 @@ def main():
                     help="skip the `unfreeze_model: True` leg (weight gradients + 4.5 GB optimiser / all-reduce payload)")
     ap.add_argument("--no-zs-frontend", action="store_true", help="skip the zero-shot front end leg (CLIP ViT-L/14 image encoder)")
     ap.add_argument("--no-compos", action="store_true", help="skip the config-4 leg (Stage-2 compositional micro-batches)")
+    ap.add_argument("--no-lanes", action="store_true",
+                    help="one stream for both micro-batches of an accumulation window (round 3's loop) instead of one each")
     ap.add_argument("--no-distill-mix", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
     args = ap.parse_args()
@@ -258,6 +260,8 @@ def main():
 
     if prefetch is not None:
         pf_submit()
+        if not (args.graph or args.no_lanes):
+            pf_submit()            # two micro-batches ahead: both latents of a window are encoded while the previous one runs
 
     def capture():
         side = torch.cuda.Stream()
@@ -315,6 +319,20 @@ def main():
             sched.step()
         return loss
 
+    # ---- the two micro-batches of an accumulation window on two streams (LatentDiffusion.training_window) -------------
+    from adaprompt_amd.ldm.models.diffusion.ddpm import MicroBatchLanes
+    use_lanes = (prefetch is not None and not args.graph and not args.no_lanes and ld.manual_accumulate_grad_batches == 2)
+    lanes = MicroBatchLanes(params, n=2, reducer=reducer if world > 1 else None) if use_lanes else None
+
+    def window_prefetch(i):
+        def draws(k):
+            t = torch.randint(0, 1000, (B,), device=device, generator=gen)
+            noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+            return dict(t=t, noise=noise, x_start=prefetch.get(), anneal_t=True)
+        out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
+                                 after_forward=lambda k: pf_submit())
+        return out[-1][0]
+
     def step(i):
         if prefetch is not None and ops.TIMER is None and graphs is None:
             return step_prefetch(i)
@@ -347,12 +365,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, n):
+        """n micro-batches; with lanes, whole accumulation windows go through ``window_prefetch`` (two micro-batches on two
+        streams, one optimiser step), a micro-batch off a window border through ``step``."""
+        loss, i = None, first
+        while i < first + n:
+            if lanes is not None and ld.batch_idx % 2 == 0 and i + 2 <= first + n:
+                loss = window_prefetch(i)
+                i += 2
+            else:
+                loss = step(i)
+                i += 1
+        return loss
+
+    run_steps(0, args.warmup)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
+    loss = run_steps(0, args.steps)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -742,6 +771,7 @@ def main():
             "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None, "vae_prefetch_stream": prefetch is not None,
+            "micro_batch_lanes": lanes is not None,
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
                                    "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, masked MSE + "
                                    "fg/bg complementary loss with its mask hinges + cross-layer attention consistency (both with the "

@@ -415,6 +415,8 @@ def test_training_step_auto_iteration_dispatch():
         init_iteration_flags = LatentDiffusion.init_iteration_flags
         draw_num_denoising_steps = staticmethod(LatentDiffusion.draw_num_denoising_steps)
         manual_backward = staticmethod(lambda *a: None)
+        _iteration_preamble = LatentDiffusion._iteration_preamble
+        _micro_batch_backward = LatentDiffusion._micro_batch_backward
 
         def __init__(self):
             self.calls = []

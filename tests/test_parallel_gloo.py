@@ -260,3 +260,81 @@ def test_bucketed_exchange_equals_single_shot_world2_gloo():
         assert same and nonzero, (rank, same, nonzero)
         # most chunks left during the backward; the chunk of the parameter without a gradient only with reduce()
         assert all(0 < e < nchunks for e in early), (early, nchunks)
+
+
+def _two_pass_worker(rank, world, port, q):
+    """a block Function that runs TWICE in one graph writes its weight gradient through a raw pointer once
+    per invocation; the bucketed exchange must not send the chunk after the first report."""
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from adaprompt_amd import functional
+    from adaprompt_amd.parallel import GradReducer, init_distributed
+    init_distributed(backend="gloo")
+
+    class RawLin(torch.autograd.Function):               # the block Functions' pattern (functional.ResBlockFn / SpatialTransformerFn)
+        @staticmethod
+        def forward(ctx, x, T):
+            functional._note_forward(ctx, T)
+            ctx.T = T
+            ctx.save_for_backward(x)
+            return x @ T["w"][0].detach().t()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            w = ctx.T["w"][0]
+            w.grad.add_(g.t() @ x)                        # "raw pointer" write into the flat buffer
+            functional._grads_done(ctx.T)
+            return g @ w.detach(), None
+
+    def run(bucketed):
+        torch.manual_seed(0)
+        w = torch.nn.Parameter(torch.randn(24, 24) * 0.2)
+        tail = torch.nn.Parameter(torch.randn(24) * 0.1)  # an autograd-managed parameter behind the block
+        red = GradReducer([w, tail], bucket_bytes=512)    # 128 floats per chunk: w spans 5 chunks
+        T = {"w": (w, None)}
+        x = torch.randn(6, 24, generator=torch.Generator().manual_seed(20 + rank)).requires_grad_(True)
+        sent_after_first = []
+        for mb in range(2):
+            red.wait()
+            h = RawLin.apply(RawLin.apply(x * (mb + 1), T), T)          # two invocations, one backward
+            loss = (h * tail).pow(2).sum()
+            if bucketed:
+                red.begin_backward()
+                reports = []
+                orig = red.grad_ready
+
+                def spy(p, _orig=orig, _reports=reports):
+                    _orig(p)
+                    if p is w:
+                        _reports.append(sum(red._issued[c] for c in red._chunks_of[id(w)]))
+                functional.GRAD_DONE = spy
+            loss.backward()
+            if bucketed:
+                sent_after_first.append(reports)
+                functional.GRAD_DONE = red.grad_ready
+            red.reduce()
+        red.wait()
+        return red.flat.clone(), sent_after_first
+
+    a, reports = run(True)
+    b, _ = run(False)
+    # per micro-batch: two reports for w; none of w's chunks may be out after the first, all after the second
+    order_ok = all(len(r) == 2 and r[0] == 0 and r[1] > 0 for r in reports)
+    q.put((rank, bool(torch.equal(a, b)), bool(order_ok), reports, float(a.abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_with_a_block_invoked_twice_in_one_backward_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_pass_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, order_ok, reports, mass in res:
+        assert same and order_ok and mass > 0, (rank, same, order_ok, reports)
