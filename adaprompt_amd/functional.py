@@ -101,6 +101,8 @@ class _Lane:
         ev.record(self.side)
         return ev
 
+    mark_now = mark                     # (the event is recorded on the lane's stream whichever stream is current)
+
 
 _LANE_STREAMS = set()
 
@@ -476,6 +478,51 @@ class ResBlockFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # SpatialTransformer with one BasicTransformerBlock (attention.py:260-341)
 # ---------------------------------------------------------------------------------------------
+# the frozen SpatialTransformer block issued from one C call each way (csrc/blocks.hip adap_stblock_fwd / _bwd)
+STBLOCK_C = os.environ.get("ADAP_STBLOCK_C", "1") != "0"
+STB_CALLS = [0, 0]                    # forward / backward calls that took the C path (tests assert it is taken)
+_STB_WS = {}
+# include/adaprompt_hip.h: ADAP_STB_* flags
+_STB_SAME_CTX, _STB_COMPACT, _STB_CAPTURE, _STB_Q1_PRESCALED, _STB_TOKGRAD, _STB_WANT_GK, _STB_WANT_GV, _STB_G_BF16 = \
+    1, 2, 4, 8, 16, 32, 64, 128
+
+
+def _stb_sizes(B, N, C, Cctx, M, heads, G):
+    key = (B, N, C, Cctx, M, heads, G)
+    v = _STB_WS.get(key)
+    if v is None:
+        q = ops._lib.size_query
+        d = C // heads
+        v = (q("adap_groupnorm_workspace_floats", B, N, C), q("adap_stblock_workspace_floats", B, N, C, Cctx, M),
+             max(q("adap_attention_bwd_workspace_floats", B, heads, N, N, d), q("adap_attention_bwd_workspace_floats", B, heads, N, M, d)),
+             q("adap_attention_tokmap_prep_workspace_floats", B, heads, N, d, G) if G else 0)
+        v = _STB_WS[key] = tuple((n + 63) // 64 * 64 for n in v)          # the carved pieces stay 256-byte aligned
+    return v
+
+
+def _stb_weights(P, same_ctx):
+    """the block's device pointers in ADAP_STW_* / ADAP_STWB_* order (ctypes arrays), cached on the pack dict (which lives as
+    long as the weights it was built from are unchanged: functional.MODEL_STAMP)."""
+    hit = P.get("_stb")
+    if hit is not None:
+        return hit
+    import ctypes
+    gn, n1, n2, n3 = P["norm"], P["norm1"], P["norm2"], P["norm3"]
+    pin, qkv, o1, q2, o2, ff1g, ff2, pout = (P["proj_in"], P["qkv1"], P["to_out1"], P["q2"], P["to_out2"], P["ff1g"](), P["ff2"],
+                                             P["proj_out"])
+    kv, v2 = (P["kv2"], None) if same_ctx else (P["k2"], P["v2"])
+    dp = lambda t: 0 if t is None else t.data_ptr()          # noqa: E731
+    fw = [dp(gn[0]), dp(gn[1]), dp(pin.fwd), dp(pin.bias), dp(n1[0]), dp(n1[1]), dp(qkv.fwd), dp(o1.fwd), dp(o1.bias), dp(n2[0]),
+          dp(n2[1]), dp(q2.fwd), dp(kv.fwd), 0 if v2 is None else dp(v2.fwd), dp(o2.fwd), dp(o2.bias), dp(n3[0]), dp(n3[1]),
+          dp(ff1g.fwd), dp(ff1g.bias), dp(ff2.fwd), dp(ff2.bias), dp(pout.fwd), dp(pout.bias)]
+    bw = [dp(gn[0]), dp(gn[1]), dp(pin.bwd), dp(n1[0]), dp(qkv.bwd), dp(o1.bwd), dp(n2[0]), dp(q2.bwd), dp(kv.bwd),
+          0 if v2 is None else dp(v2.bwd), dp(o2.bwd), dp(n3[0]), dp(ff1g.bwd), dp(ff2.bwd), dp(pout.bwd)]
+    ok = (pin.bias is not None and o1.bias is not None and o2.bias is not None and ff1g.bias is not None and ff2.bias is not None
+          and pout.bias is not None and all(pk.O4 == pk.O and pk.I8 == pk.I for pk in (pin, qkv, o1, q2, o2, ff1g, ff2, pout, kv)))
+    hit = P["_stb"] = ((ctypes.c_void_p * len(fw))(*fw), (ctypes.c_void_p * len(bw))(*bw), ok, kv.I)
+    return hit
+
+
 class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None, tokmap_only=False):
@@ -483,6 +530,15 @@ class SpatialTransformerFn(torch.autograd.Function):
         B, H, W, C = x.shape
         N = H * W
         same_ctx = ctx_k is ctx_v or (ctx_k.data_ptr() == ctx_v.data_ptr() and ctx_k.shape == ctx_v.shape)
+        ctx.fast = False
+        if (STBLOCK_C and GEGLU_FUSED and TOKMAP_FOLD and not F32_STORAGE and P.get("train") is None and ops.TIMER is None
+                and x.dtype == torch.float32 and x.is_contiguous() and ctx_k.dtype == torch.float32 and ctx_k.is_contiguous()
+                and ctx_v.dtype == torch.float32 and ctx_v.is_contiguous() and ctx_k.shape == ctx_v.shape
+                and (not capture or (tokmap_only and tok_w is not None))
+                and (key_mask is None or isinstance(key_mask, KeyCompaction) or torch.is_tensor(key_mask))):
+            fw, _bw, ok, Cctx = _stb_weights(P, same_ctx)
+            if ok and ctx_k.shape[-1] == Cctx:
+                return SpatialTransformerFn._forward_c(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w, same_ctx, fw, Cctx)
         # the cross-attention K/V projection reads only the 77 context tokens: on the side lane, under the block's first half
         lane = side_lane(x)
         M = ctx_k.shape[1]
@@ -589,7 +645,130 @@ class SpatialTransformerFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _forward_c(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w, same_ctx, fw, Cctx):
+        import ctypes
+        B, H, W, C = x.shape
+        N, M = H * W, ctx_k.shape[1]
+        rows = B * N
+        dev = x.device
+        G = tok_w.shape[2] if capture else 0
+        gn_n, sk_n, _at_n, _prep_n = _stb_sizes(B, N, C, Cctx, M, heads, G)
+        lane = side_lane(x)
+        flags = (_STB_SAME_CTX if same_ctx else 0) | (_STB_CAPTURE if capture else 0) | (_STB_Q1_PRESCALED if P.get("q1_prescaled") else 0)
+        kc = mask_ptr = None
+        if isinstance(key_mask, KeyCompaction):
+            kc, key_mask = key_mask, key_mask.mask
+            flags |= _STB_COMPACT
+        elif key_mask is not None:
+            assert key_mask.dtype == torch.uint8 and key_mask.shape == (B, N) and key_mask.is_contiguous()
+            mask_ptr = key_mask.data_ptr()
+        e = torch.empty
+        kv2 = e(B, M, 2 * C, device=dev, dtype=BF16)
+        gn_stats = e(2, B, 32, device=dev, dtype=torch.float32)
+        tres = e(3, B, N, C, device=dev, dtype=torch.float32)
+        ln_stats = e(6, rows, device=dev, dtype=torch.float32)
+        qkv1 = e(B, N, 3 * C, device=dev, dtype=BF16)
+        obuf = e(3, B, N, C, device=dev, dtype=BF16)
+        lse = e(2, B, heads, N, device=dev, dtype=torch.float32)
+        hh = e(B, N, 8 * C, device=dev, dtype=BF16)
+        kv1c = e(B, N, 2 * C, device=dev, dtype=BF16) if kc is not None else None
+        tokmap = e(B, heads, N, G, device=dev, dtype=torch.float32) if capture else None
+        out = e(B, H, W, C, device=dev, dtype=torch.float32)
+        scr = e(7 * rows * C, device=dev, dtype=BF16)
+        ws = e(gn_n + 2 * sk_n, device=dev, dtype=torch.float32)
+        wp = ws.data_ptr()
+        if capture:
+            assert tok_w.dtype == torch.float32 and tok_w.is_contiguous() and tuple(tok_w.shape[:2]) == (B, M) and G <= 4
+        dp = lambda t: 0 if t is None else t.data_ptr()          # noqa: E731
+        tens = (ctypes.c_void_p * 23)(x.data_ptr(), ctx_k.data_ptr(), ctx_v.data_ptr(), mask_ptr or 0,
+                                      0 if kc is None else kc.perm.data_ptr(), 0 if kc is None else kc.count.data_ptr(),
+                                      dp(tok_w) if capture else 0, kv2.data_ptr(), gn_stats.data_ptr(), tres.data_ptr(),
+                                      ln_stats.data_ptr(), qkv1.data_ptr(), obuf.data_ptr(), lse.data_ptr(), hh.data_ptr(), dp(kv1c),
+                                      dp(tokmap), out.data_ptr(), scr.data_ptr(), wp, (wp + 4 * gn_n) if sk_n else 0,
+                                      (wp + 4 * (gn_n + sk_n)) if sk_n else 0, ops.gn_sync_buffer(dev))
+        cfg = (ctypes.c_int * 11)(B, H, W, C, heads, M, Cctx, flags, G, 0, 0)
+        ops._lib.call("adap_stblock_fwd", cfg, fw, tens, 0 if lane is None else lane.side.cuda_stream, ops._stream())
+        STB_CALLS[0] += 1
+        if capture and lane is not None:
+            lane.pending = lane.mark_now()              # the capture's join is deferred to UNetModel.forward (join_side_lane)
+        ctx.fast = True
+        ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
+        ctx.key_mask, ctx.key_compaction = key_mask, kc
+        ctx.tok_w = tok_w if capture else None
+        ctx.save_for_backward(x, gn_stats, tres, ln_stats, qkv1, obuf, lse, hh, kv1c, kv2, ctx_k, ctx_v)
+        if capture:
+            ctx.set_materialize_grads(False)
+            stub = x.new_empty(1)
+            cap = (stub.expand(B, heads, N, M), stub.expand(B, heads, N, M), stub.expand(B, heads, N, C // heads), tokmap)
+            ctx.mark_non_differentiable(cap[0], cap[1], cap[2])
+            return (out,) + cap
+        return out
+
+    @staticmethod
+    def _backward_c(ctx, g, g_tokmap):
+        import ctypes
+        x, gn_stats, tres, ln_stats, qkv1, obuf, lse, hh, kv1c, kv2, ctx_k, ctx_v = ctx.saved_tensors
+        P, heads, same_ctx = ctx.P, ctx.heads, ctx.same_ctx
+        B, H, W, C = x.shape
+        N, M, Cctx = H * W, kv2.shape[1], ctx_k.shape[-1]
+        rows = B * N
+        dev = x.device
+        if g is None:                       # only a side output was used downstream
+            g = torch.zeros_like(x)
+        lane = side_lane(x)
+        tok = g_tokmap is not None
+        G = ctx.tok_w.shape[2] if tok else 0
+        gn_n, sk_n, at_n, prep_n = _stb_sizes(B, N, C, Cctx, M, heads, G)
+        gop = _operand(g)            # bf16 copy if the producer left one; g itself (f32) is only the final addend
+        if g.dim() == 4 and not g.is_contiguous():          # a channel slice out of a concat gradient: rows ld apart
+            ld = g.stride(-2)
+            gop = gop.as_strided((B, N, C), (N * ld, ld, 1)) if gop.stride(-2) == ld and gop.shape == g.shape \
+                else g.contiguous().view(B, N, C)
+        else:
+            gop = gop.reshape(B, N, C)
+        ldg, ldg32 = ops._rows_ld(gop)[1], ops._rows_ld(g)[1]
+        kc = ctx.key_compaction
+        want_gk = bool(ctx.needs_input_grad[1] or (same_ctx and ctx.needs_input_grad[2]))
+        want_gv = bool(not same_ctx and ctx.needs_input_grad[2])
+        flags = ((_STB_SAME_CTX if same_ctx else 0) | (_STB_COMPACT if kc is not None else 0) | (_STB_TOKGRAD if tok else 0)
+                 | (_STB_Q1_PRESCALED if P.get("q1_prescaled") else 0) | (_STB_WANT_GK if want_gk else 0)
+                 | (_STB_WANT_GV if want_gv else 0) | (_STB_G_BF16 if gop.dtype == BF16 else 0))
+        e = torch.empty
+        gx = e(B, H, W, C, device=dev, dtype=torch.float32)
+        gx16 = e(B, H, W, C, device=dev, dtype=BF16)
+        dkv2 = e(B, M, 2 * C, device=dev, dtype=BF16)
+        g_ck = e(B, M, Cctx, device=dev, dtype=torch.float32) if want_gk else None
+        g_cv = e(B, M, Cctx, device=dev, dtype=torch.float32) if want_gv else None
+        s32 = e(2 * rows * C + at_n + prep_n + gn_n + 2 * sk_n, device=dev, dtype=torch.float32)
+        s16 = e(17 * rows * C, device=dev, dtype=BF16)
+        p32 = s32.data_ptr()
+        at_p = p32 + 8 * rows * C
+        prep_p = at_p + 4 * at_n
+        gn_p = prep_p + 4 * prep_n
+        sk_p = gn_p + 4 * gn_n
+        if tok:
+            g_tokmap = g_tokmap.contiguous()
+            assert g_tokmap.dtype == torch.float32 and tuple(g_tokmap.shape) == (B, heads, N, G)
+        dp = lambda t: 0 if t is None else t.data_ptr()          # noqa: E731
+        _fw, bw, _ok, _ = _stb_weights(P, same_ctx)
+        km = ctx.key_mask
+        tens = (ctypes.c_void_p * 30)(gop.data_ptr(), g.data_ptr(), x.data_ptr(), gn_stats.data_ptr(), tres.data_ptr(), ln_stats.data_ptr(),
+                                      qkv1.data_ptr(), obuf.data_ptr(), lse.data_ptr(), hh.data_ptr(), dp(kv1c), kv2.data_ptr(),
+                                      0 if (km is None or kc is not None) else km.data_ptr(), 0 if kc is None else kc.inv_perm.data_ptr(),
+                                      0 if kc is None else kc.count.data_ptr(), dp(g_tokmap) if tok else 0,
+                                      ctx.tok_w.data_ptr() if tok else 0, prep_p if tok else 0, gx.data_ptr(), gx16.data_ptr(),
+                                      dkv2.data_ptr(), dp(g_ck), dp(g_cv), p32, s16.data_ptr(), at_p, gn_p, sk_p if sk_n else 0,
+                                      (sk_p + 4 * sk_n) if sk_n else 0, ops.gn_sync_buffer(dev))
+        cfg = (ctypes.c_int * 11)(B, H, W, C, heads, M, Cctx, flags, G, ldg, ldg32)
+        ops._lib.call("adap_stblock_bwd", cfg, bw, tens, 0 if lane is None else lane.side.cuda_stream, ops._stream())
+        STB_CALLS[1] += 1
+        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, g, g_score=None, _g_prob=None, g_qs=None, g_tokmap=None):
+        if ctx.fast:
+            assert g_score is None and g_qs is None
+            return SpatialTransformerFn._backward_c(ctx, g, g_tokmap)
         (x, gm, gr, t0, l1m, l1r, qkv1, o1, lse1, t1, l2m, l2r, q2, kv2, o2, lse2, t2, l3m, l3r, hh, ctx_k,
          ctx_v, xn, n1, n2, n3, gg, t3, kv1c) = ctx.saved_tensors
         P, heads = ctx.P, ctx.heads

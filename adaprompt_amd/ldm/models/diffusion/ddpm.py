@@ -1547,6 +1547,11 @@ class MicroBatchLanes:
         self._window = torch.cuda.Event()
         self._window.record(self.main)
         self._hooks = [p.register_hook(self._gate) for p in params if p.requires_grad]
+        # autograd accumulates a leaf's gradient on the stream its AccumulateGrad node was created on (lane 0's, typically),
+        # synchronised with the producing lane: intended here, and ordered by the gate
+        warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if warn_off is not None:
+            warn_off(False)
 
     def _gate(self, g):
         ev = self._prev_done

@@ -117,6 +117,59 @@ int adap_resblock_bwd(const void* g, int g_dtype, const float* g32, const float*
                       const void* c2wb, const void* skwb, void* ga2, void* gh1, void* ga1, float* gx, void* gx16,
                       float* gn_ws, float* sk_ws, void* gn_sync, int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* One SpatialTransformer block (attention.py:260-341: GroupNorm -> proj_in -> [LN -> self attention] -> [LN -> cross attention] ->
+ * [LN -> GEGLU feed-forward] -> proj_out + x; CrossAttention.forward attention.py:147-257) issued from ONE call each way: the
+ * launches of the per-op sequence in its order and with its arguments, so the numbers are bit-identical to it; the work off
+ * the block's dependency chain -- the cross-attention K/V projection of the context tokens, the token-map capture, the token
+ * maps' gradient prologue, the context gradients -- goes to `lane` (a second stream, or NULL = all on `stream`), forked and
+ * joined with events of the library's own (the capture's join is the caller's: it is only read after the UNet's forward).
+ * Frozen weights (no weight gradients), bf16 storage, fused GEGLU.
+ *   cfg (host ints): [0] B, [1] H, [2] W, [3] C, [4] heads, [5] M context tokens, [6] Cctx, [7] ADAP_STB_* flags,
+ *                    [8] G token groups (capture / token-map gradient), bwd only: [9] / [10] leading dims of gop / g32
+ *   w / wb: host arrays of DEVICE pointers in ADAP_STW_* / ADAP_STWB_* order (bf16 packs of adap_pack_conv_weight, f32 biases and
+ *           norm gains; with a split context KV2 / V2 are the to_k / to_v packs, otherwise KV2 is their concatenation)
+ *   t: host array of DEVICE pointers in ADAP_STF_* (fwd) / ADAP_STG_* (bwd) order; rows = B * H * W:
+ *     fwd in : X f32 [rows][C]; CTX_K (CTX_V) f32 [B][M][Cctx]; KEY_MASK u8 [B][N] or NULL; PERM int32 [B][N] + KEY_COUNT int32 [B]
+ *              (ADAP_STB_COMPACT); TOK_W f32 [B][M][G] (ADAP_STB_CAPTURE)
+ *     fwd out: KV2 bf16 [B][M][2C] (k | v); GN_STATS f32 [2][B][32]; TRES f32 [3][rows][C] = t0, t1, t2 (the residual stream after
+ *              proj_in / attn1 / attn2); LN_STATS f32 [6][rows]; QKV1 bf16 [rows][3C]; OBUF bf16 [3][rows][C] = o1, q2, o2;
+ *              LSE f32 [2][B][heads][N]; HH bf16 [rows][8C] (permuted GEGLU pre-activation); KV1C bf16 [rows][2C] (compaction);
+ *              TOKMAP f32 [B][heads][N][G] (capture); OUT f32 [rows][C]
+ *     scratch: SCRATCH16 bf16 7 * rows * C; GN_WS adap_groupnorm_workspace_floats(B, N, C) floats; SK_WS / SK_WS_LANE
+ *              adap_stblock_workspace_floats(...) floats each (either may be NULL when that is 0); GN_SYNC as adap_groupnorm_fwd
+ *     bwd in : GOP = d out as bf16 (ADAP_STB_G_BF16) or f32, G32 = the f32 gradient (added to dx); the forward's saved tensors;
+ *              INV_PERM; D_TOKMAP f32 [B][heads][N][G] + TOK_W + TOK_PREP (adap_attention_tokmap_prep_workspace_floats floats
+ *              of scratch) with ADAP_STB_TOKGRAD
+ *     bwd out: GX f32 / GX16 bf16 [rows][C]; DKV2 bf16 [B][M][2C]; G_CK (G_CV) f32 [B][M][Cctx] with ADAP_STB_WANT_GK / _GV
+ *     scratch: SCRATCH32 f32 2 * rows * C; SCRATCH16 bf16 17 * rows * C; ATTN_WS max of adap_attention_bwd_workspace_floats over
+ *              the self (M = N) and cross attention; GN_WS, SK_WS, SK_WS_LANE, GN_SYNC as above */
+#define ADAP_STB_SAME_CTX 1
+#define ADAP_STB_COMPACT 2
+#define ADAP_STB_CAPTURE 4
+#define ADAP_STB_Q1_PRESCALED 8
+#define ADAP_STB_TOKGRAD 16
+#define ADAP_STB_WANT_GK 32
+#define ADAP_STB_WANT_GV 64
+#define ADAP_STB_G_BF16 128
+enum { ADAP_STW_GN_G, ADAP_STW_GN_B, ADAP_STW_PIN_W, ADAP_STW_PIN_B, ADAP_STW_LN1_G, ADAP_STW_LN1_B, ADAP_STW_QKV, ADAP_STW_OUT1_W,
+       ADAP_STW_OUT1_B, ADAP_STW_LN2_G, ADAP_STW_LN2_B, ADAP_STW_Q2, ADAP_STW_KV2, ADAP_STW_V2, ADAP_STW_OUT2_W, ADAP_STW_OUT2_B,
+       ADAP_STW_LN3_G, ADAP_STW_LN3_B, ADAP_STW_FF1G_W, ADAP_STW_FF1G_B, ADAP_STW_FF2_W, ADAP_STW_FF2_B, ADAP_STW_POUT_W,
+       ADAP_STW_POUT_B, ADAP_STW_COUNT };
+enum { ADAP_STWB_GN_G, ADAP_STWB_GN_B, ADAP_STWB_PIN, ADAP_STWB_LN1_G, ADAP_STWB_QKV, ADAP_STWB_OUT1, ADAP_STWB_LN2_G, ADAP_STWB_Q2,
+       ADAP_STWB_KV2, ADAP_STWB_V2, ADAP_STWB_OUT2, ADAP_STWB_LN3_G, ADAP_STWB_FF1G, ADAP_STWB_FF2, ADAP_STWB_POUT, ADAP_STWB_COUNT };
+enum { ADAP_STF_X, ADAP_STF_CTX_K, ADAP_STF_CTX_V, ADAP_STF_KEY_MASK, ADAP_STF_PERM, ADAP_STF_KEY_COUNT, ADAP_STF_TOK_W, ADAP_STF_KV2,
+       ADAP_STF_GN_STATS, ADAP_STF_TRES, ADAP_STF_LN_STATS, ADAP_STF_QKV1, ADAP_STF_OBUF, ADAP_STF_LSE, ADAP_STF_HH, ADAP_STF_KV1C,
+       ADAP_STF_TOKMAP, ADAP_STF_OUT, ADAP_STF_SCRATCH16, ADAP_STF_GN_WS, ADAP_STF_SK_WS, ADAP_STF_SK_WS_LANE, ADAP_STF_GN_SYNC,
+       ADAP_STF_COUNT };
+enum { ADAP_STG_GOP, ADAP_STG_G32, ADAP_STG_X, ADAP_STG_GN_STATS, ADAP_STG_TRES, ADAP_STG_LN_STATS, ADAP_STG_QKV1, ADAP_STG_OBUF,
+       ADAP_STG_LSE, ADAP_STG_HH, ADAP_STG_KV1C, ADAP_STG_KV2, ADAP_STG_KEY_MASK, ADAP_STG_INV_PERM, ADAP_STG_KEY_COUNT,
+       ADAP_STG_D_TOKMAP, ADAP_STG_TOK_W, ADAP_STG_TOK_PREP, ADAP_STG_GX, ADAP_STG_GX16, ADAP_STG_DKV2, ADAP_STG_G_CK, ADAP_STG_G_CV,
+       ADAP_STG_SCRATCH32, ADAP_STG_SCRATCH16, ADAP_STG_ATTN_WS, ADAP_STG_GN_WS, ADAP_STG_SK_WS, ADAP_STG_SK_WS_LANE, ADAP_STG_GN_SYNC,
+       ADAP_STG_COUNT };
+long adap_stblock_workspace_floats(int B, int N, int C, int Cctx, int M);
+int adap_stblock_fwd(const int* cfg, const void* const* w, void* const* t, void* lane, void* stream);
+int adap_stblock_bwd(const int* cfg, const void* const* wb, void* const* t, void* lane, void* stream);
+
 /* FeedForward with its GEGLU fused into the two contractions (attention.py:32-59: proj -> chunk -> a * gelu(gate) -> Linear).
  * The 8C pre-activation h is stored in a PERMUTED channel order -- 16 value channels, then their 16 gate channels, then the next
  * 16 values ... (new row 32 k + j <- value channel 16 k + j, new row 32 k + 16 + j <- gate channel 16 k + j) -- and w_packed /

@@ -329,6 +329,83 @@ def test_resblock_one_c_call_equals_the_per_op_sequence(B, H, Cin, Cout):
     assert rel(o1, o0) == 0.0 and torch.isfinite(g1).all()
 
 
+@pytest.mark.parametrize("B,H,C,heads,masked,split_ctx,capture", [
+    (2, 32, 320, 8, True, False, True),        # N = 1024: key compaction; token-map capture + its gradient
+    (2, 16, 640, 8, True, False, False),       # N = 256: the mask as key bias
+    (1, 64, 320, 8, False, False, True),       # the 64 x 64 level, no mask
+    (2, 8, 1280, 8, False, True, False),       # d = 160; split K / V context (mix_hijk form, 154 tokens)
+    (3, 16, 64, 8, True, True, True)])         # narrow (the test models' width), everything on
+def test_transformer_block_one_c_call_equals_the_per_op_sequence(B, H, C, heads, masked, split_ctx, capture):
+    """``adap_stblock_fwd`` / ``_bwd`` (csrc/blocks.hip: the frozen SpatialTransformer block's launches, side lane included,
+    issued from one C call each way) against the same block issued op by op from Python (``functional.STBLOCK_C`` off) through
+    the real module: output, token maps, the input gradient (f32 and its bf16 side copy) and the context gradients must be
+    bit-identical -- the same kernels with the same arguments, only the host side differs."""
+    from adaprompt_amd import functional as HF
+    from adaprompt_amd.ldm.modules.attention import SpatialTransformer, KeyMasks
+    torch.manual_seed(7)
+    Cctx, M = 96, (154 if split_ctx else 77)
+    st = SpatialTransformer(C, heads, C // heads, depth=1, context_dim=Cctx).to(dev())
+    with torch.no_grad():
+        for p_ in st.parameters():
+            p_.copy_(torch.randn_like(p_) * (0.5 if p_.dim() == 1 else p_.shape[1] ** -0.5))
+    for p_ in st.parameters():
+        p_.requires_grad_(False)
+    x = rnd(B, H, H, C, seed=1)
+    ck = rnd(B, M, Cctx, seed=2)
+    cv = rnd(B, M, Cctx, seed=3)
+    g = rnd(B, H, H, C, seed=4)
+    img_mask = None
+    if masked:
+        img_mask = torch.ones(B, 1, 64, 64, device=dev())
+        img_mask[:, :, :7] = 0
+        img_mask[0, :, :, 50:] = 0
+    G = 2
+    tok_w = torch.zeros(B, M, G, device=dev())
+    tok_w[:, 4:20, 0] = 1.0
+    tok_w[:, 20:24, 1] = 0.25
+    gt = rnd(B, heads, H * H, G, seed=5)
+    blk = st.transformer_blocks[0]
+
+    def run(c_call):
+        old = HF.STBLOCK_C
+        HF.STBLOCK_C = c_call
+        try:
+            blk.attn2.save_attn_vars = capture
+            blk.attn2.token_weights = tok_w if capture else None
+            blk.attn2.tokmap_only = capture
+            xi = x.clone().requires_grad_(True)
+            cki, cvi = ck.clone().requires_grad_(True), cv.clone().requires_grad_(True)
+            ctx_arg = (cvi, cki) if split_ctx else cki
+            HF.MODEL_STAMP = None
+            out = st(xi, ctx_arg, None if img_mask is None else KeyMasks(img_mask))
+            roots, grads = [out], [g]
+            tm = None
+            if capture:
+                tm = blk.attn2.cached_activations["attnscore_tokmap"]
+                HF.join_side_lane()
+                roots.append(tm)
+                grads.append(gt)
+            torch.autograd.backward(roots, grads)
+            gx16 = HF._operand(xi.grad)           # (the bf16 side copy the block left for its predecessor)
+            torch.cuda.synchronize()
+            return (out.detach(), None if tm is None else tm.detach().clone(), xi.grad.detach().clone(),
+                    None if gx16 is xi.grad else gx16.clone(), cki.grad.detach().clone(),
+                    None if cvi.grad is None else cvi.grad.detach().clone())
+        finally:
+            HF.STBLOCK_C = old
+    a = run(False)
+    n0 = list(HF.STB_CALLS)
+    b = run(True)
+    assert HF.STB_CALLS == [n0[0] + 1, n0[1] + 1], "the C path was not taken"
+    names = ("out", "tokmap", "gx", "gx16", "g_ck", "g_cv")
+    for n, u, v in zip(names, a, b):
+        assert (u is None) == (v is None), n
+        if u is not None:
+            assert torch.isfinite(u.float()).all() and torch.equal(u, v), (n, rel(v.float(), u.float()))
+    assert float(a[2].abs().max()) > 0 and float(a[4].abs().max()) > 0
+    assert not ops.gn_sync_poisoned()
+
+
 def test_groupnorm_single_launch_only_on_one_stream():
     """the workgroups of a single-launch GroupNorm wait for each other, so only ONE stream per device may issue them (two
     such kernels in flight could each hold part of the chip and wait for the rest): the default stream takes that path, a
