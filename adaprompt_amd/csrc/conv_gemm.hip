@@ -1858,6 +1858,23 @@ extern "C" int adap_conv2d_nhwc(
     if (x_dtype == 1 && nbatch == 1 && up == 0 && p.ktiles_total >= 4 &&
         (long)p.ntiles_m * p.ntiles_n * p.ksplit <= 300) {
         g_last_variant = 3000 + bn;
+        // ADAP_RING_NST (tuning): a shallower ring leaves room for a second workgroup per CU (LDS: (128 + BN) x 128 B per
+        // stage) -- with two micro-batches in flight (MicroBatchLanes) another stream's workgroups can then share the CU
+        static int nst = -1;
+        if (nst < 0) {
+            const char* e = getenv("ADAP_RING_NST");
+            nst = e ? atoi(e) : 4;
+        }
+        if (nst == 2) {
+            if (bn == 160) return launch_ring<128, 160, 2>(p, s);
+            if (bn == 128) { arm_gn(128); return launch_ring<128, 128, 2>(p, s); }
+            return launch_ring<128, 64, 2>(p, s);
+        }
+        if (nst == 3) {
+            if (bn == 160) return launch_ring<128, 160, 3>(p, s);
+            if (bn == 128) { arm_gn(128); return launch_ring<128, 128, 3>(p, s); }
+            return launch_ring<128, 64, 3>(p, s);
+        }
         if (bn == 160) return launch_ring<128, 160, 4>(p, s);
         if (bn == 128) { arm_gn(128); return launch_ring<128, 128, 4>(p, s); }
         return launch_ring<128, 64, 4>(p, s);

@@ -473,6 +473,87 @@ def test_training_loop_prodigy_two_optimizer_steps_vs_oracle():
         assert rel_err(d_hip, d_ref) < 0.1, rel_err(d_hip, d_ref)
 
 
+def test_recon_micro_batch_bs4_sd15_vs_oracle():
+    """The HEADLINE workload's shape against the oracle (missing #3): one config-2 recon micro-batch at bs 4, 512 x 512,
+    full SD-1.5 sizes (859.5 M UNet + 34 M VAE encoder) -- VAE encode with the fg / aug masks -> posterior sample -> q_sample ->
+    UNet with the 16-way layerwise context and the image mask on the self-attention keys -> masked MSE -> d loss / d context
+    (reference: ddpm.py:1178-1256, 2483-2532, 2841-3039, 3571-3595; openaimodel.py:827-1052), then the same micro-batch with the
+    iteration's attention regularisers against the oracle's values on its own captured attnscore.
+    Gates: loss <= 1e-3 relative (north_star), d loss / d context <= 2.5e-2 relative L2, every regulariser <= 5 %."""
+    from adaprompt_amd import hostinfo
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import ldm_oracle as O
+    from oracle import regs_oracle as R
+    hostinfo.limit_torch_threads()
+    ucfg, vdd = dict(synth.SD15_UNET), dict(synth.SD15_VAE_DD)
+    ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                                  {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
+    usd, vsd = synth.synthetic_unet_state_dict(ucfg), synth.synthetic_vae_state_dict(vdd)
+    _, unexpected = ld.load_state_dict({**usd, **vsd}, strict=False)
+    assert not unexpected
+    ld = ld.to(dev())
+    ld.freeze_unet()
+    B = 4
+    img = synth.synthetic_input("bs4.img", (B, 512, 512, 3), 0, 0.5).clamp(-1, 1)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 512), torch.linspace(-1, 1, 512), indexing="ij")
+    fg = torch.stack([((xx / (0.5 + 0.05 * b)) ** 2 + (yy / (0.7 - 0.04 * b)) ** 2 <= 1.0).float() for b in range(B)])
+    aug = torch.zeros(B, 512, 512)
+    for b, w in enumerate((0, 24, 48, 72)):                  # the dataloader's random-scale borders, 0 .. 76 px
+        aug[b, w:512 - w, w:512 - w] = 1
+    pn = synth.synthetic_input("bs4.pn", (B, 4, 64, 64))
+    noise = synth.synthetic_input("bs4.noise", (B, 4, 64, 64))
+    t = torch.tensor([37, 417, 702, 961])
+    ctx = synth.synthetic_input("bs4.ctx", (16 * B, 77, 768))
+    extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon",
+             "is_training": True, "capture_distill_attn": True, "placeholder2indices": None}
+    batch = {"image": img.to(dev()), "fg_mask": fg.to(dev()), "aug_mask": aug.to(dev())}
+    # ---- HIP: the MSE-only micro-batch, then the one with the regularisers
+    ctx_d = ctx.to(dev()).requires_grad_(True)
+    loss, grad, out, aux = ld.shared_step(batch, t=t.to(dev()), noise=noise.to(dev()), post_noise=pn.to(dev()),
+                                          cond=(ctx_d, None, dict(extra)))
+    ld.manual_backward(out, grad, aux)
+    subj = (torch.arange(B).repeat_interleave(16), torch.arange(4, 20).repeat(B))
+    bgi = (torch.arange(B).repeat_interleave(4), torch.arange(24, 28).repeat(B))
+    ctx_d2 = ctx.to(dev()).requires_grad_(True)
+    extra2 = dict(extra, subj_indices=tuple(i.to(dev()) for i in subj), bg_indices=tuple(i.to(dev()) for i in bgi))
+    _, grad2, out2, aux2 = ld.shared_step(batch, t=t.to(dev()), noise=noise.to(dev()), post_noise=pn.to(dev()),
+                                          cond=(ctx_d2, None, extra2))
+    ld.manual_backward(out2, grad2, aux2)
+    torch.cuda.synchronize()
+    # ---- oracle: one forward with the capture on, backward to the context
+    fg64 = F.interpolate(fg[:, None], size=(64, 64), mode="nearest")
+    im64 = F.interpolate(aug[:, None], size=(64, 64), mode="nearest")
+    sched = O.make_schedule()
+    with torch.no_grad():
+        mom = O.autoencoder_encode_moments(vsd, vdd, img.permute(0, 3, 1, 2), {"fg_mask": fg[:, None], "aug_mask": aug[:, None]})
+        z = O.get_first_stage_encoding(mom, pn)
+        x_noisy = O.q_sample(sched, z, t, noise)
+    ctx_r = ctx.clone().requires_grad_(True)
+    ex_o = dict(extra, img_mask=im64)
+    eps_ref = O.unet_forward(usd, ucfg, x_noisy, t, ctx_r, ex_o)
+    loss_ref, _ = O.calc_recon_loss(eps_ref, noise, im64, fg64, 1.0, 0.1)
+    (g_ref,) = torch.autograd.grad(loss_ref, ctx_r)
+    lh, lr = float(loss), float(loss_ref)
+    gerr = rel_err(ctx_d.grad.cpu(), g_ref)
+    assert tuple(out.shape) == tuple(eps_ref.shape)
+    eerr = rel_err(out.detach().cpu(), eps_ref.detach())
+    print(f"[bs4 sd15] loss hip {lh:.6f} oracle {lr:.6f} rel {abs(lh - lr) / lr:.2e}; eps rel L2 {eerr:.2e}; "
+          f"d/d context rel L2 {gerr:.2e}")
+    assert abs(lh - lr) / lr < LOSS_TOL
+    assert eerr < EPS_TOL
+    assert gerr < GRAD_CTX_TOL
+    with torch.no_grad():
+        sc = {k: v.detach() for k, v in ex_o["ca_layers_activations"]["attnscore"].items()}
+        want = dict(zip(("fg_xlayer_consist", "bg_xlayer_consist"), R.calc_fg_bg_xlayer_consist_loss(sc, subj, bgi, B)))
+        want.update(zip(("fg_bg_complem", "subj_mb_suppress", "bg_mf_suppress", "fg_bg_mask_contrast"),
+                        R.calc_fg_bg_complementary_loss(sc, subj, bgi, B, fg_grad_scale=0.1, fg_mask=fg64)))
+    for k, v in want.items():
+        got = float(aux2["reg_parts"][k])
+        assert abs(got - float(v)) < 5e-2 * abs(float(v)) + 1e-4, (k, got, float(v))
+    assert torch.isfinite(ctx_d2.grad).all() and float((ctx_d2.grad - ctx_d.grad).abs().max()) > 0
+    assert not ops.gn_sync_poisoned()
+
+
 def test_training_window_on_two_lanes_equals_sequential_training_steps():
     """``LatentDiffusion.training_window`` with ``MicroBatchLanes`` (the two micro-batches of an accumulation window on two HIP
     streams, forward-first, gradients meeting in the shared buffer in micro-batch order behind the lanes' gate) against
