@@ -1826,25 +1826,56 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
 // formed: a workgroup builds the G x d vectors of its (batch, head) in LDS from the <= 192 keys (keys no group lists are
 // skipped), then one thread per query row reads its d bf16 values and writes G floats.  HBM: q once (10 MB at 64 x 64, bs 4).
 #define TOKF_ROWS 256
+#define TOK_MAXP (4 * 160)                         // G <= 4 token groups x d <= 160
+// kw[g][c] = sum_m w[m][g] k[m][c] of one (batch, head) into LDS, times `scale`.  With G d <= 256 outputs a thread per output
+// walks all M keys while most of the workgroup idles (G d = 80 at d = 40): the keys are dealt over KS thread slices instead
+// (item (s, p) sums the keys m = s, s + KS, ...) and the slices are summed in a fixed order -- measured 9.4 -> 5.0 us for the
+// kw kernel and 15.5 -> 11.4 us for the forward at 64 x 64 (tools/microbench/tokmap_family.hip); KS = 1 is the plain walk.
+__device__ __forceinline__ void tokmap_kw_phase(float* part, float* out_lds, const float* __restrict__ w,
+                                                const uint16_t* __restrict__ k, long ldk, int b, int head, int M, int d, int G,
+                                                float scale) {
+    const int P = G * d;
+    int KS = 512 / P;
+    KS = KS < 1 ? 1 : (KS > 8 ? 8 : KS);
+    if (KS == 1) {
+        for (int idx = threadIdx.x; idx < P; idx += 256) {
+            const int g = idx / d, c = idx - g * d;
+            // branch-free and unrolled: a skip of the zero weights would chain the keys' loads one behind the other
+            float a = 0.f;
+            const float* wp = w + (size_t)b * M * G + g;
+            const uint16_t* kp = k + (size_t)b * M * ldk + head * d + c;
+#pragma unroll 8
+            for (int m = 0; m < M; ++m) a = fmaf(wp[(size_t)m * G], bf16_to_f32(kp[(size_t)m * ldk]), a);
+            out_lds[idx] = a * scale;
+        }
+        __syncthreads();
+        return;
+    }
+    for (int idx = threadIdx.x; idx < P * KS; idx += 256) {
+        const int s = idx / P, p = idx - s * P, g = p / d, c = p - g * d;
+        float a = 0.f;
+        for (int m = s; m < M; m += KS)
+            a = fmaf(w[((size_t)b * M + m) * G + g], bf16_to_f32(k[((size_t)b * M + m) * ldk + head * d + c]), a);
+        part[idx] = a;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 256) {
+        float v = 0.f;
+        for (int s = 0; s < KS; ++s) v += part[s * P + p];
+        out_lds[p] = v * scale;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __restrict__ q, long ldq,
                                                               const uint16_t* __restrict__ k, long ldk,
                                                               const float* __restrict__ tok_w, float* __restrict__ tokmap,
                                                               int G, int H, int N, int M, int d, float scale) {
-    __shared__ float sKW[4 * 160];                  // [G <= 4][d <= 160]
+    __shared__ float sKW[TOK_MAXP];                 // [G <= 4][d <= 160]
+    __shared__ float sPart[512];                    // the key slices' partial sums (G d <= 256: tokmap_kw_phase)
     const int tid = threadIdx.x;
     const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
-    for (int idx = tid; idx < G * d; idx += 256) {
-        const int g = idx / d, c = idx - g * d;
-        // branch-free and unrolled: a skip of the zero weights would chain the keys' loads one behind the other (~0.4 us
-        // each, 77 of them); a zero weight adds 0 * k = 0, so the sum is the same number
-        float a = 0.f;
-        const float* wp = tok_w + (size_t)b * M * G + g;
-        const uint16_t* kp = k + (size_t)b * M * ldk + head * d + c;
-#pragma unroll 8
-        for (int m = 0; m < M; ++m) a = fmaf(wp[(size_t)m * G], bf16_to_f32(kp[(size_t)m * ldk]), a);
-        sKW[idx] = a * scale;
-    }
-    __syncthreads();
+    tokmap_kw_phase(sPart, sKW, tok_w, k, ldk, b, head, M, d, G, scale);
     const int n = blockIdx.x * TOKF_ROWS + tid;
     if (n >= N) return;
     const uint16_t* qr = q + ((size_t)b * N + n) * ldq + head * d;
@@ -2034,16 +2065,11 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dk_finish_kernel(const f
 // kw[bh][g][c] = sum_m w[b][m][g] * k[b][m][head*d + c]  -- G*d numbers per (batch, head), one small workgroup each
 __global__ __launch_bounds__(256) void attn_tokmap_kw_kernel(const float* __restrict__ tok_w, const uint16_t* __restrict__ k,
                                                              long ldk, float* __restrict__ kw, int H, int M, int d, int G) {
+    __shared__ float sKW[TOK_MAXP];
+    __shared__ float sPart[512];
     const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
-    for (int idx = threadIdx.x; idx < G * d; idx += 256) {
-        const int g = idx / d, c = idx - g * d;
-        float a = 0.f;                              // branch-free, unrolled: independent loads (see attn_tokmap_fwd_kernel)
-        const float* wp = tok_w + (size_t)b * M * G + g;
-        const uint16_t* kp = k + (size_t)b * M * ldk + head * d + c;
-#pragma unroll 8
-        for (int m = 0; m < M; ++m) a = fmaf(wp[(size_t)m * G], bf16_to_f32(kp[(size_t)m * ldk]), a);
-        kw[(size_t)bh * G * d + idx] = a;
-    }
+    tokmap_kw_phase(sPart, sKW, tok_w, k, ldk, b, head, M, d, G, 1.f);
+    for (int p = threadIdx.x; p < G * d; p += 256) kw[(size_t)bh * G * d + p] = sKW[p];
 }
 
 // dq[b][n][head*d + c] += scale * sum_g dT[b][head][n][g] * kw[bh][g][c]: element-wise, 8 channels per thread
@@ -2078,48 +2104,55 @@ __global__ __launch_bounds__(256) void attn_tokmap_bwd_dq_kernel(const float* __
     }
 }
 
-// stage 1 of gq: part[bh][chunk][g][c] = sum over the chunk's rows of dT[n][g] * q[n][c]
+// stage 1 of gq: part[bh][chunk][g][c] = sum over the chunk's rows of dT[n][g] * q[n][c].  d / 8 lanes per query row, one 16-byte
+// load each, RL = 256 / (d / 8) rows in flight per pass, then a fixed-order LDS reduction over the row lanes (one bf16 per lane
+// with 40 of 64 lanes busy at d = 40 ran at 0.2 TB/s: 11.7 -> 6.2 us at 64 x 64, 14.7 -> 6.4 us at 16 x 16,
+// tools/microbench/tokmap_family.hip).  Dynamic LDS: RL * G * d floats.
 __global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __restrict__ dt, const uint16_t* __restrict__ q,
                                                                  long ldq, float* __restrict__ part, int B, int H, int N, int d,
                                                                  int G) {
-    __shared__ float red[4][TOK_MAXG * 3][64];
-    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+    extern __shared__ float tok_red[];             // [RL][G * d]
+    const int tid = threadIdx.x;
+    const int octs = d >> 3, RL = 256 / octs;
+    const int o = tid % octs, rl = tid / octs;
     const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
     const int n0 = blockIdx.x * CAPB_ROWS;
     const int rows = min(CAPB_ROWS, N - n0);
-    float acc[TOK_MAXG][3];
+    const int P = G * d;
+    float acc[TOK_MAXG][8];
 #pragma unroll
     for (int g = 0; g < TOK_MAXG; ++g)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[g][j] = 0.f;
-    const float* dtb = dt + (((size_t)b * H + head) * N + n0) * G;
-    const uint16_t* qb = q + ((size_t)b * N + n0) * ldq + head * d;
-#pragma unroll 4
-    for (int r = rl; r < rows; r += 4) {
-        float qv[3];
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    if (rl < RL) {
+        const float* dtb = dt + (((size_t)b * H + head) * N + n0) * G;
+        const uint16_t* qb = q + ((size_t)b * N + n0) * ldq + head * d + 8 * o;
+        for (int r = rl; r < rows; r += RL) {
+            float x[8];
+            unpack_bf16x8(*(const uint4*)(qb + (size_t)r * ldq), x);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) qv[j] = (cl + 64 * j < d) ? bf16_to_f32(qb[(size_t)r * ldq + cl + 64 * j]) : 0.f;
+            for (int g = 0; g < TOK_MAXG; ++g)
+                if (g < G) {
+                    const float t = dtb[(size_t)r * G + g];
 #pragma unroll
-        for (int g = 0; g < TOK_MAXG; ++g) {
-            const float t = g < G ? dtb[(size_t)r * G + g] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[g][j] += t * qv[j];
+                    for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(t, x[e], acc[g][e]);
+                }
         }
+#pragma unroll
+        for (int g = 0; g < TOK_MAXG; ++g)
+            if (g < G) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tok_red[(size_t)rl * P + g * d + 8 * o + e] = acc[g][e];
+            }
     }
-#pragma unroll
-    for (int g = 0; g < TOK_MAXG; ++g)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) red[rl][g * 3 + j][cl] = acc[g][j];
     __syncthreads();
-    for (int idx = tid; idx < TOK_MAXG * 3 * 64; idx += 256) {
-        const int gj = idx >> 6, c0 = idx & 63;
-        const int g = gj / 3, j = gj - 3 * g, c = c0 + 64 * j;
-        if (g < G && c < d) {
-            const float v = ((red[0][gj][c0] + red[1][gj][c0]) + red[2][gj][c0]) + red[3][gj][c0];
-            part[(((size_t)bh * gridDim.x + blockIdx.x) * G + g) * d + c] = v;
-        }
+    for (int p = tid; p < P; p += 256) {
+        float v = 0.f;
+        for (int i = 0; i < RL; ++i) v += tok_red[(size_t)i * P + p];
+        part[((size_t)bh * gridDim.x + blockIdx.x) * P + p] = v;
     }
 }
+static size_t tokmap_gq_lds(int d, int G) { return (size_t)(256 / (d >> 3)) * G * d * sizeof(float); }
 
 // stage 2: a workgroup per (batch*head, key): keys no group lists exit at once; the others sum the chunk partials of
 // their channels in fixed order (every listed key repeats that small sum -- cheaper than a serial walk over the keys)
@@ -2183,8 +2216,9 @@ extern "C" int adap_attention_tokmap_prep(const float* d_tokmap, const float* to
     float* gq = workspace + bhgd;
     float* part = workspace + 2 * bhgd;
     hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), 0, s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
-    hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), 0, s, d_tokmap, (const uint16_t*)q, ldq, part, B, H,
-                       N, d, G);
+    ADAP_REQUIRE(ldq % 8 == 0 && ((uintptr_t)q % 16) == 0, ADAP_ERR_ALIGN, "attention_tokmap_prep: q alignment");
+    hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), tokmap_gq_lds(d, G), s, d_tokmap, (const uint16_t*)q,
+                       ldq, part, B, H, N, d, G);
     hipLaunchKernelGGL(attn_tokmap_gq_reduce_kernel, dim3((unsigned)((bhgd + 255) / 256)), dim3(256), 0, s, part, gq, nchunks, G * d,
                        bhgd);
     return adap_check_launch("attention_tokmap_prep");
@@ -2213,8 +2247,9 @@ extern "C" int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok
         hipLaunchKernelGGL(attn_tokmap_bwd_dq_kernel, dim3((unsigned)g), dim3(256), 0, s, d_tokmap, kw, (uint16_t*)dq16, lddq, B,
                            H, N, d, G, scale);
     }
-    hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), 0, s, d_tokmap, (const uint16_t*)q, ldq,
-                       workspace, B, H, N, d, G);
+    ADAP_REQUIRE(ldq % 8 == 0 && ((uintptr_t)q % 16) == 0, ADAP_ERR_ALIGN, "attention_tokmap_bwd: q alignment");
+    hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), tokmap_gq_lds(d, G), s, d_tokmap, (const uint16_t*)q,
+                       ldq, workspace, B, H, N, d, G);
     hipLaunchKernelGGL(attn_tokmap_bwd_dk_kernel, dim3(M, B * H), dim3(64), 0, s, workspace, tok_w, (uint16_t*)dk16, lddk, B, H, M,
                        d, G, nchunks, scale);
     return adap_check_launch("attention_tokmap_bwd");
