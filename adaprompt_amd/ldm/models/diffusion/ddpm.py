@@ -1483,7 +1483,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             scheduler.step()                               # ddpm.py:629-633
 
     def training_window(self, batches, optimizer, reducer=None, scheduler=None, lanes=None, auto_iteration=None,
-                        step_kwargs=None, after_forward=None):
+                        step_kwargs=None, after_forward=None, after_backward=None):
         """The micro-batches of ONE accumulation window (``manual_accumulate_grad_batches`` of them: ddpm.py:591-633
         accumulates their gradients and steps once) issued forward-first -- F0 F1 .. B0 B1 .. step -- and, with ``lanes``
         (``MicroBatchLanes``), each on its own HIP stream.  All of a window's micro-batches read the SAME weights, so they
@@ -1494,16 +1494,32 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         those of ``training_step`` called on the batches one after the other -- up to the summation order of the GroupNorm
         statistics on the second lane (two-pass kernels there: the single-launch exchange belongs to one stream per device).
         ``step_kwargs``: one dict per micro-batch, one for all, or a callable ``k -> dict`` evaluated on the micro-batch's
-        lane right before its forward (RNG draws, a prefetched latent); ``after_forward(k)``: called on the lane once the
-        forward is issued (e.g. to submit the next VAE encode to a ``LatentPrefetcher``).  -> [(loss, aux), ...]"""
+        lane right before its forward (RNG draws, a prefetched latent); ``after_forward(k)`` / ``after_backward(k)``: called on
+        the lane once its forward / backward is issued (e.g. to submit the next VAE encode to a ``LatentPrefetcher``).
+        -> [(loss, aux), ...]"""
         n = len(batches)
         assert n == self.manual_accumulate_grad_batches and self.batch_idx % n == 0, \
             "training_window: one whole accumulation window, starting on a window border"
         if lanes is not None and any(p.requires_grad for p in self.model.parameters()):
             lanes = None               # the UNet's own gradients are written through raw pointers during the whole backward
         import contextlib
+        from .... import functional as HF
+        side_lane_was = HF.SIDE_LANE
         if lanes is not None:
             lanes.window_start()       # the weights (and whatever else lane 0 has queued so far) as the side lanes' starting point
+            # a block's side lane (functional.side_lane: work off its dependency chain on a second stream) fills CUs the chain
+            # leaves idle -- which the other micro-batch's lane does here; with two lanes, their two side lanes and the prefetch
+            # stream the five streams outnumber the hardware queues, and the blocks' fork / join events then cost more than the
+            # lanes buy (measured: 26.9 vs 26.4 ms per micro-batch; with a hardware queue per stream 34 ms)
+            HF.SIDE_LANE = HF.SIDE_LANE and os.environ.get("ADAP_SIDE_LANE_WITH_LANES", "0") == "1"
+        try:
+            return self._training_window(batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward,
+                                         contextlib, after_backward)
+        finally:
+            HF.SIDE_LANE = side_lane_was
+
+    def _training_window(self, batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward, contextlib,
+                         after_backward=None):
         fronts = []
         for k, batch in enumerate(batches):
             with (lanes.micro_batch(k) if lanes is not None else contextlib.nullcontext()):
@@ -1518,6 +1534,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         for k, (loss, grad, model_output, aux) in enumerate(fronts):
             with (lanes.micro_batch(k, closing=True) if lanes is not None else contextlib.nullcontext()):
                 self._micro_batch_backward(model_output, grad, aux, reducer, lanes)
+                if after_backward is not None:
+                    after_backward(k)
         if lanes is not None:
             lanes.join()
         self._optimizer_step(optimizer, reducer, scheduler)
@@ -1541,7 +1559,14 @@ class MicroBatchLanes:
 
     def __init__(self, params, n=2, reducer=None):
         self.main = torch.cuda.current_stream()
-        self.streams = [self.main] + [torch.cuda.Stream() for _ in range(n - 1)]
+        prio = int(os.environ.get("ADAP_LANE_PRIO", "0"))              # (tuning: HIP priority of the lanes' own streams)
+        if os.environ.get("ADAP_LANES_OWN_STREAMS", "0") == "1":
+            # (tuning) every lane on a stream of its own, the current stream only carries the optimiser: the lanes can then
+            # all have a priority above the prefetch stream's (the default stream's priority is fixed)
+            self.streams = [torch.cuda.Stream(priority=prio) for _ in range(n)]
+            ops.set_gn_single_launch_stream(self.main.device, self.streams[0].cuda_stream)
+        else:
+            self.streams = [self.main] + [torch.cuda.Stream(priority=prio) for _ in range(n - 1)]
         self.reducer = reducer
         self._prev_done = None
         self._window = torch.cuda.Event()
@@ -1610,7 +1635,7 @@ class LatentPrefetcher:
 
     def __init__(self, model):
         self.model = model
-        self.stream = torch.cuda.Stream()
+        self.stream = torch.cuda.Stream(priority=int(os.environ.get("ADAP_PF_PRIO", "0")))
         self._queue = []                  # FIFO: with MicroBatchLanes a whole window's encodes are in flight
 
     @property
@@ -1633,8 +1658,17 @@ class LatentPrefetcher:
             if torch.is_tensor(x) and x.is_cuda:
                 x.record_stream(self.stream)
 
-    def submit(self, batch, post_noise=None):
+    def submit(self, batch, post_noise=None, inline=False):
+        """``inline``: encode on the CURRENT stream instead of the prefetcher's own (a micro-batch lane encoding its next
+        latent behind its own backward: fewer streams than hardware queues)."""
         main = torch.cuda.current_stream()
+        if inline:
+            x_start, _ = self.model.get_input(batch, post_noise)
+            x_start = x_start.contiguous()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._pending = (x_start, ev)
+            return
         self.stream.wait_stream(main)                 # inputs written on the main stream are visible
         self._hold(post_noise, *batch.values())
         with torch.cuda.stream(self.stream):

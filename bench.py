@@ -252,10 +252,10 @@ def main():
     prefetch = None if args.no_prefetch else ld.make_prefetcher()
     pf_state = {"next": 0}
 
-    def pf_submit():
+    def pf_submit(inline=False):
         i = pf_state["next"]
         pn = torch.randn(B, 4, 64, 64, device=device, generator=gen)
-        prefetch.submit(batches[i % 2], pn)
+        prefetch.submit(batches[i % 2], pn, inline=inline)
         pf_state["next"] = i + 1
 
     if prefetch is not None:
@@ -329,6 +329,8 @@ def main():
             t = torch.randint(0, 1000, (B,), device=device, generator=gen)
             noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
             return dict(t=t, noise=noise, x_start=prefetch.get(), anneal_t=True)
+        # (measured alternatives, each 26.7 vs 25.6 ms: encoding the next latents on the micro-batch's own lane behind its forward or
+        # its backward, or submitting them to the prefetch stream only once the backward is issued)
         out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
                                  after_forward=lambda k: pf_submit())
         return out[-1][0]
