@@ -43,10 +43,12 @@ struct Ctx {
 };
 
 // a conv3x3's output this large gets its GroupNorm statistics from the conv's own epilogue (the Python mirror's rule:
-// model.py ResnetBlock.forward) -- below it the statistics pass is cheap and the two extra launches of the records' finish are not
+// model.py ResnetBlock.forward).  2^23 elements = every level of the SD-1.5 encoder at bs 4 (round 4: with two micro-batch lanes
+// beside the prefetch stream a statistics pass costs ~48 us there, the records' finish ~16)
 bool stats_from_epilogue(int B, int H, int W, int C) {
     static const bool off = [] { const char* e = getenv("ADAP_GN_EPILOGUE_STATS"); return e && atoi(e) == 0; }();   // A/B switch
-    return !off && (long)B * H * W * C >= (1L << 24) && (H * W) % 256 == 0 && C % 32 == 0;
+    static const int lg = [] { const char* e = getenv("ADAP_GN_EPILOGUE_MIN_LOG2"); return e ? atoi(e) : 23; }();         // tuning
+    return !off && (long)B * H * W * C >= (1L << lg) && (H * W) % 256 == 0 && C % 32 == 0;
 }
 
 // y = conv(x) [+ bias] [+ residual]; f32 and / or bf16 output (ops.conv2d)

@@ -39,12 +39,15 @@ class Downsample(nn.Module):
         return y
 
 
+_GN_EPI_MIN_LOG2 = int(__import__("os").environ.get("ADAP_GN_EPILOGUE_MIN_LOG2", "23"))      # (tuning; csrc/vae.hip reads the same)
+
+
 def gn_stats_from_epilogue(B, H, W, C):
     """A conv output this large (the 128^2 ... 512^2 levels: 64-537 MB) gets its GroupNorm statistics from the conv's own epilogue
     (``ops.conv2d(gn_stats=True)``: the records ride on the output tensor and ``groupnorm_fwd`` skips its statistics pass); below it
     the pass is cheap and the records' finish launch is not.  The same rule as csrc/vae.hip ``stats_from_epilogue``, so that
     ``adap_vae_encode`` and this mirror stay bit-identical."""
-    return B * H * W * C >= (1 << 24) and (H * W) % 256 == 0 and C % 32 == 0
+    return B * H * W * C >= (1 << _GN_EPI_MIN_LOG2) and (H * W) % 256 == 0 and C % 32 == 0
 
 
 class ResnetBlock(nn.Module):

@@ -182,7 +182,21 @@ def main():
                     help="one stream for both micro-batches of an accumulation window (round 3's loop) instead of one each")
     ap.add_argument("--no-distill-mix", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that runs config 2's Arc2Face-distillation iteration mix")
+    ap.add_argument("--emulate-node-share", type=int, default=0, metavar="RANKS",
+                    help="rehearse this rank's HOST side as one of RANKS ranks sharing the node's CPUs: before any HIP call the "
+                         "process is pinned to cpu_share / RANKS CPUs (sched_setaffinity) and torch's pool sized to match; the "
+                         "line reports it (`emulated_node_share`).  8 ranks of an 8-GPU node share its CPU quota (main.py:829)")
     args = ap.parse_args()
+
+    emulated = None
+    if args.emulate_node_share > 1:
+        from adaprompt_amd import hostinfo
+        share = hostinfo.cpu_share()
+        ncpu = max(1, share // args.emulate_node_share)
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(allowed[:ncpu]))          # (no HIP call has been made yet; child threads inherit the mask)
+        torch.set_num_threads(ncpu)
+        emulated = {"ranks": args.emulate_node_share, "cpus": ncpu, "of_cpu_share": share}
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks here, one process per GPU (the reference's launcher does the
@@ -324,11 +338,18 @@ def main():
     use_lanes = (prefetch is not None and not args.graph and not args.no_lanes and ld.manual_accumulate_grad_batches == 2)
     lanes = MicroBatchLanes(params, n=2, reducer=reducer if world > 1 else None) if use_lanes else None
 
+    diag_no_vae = os.environ.get("ADAP_DIAG_NO_VAE", "0") == "1"      # DIAGNOSTIC (invalid as a result): latents not encoded
+    diag_x = torch.randn(B, 4, 64, 64, device=device) if diag_no_vae else None
+
     def window_prefetch(i):
         def draws(k):
             t = torch.randint(0, 1000, (B,), device=device, generator=gen)
             noise = torch.randn(B, 4, 64, 64, device=device, generator=gen)
+            if diag_no_vae:
+                return dict(t=t, noise=noise, x_start=diag_x, anneal_t=True)
             return dict(t=t, noise=noise, x_start=prefetch.get(), anneal_t=True)
+        if diag_no_vae:
+            return ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws)[-1][0]
         # (measured alternatives, each 26.7 vs 25.6 ms: encoding the next latents on the micro-batch's own lane behind its forward or
         # its backward, or submitting them to the prefetch stream only once the backward is issued)
         out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
@@ -773,7 +794,8 @@ def main():
             "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None, "vae_prefetch_stream": prefetch is not None,
-            "micro_batch_lanes": lanes is not None,
+            "micro_batch_lanes": lanes is not None, **({"DIAGNOSTIC_INVALID": "no VAE encode"} if diag_no_vae else {}),
+            **({"emulated_node_share": emulated} if emulated else {}),
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
                                    "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, masked MSE + "
                                    "fg/bg complementary loss with its mask hinges + cross-layer attention consistency (both with the "
