@@ -1850,6 +1850,16 @@ extern "C" int adap_conv2d_nhwc(
     };
     if (use_big) {
         g_last_variant = 2000 + bn;
+        static int big_nst = -1;                 // ADAP_RING_BIG_NST (tuning): 2 stages = 104 KB of LDS instead of all 160
+        if (big_nst < 0) {
+            const char* e = getenv("ADAP_RING_BIG_NST");
+            big_nst = e ? atoi(e) : 3;
+        }
+        if (big_nst == 2) {
+            if (bn == 160) return launch_ring<256, 160, 2>(p, s);
+            arm_gn(256);
+            return launch_ring<256, 128, 2>(p, s);
+        }
         if (bn == 160) return launch_ring<256, 160, 3>(p, s);
         arm_gn(256);
         return launch_ring<256, 128, 3>(p, s);

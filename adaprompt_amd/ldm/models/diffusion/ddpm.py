@@ -1566,12 +1566,28 @@ class MicroBatchLanes:
             self.streams = [torch.cuda.Stream(priority=prio) for _ in range(n)]
             ops.set_gn_single_launch_stream(self.main.device, self.streams[0].cuda_stream)
         else:
-            self.streams = [self.main] + [torch.cuda.Stream(priority=prio) for _ in range(n - 1)]
+            self.streams = [self.main] + [lane_stream(k) for k in range(1, n)]
         self.reducer = reducer
         self._prev_done = None
+        # Every stream this process will use takes its hardware queue NOW, in a fixed order -- the lanes, then each lane's block
+        # side lane (functional.side_lane; suspended while the lanes run, used by every other leg of a process).  Which streams
+        # end up sharing a queue depends on the order of their first use, and the order "lanes first, side lanes whenever a later
+        # leg first needs them" cost config 2's distillation mix 17 % (65 vs 78 images/s: its teacher stream then shares a queue
+        # with the student's).
+        if os.environ.get("ADAP_DIAG_NO_STREAM_WARMUP") != "1" and params:
+            from .... import functional as HF
+            probe = next(p for p in params)
+            for s_ in self.streams:
+                with torch.cuda.stream(s_):
+                    torch.zeros(1, device=probe.device)
+                    lane = HF.side_lane(probe)
+                    if lane is not None:
+                        with lane:
+                            torch.zeros(1, device=probe.device)
         self._window = torch.cuda.Event()
         self._window.record(self.main)
-        self._hooks = [p.register_hook(self._gate) for p in params if p.requires_grad]
+        self._hooks = [] if os.environ.get("ADAP_DIAG_LANES_NO_GATE") == "1" else \
+            [p.register_hook(self._gate) for p in params if p.requires_grad]
         # autograd accumulates a leaf's gradient on the stream its AccumulateGrad node was created on (lane 0's, typically),
         # synchronised with the producing lane: intended here, and ordered by the gate
         warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -1623,6 +1639,35 @@ class MicroBatchLanes:
         self._hooks = []
 
 
+_PREFETCH_STREAMS = {}
+
+
+def prefetch_stream(device=None):
+    """ONE prefetch stream per device, shared by every prefetcher of the process.  A HIP stream is bound to one of a few
+    hardware queues when it is created (four here, dealt round-robin, the default stream on the first), and two streams on one
+    queue run one behind the other: with the lanes' stream, the blocks' side lanes and a stream per prefetcher the distillation
+    prefetcher's landed on the DEFAULT stream's queue, and config 2's mix (teacher rollout beside the student pass) fell from
+    77 to 63 images/s.  Streams are therefore few and shared: prefetchers of different legs never run at the same time."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    s = _PREFETCH_STREAMS.get(idx)
+    if s is None:
+        s = _PREFETCH_STREAMS[idx] = torch.cuda.Stream(device=idx, priority=int(os.environ.get("ADAP_PF_PRIO", "0")))
+    return s
+
+
+_LANE_STREAMS = {}
+
+
+def lane_stream(k, device=None):
+    """the process-wide stream of micro-batch lane ``k`` >= 1 (``MicroBatchLanes``); also the distillation prefetcher's: a
+    second stream of whole UNet passes beside the current one, whichever leg runs (few, shared streams: ``prefetch_stream``)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    s = _LANE_STREAMS.get((idx, k))
+    if s is None:
+        s = _LANE_STREAMS[(idx, k)] = torch.cuda.Stream(device=idx, priority=int(os.environ.get("ADAP_LANE_PRIO", "0")))
+    return s
+
+
 class LatentPrefetcher:
     """Software pipelining of the no-grad first stage: the VAE encode of micro-batch i+1 is issued on a second HIP
     stream while micro-batch i's UNet forward/backward runs on the main stream.  The UNet's 32x32 .. 8x8 levels launch
@@ -1635,7 +1680,7 @@ class LatentPrefetcher:
 
     def __init__(self, model):
         self.model = model
-        self.stream = torch.cuda.Stream(priority=int(os.environ.get("ADAP_PF_PRIO", "0")))
+        self.stream = prefetch_stream()
         self._queue = []                  # FIFO: with MicroBatchLanes a whole window's encodes are in flight
 
     @property
@@ -1696,6 +1741,11 @@ class DistillPrefetcher(LatentPrefetcher):
         model.shared_step(batch, x_start=x_start, t=t, noise=noise, num_denoising_steps=nd,
                           use_arc2face_as_target=True, trim_to_half_batch=False-equivalent handled by the caller ...)
     """
+
+    def __init__(self, model):
+        super().__init__(model)
+        if os.environ.get("ADAP_DPF_STREAM", "lane") == "lane":
+            self.stream = lane_stream(1)        # whole UNet passes (the teacher's rollout): the second compute stream
 
     def submit(self, batch, post_noise, t, noise, nd, anneal_t=True):
         """``anneal_t``: the recon iteration's timestep annealing, applied BEFORE the multi-step shift as in the reference

@@ -272,10 +272,16 @@ def main():
         prefetch.submit(batches[i % 2], pn, inline=inline)
         pf_state["next"] = i + 1
 
+    # latents encoded ahead of their use: 4 = two accumulation windows, submitted behind the window's backwards, so that the
+    # encodes run in the window's tail, under the optimiser step and in the next window's head -- where one lane alone leaves
+    # most of the chip idle (25.5 vs 25.75 ms; 2 = one window ahead, submitted behind the forwards)
+    pf_depth = int(os.environ.get("ADAP_BENCH_PF_DEPTH", "4"))
     if prefetch is not None:
         pf_submit()
         if not (args.graph or args.no_lanes):
             pf_submit()            # two micro-batches ahead: both latents of a window are encoded while the previous one runs
+            for _ in range(pf_depth - 2):
+                pf_submit()
 
     def capture():
         side = torch.cuda.Stream()
@@ -352,8 +358,12 @@ def main():
             return ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws)[-1][0]
         # (measured alternatives, each 26.7 vs 25.6 ms: encoding the next latents on the micro-batch's own lane behind its forward or
         # its backward, or submitting them to the prefetch stream only once the backward is issued)
-        out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
-                                 after_forward=lambda k: pf_submit())
+        if pf_depth == 4:        # tuning: two windows ahead, submitted behind the backwards (the encodes then run in the window's tail)
+            out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
+                                     after_backward=lambda k: pf_submit())
+        else:
+            out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
+                                     after_forward=lambda k: pf_submit())
         return out[-1][0]
 
     def step(i):
