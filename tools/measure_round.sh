@@ -16,6 +16,8 @@ cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-distill-mix --no-ddim --no-unfrozen --no-compos --no-zs-frontend"   # the profiled legs: the main step only
 echo "[measure] stats pass"; date
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_stats" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-clock-probe --no-aggregates $COMMON > "$OUT/${TAG}_stats.log" 2>&1
+echo "[measure] stats pass, one stream (--no-lanes: the kernels without the other lane's contention, as bench.py's HIP-event roofline times them)"; date
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_stats1" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-lanes --no-clock-probe --no-aggregates $COMMON > "$OUT/${TAG}_stats1.log" 2>&1
 echo "[measure] pmc FETCH_SIZE pass"; date
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$OUT/${TAG}_pmcF" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-roofline $COMMON > "$OUT/${TAG}_pmcF.log" 2>&1
 echo "[measure] pmc WRITE_SIZE pass"; date
@@ -25,7 +27,7 @@ cd "$ROOT"
 timeout -k 10 600 python3 bench.py > "$OUT/${TAG}_bench.log" 2>&1
 tail -1 "$OUT/${TAG}_bench.log" > "$OUT/${TAG}_bench_line.json"
 # keep the merge small: the raw traces are large, the stats / counter csv are what is summarised
-find "$OUT/${TAG}_stats" -name "*kernel_trace.csv" -delete || true
+find "$OUT/${TAG}_stats" "$OUT/${TAG}_stats1" -name "*kernel_trace.csv" -delete || true
 find "$OUT/${TAG}_pmcF" "$OUT/${TAG}_pmcW" -name "*kernel_trace.csv" -delete || true
 du -sh "$OUT/${TAG}_stats" "$OUT/${TAG}_pmcF" "$OUT/${TAG}_pmcW"
 echo "[measure] done"; date
