@@ -188,6 +188,13 @@ def main():
                          "line reports it (`emulated_node_share`).  8 ranks of an 8-GPU node share its CPU quota (main.py:829)")
     args = ap.parse_args()
 
+    # a hung run should say where: after ADAP_BENCH_WATCHDOG seconds (default 900; 0 = off) every thread's Python stack goes to
+    # stderr and the process exits
+    import faulthandler
+    wd = int(os.environ.get("ADAP_BENCH_WATCHDOG", "900"))
+    if wd > 0:
+        faulthandler.dump_traceback_later(wd, exit=True)
+
     emulated = None
     if args.emulate_node_share > 1:
         from adaprompt_amd import hostinfo

@@ -4,6 +4,6 @@ B="python bench.py --no-cpu-baseline --no-distill-mix --no-ddim --no-unfrozen --
 P='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["host_work_ms_per_step"])'
 for rep in 1 2; do
   for cfg in "BASE=1" "$@"; do
-    echo -n "$cfg  "; env $cfg timeout -k 10 300 $B 2>/dev/null | tail -1 | python -c "$P"
+    echo -n "$cfg  "; env $cfg ADAP_BENCH_WATCHDOG=200 timeout -k 10 300 $B 2>>gpurun_out/ab_env_stderr.log | tail -1 | python -c "$P"
   done
 done
