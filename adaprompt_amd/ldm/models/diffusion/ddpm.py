@@ -1502,6 +1502,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             "training_window: one whole accumulation window, starting on a window border"
         if lanes is not None and any(p.requires_grad for p in self.model.parameters()):
             lanes = None               # the UNet's own gradients are written through raw pointers during the whole backward
+        if lanes is not None and self.cond_fn is None and not self._window_has_conds(step_kwargs, len(batches)):
+            lanes = None               # the conditioning side runs inside shared_step: it cannot be kept on lane 0 (see below)
         import contextlib
         from .... import functional as HF
         side_lane_was = HF.SIDE_LANE
@@ -1518,13 +1520,36 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         finally:
             HF.SIDE_LANE = side_lane_was
 
+    @staticmethod
+    def _window_has_conds(step_kwargs, n):
+        if callable(step_kwargs) or step_kwargs is None:
+            return False
+        kws = step_kwargs if isinstance(step_kwargs, (list, tuple)) else [step_kwargs] * n
+        return all(isinstance(kw, dict) and kw.get("cond") is not None for kw in kws)
+
     def _training_window(self, batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward, contextlib,
                          after_backward=None):
+        # THIRD-PARTY KERNELS STAY ON LANE 0.  The conditioning side (the hook: SubjBasisGenerator / CLIP behind ``cond_fn``) runs
+        # vendor GEMMs; hipBLASLt's stream-K kernels wait inside the launch for partial tiles of their other workgroups, and two
+        # of them in flight on two streams (the two lanes' hook forwards start within a millisecond of each other) were seen to
+        # wait for ever (rocgdb: every wave at ``label_SK_Fixup``; profiles/r04_streams.md).  So every micro-batch's conditioning
+        # is computed on lane 0, one after the other, BEFORE the window's lanes start; its backward then also runs on lane 0
+        # (autograd issues a node's backward on its forward's stream), in micro-batch order.  Beside lane 0's vendor kernels
+        # only this package's own non-waiting kernels run (lane k >= 1 never takes the single-launch GroupNorm).
+        conds = [None] * len(batches)
+        if lanes is not None and self.cond_fn is not None:
+            for k, batch in enumerate(batches):
+                conds[k] = self.cond_fn(batch)
+                if k > 0:
+                    lanes.hold(conds[k], k)
+            lanes.window_start()
         fronts = []
         for k, batch in enumerate(batches):
             with (lanes.micro_batch(k) if lanes is not None else contextlib.nullcontext()):
                 kw = dict(step_kwargs(k) if callable(step_kwargs) else
                           step_kwargs[k] if isinstance(step_kwargs, (list, tuple)) else (step_kwargs or {}))
+                if conds[k] is not None and kw.get("cond") is None:
+                    kw["cond"] = conds[k]
                 if auto_iteration is not None:
                     self._iteration_preamble(auto_iteration, kw)
                 fronts.append(self.shared_step(batch, **kw))
@@ -1621,6 +1646,19 @@ class MicroBatchLanes:
                     ev.record(s)
                     self._prev_done = ev
         return cm()
+
+    def hold(self, obj, k):
+        """tensors made on lane 0 and read by lane ``k``'s kernels (a micro-batch's conditioning): tell the caching allocator,
+        or a block freed after the window could be handed out on lane 0 while lane ``k`` still reads it."""
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                obj.record_stream(self.streams[k % len(self.streams)])
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                self.hold(v, k)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                self.hold(v, k)
 
     def join(self):
         """lane 0 waits for the others (call before the optimiser step)."""

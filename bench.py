@@ -194,6 +194,20 @@ def main():
     wd = int(os.environ.get("ADAP_BENCH_WATCHDOG", "900"))
     if wd > 0:
         faulthandler.dump_traceback_later(wd, exit=True)
+    if os.environ.get("ADAP_BENCH_NATIVE_STACKS"):           # diagnostic: native stacks of a hung run, a few seconds before the watchdog
+        import ctypes
+        import subprocess
+        import threading
+        try:
+            ctypes.CDLL("libc.so.6").prctl(0x59616d61, ctypes.c_ulong(-1), 0, 0, 0)      # PR_SET_PTRACER, PR_SET_PTRACER_ANY
+        except OSError:
+            pass
+
+        def _native(pid=os.getpid(), after=max(5, wd - 25)):
+            time.sleep(after)
+            gdb = "/opt/rocm/bin/rocgdb" if os.path.exists("/opt/rocm/bin/rocgdb") else "gdb"
+            subprocess.run([gdb, "-p", str(pid), "-batch", "-ex", "thread apply all bt 14"], stdout=sys.stderr, stderr=sys.stderr, timeout=20)
+        threading.Thread(target=_native, daemon=True).start()
 
     emulated = None
     if args.emulate_node_share > 1:
