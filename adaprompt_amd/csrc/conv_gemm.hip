@@ -1903,6 +1903,179 @@ extern "C" int adap_conv2d_nhwc(
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv3x3 on an RGB image (the VAE encoder's conv_in, model.py:426, 468: 3 -> ch at full resolution).  Through the general path
+// the three channels are padded to 8 and every tap is a K step of 64 with 8 live columns: nine steps, 8x the matrix work, 357 us
+// for an output that takes ~100 us to write.  Here the whole 3 x 3 x 3 patch of a pixel is ONE K step: k = 3 * tap + channel,
+// 27 of 32 columns live.  No LDS: a lane builds its fragment of the pixel operand from the f32 image itself (8 scalar loads per
+// 16-pixel fragment, L1 / L2 hits: the image is 12.6 MB) and its weight fragments from the general [9][Cout][8] pack; one
+// MFMA 16x16x32 per accumulator; the shared epilogue (bias, f32 / bf16 out, GroupNorm statistics records) does the rest, which
+// is the kernel's time: it is bound by the 537 MB of f32 output.  A wave owns 64 consecutive pixels of a row x all Cout <= 128
+// channels; 256 threads = 256 pixels per workgroup.
+// ---------------------------------------------------------------------------------------------
+#define RGB_TILES 4                                  // 256-pixel tiles per workgroup (the weight image is staged once)
+template <int MT>
+__global__ __launch_bounds__(256) void conv3x3_rgb_kernel(ConvParams p) {
+    constexpr int PT = 4;
+    constexpr int ROWB = MT * 64 + 16;                 // bytes per staged pixel row (+16: a quad column's 16 rows spread over banks)
+    __shared__ __attribute__((aligned(16))) uint16_t sW[MT * 16 * 32];     // [Cout][32] bf16, k = 3 * tap + channel (27 live)
+    __shared__ __attribute__((aligned(16))) char sStage[4 * 16 * ROWB];    // per wave: 16 pixel rows of the output tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int HWo = p.Hout * p.Wout, M = p.B * HWo;
+    const float* __restrict__ x = (const float*)p.x;
+    // the weight image out of the general [9][Cout][8] pack: 32 columns per output channel
+    for (int idx = tid; idx < MT * 16 * 32; idx += 256) {
+        const int r = idx >> 5, k = idx & 31, t = k / 3, c = k - 3 * t;
+        sW[idx] = (k < 27 && r < p.Cout) ? p.w[((size_t)t * p.Cout + r) * p.Cin + c] : (uint16_t)0;
+    }
+    // this lane's eight k columns: k = 8 * fchunk + e -> (tap, channel); k >= 27 is padding
+    int koff[8];                                       // element offset of the tap's pixel relative to the output pixel, + channel
+    int kdy[8], kdx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * fchunk + e, t = k < 27 ? k / 3 : 4;
+        kdy[e] = t / 3 - 1;
+        kdx[e] = t - 3 * (t / 3) - 1;
+        koff[e] = (kdy[e] * p.Win + kdx[e]) * (int)p.ldx + (k < 27 ? k - 3 * t : 0);
+    }
+    const bool klive_hi = fchunk < 3;                  // columns 24 .. 31: only 24, 25, 26 are live
+    __syncthreads();
+    bf16x8 fw[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fw[i] = *(const bf16x8*)(sW + (i * 16 + frow) * 32 + fchunk * 8);
+    for (int tile = 0; tile < RGB_TILES; ++tile) {
+        const int m0 = (blockIdx.x * RGB_TILES + tile) * 256 + wv * 64;
+        if (m0 >= M) break;                            // wave-uniform
+        bf16x8 fx[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int m = m0 + j * 16 + frow;
+            const int mm = m < M ? m : M - 1;
+            const int b = mm / HWo, r = mm - b * HWo, oy = r / p.Wout, ox = r - oy * p.Wout;
+            const float* px = x + ((size_t)(b * p.Hin + oy) * p.Win + ox) * p.ldx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int iy = oy + kdy[e], ix = ox + kdx[e];
+                const bool ok = (klive_hi || e < 3) && m < M && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                const float v = ok ? px[koff[e]] : 0.f;
+                fx[j][e] = (__bf16)v;
+            }
+        }
+        f32x4 acc[MT][PT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (p.y16 != nullptr || m0 + 64 > M) {         // bf16 output or a ragged last tile: the shared epilogue
+            const GemmGeo geo{m0, 0, M, HWo, frow, fchunk};
+            if (p.gn_part == nullptr) {
+                conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16);
+            } else {
+                float st[MT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { st[i][0] = 0.f; st[i][1] = 0.f; }
+                conv_epilogue<MT, PT, GemmGeo, 2>(p, acc, geo, p.y32, p.y16, st);
+                epilogue_gn_stats<MT>(p, st, frow, fchunk, 0, (size_t)(m0 / 64));
+            }
+            continue;
+        }
+        // ---- f32 output, whole tile: this kernel is nothing but its stores (537 MB at 512 x 512).  An accumulator quad is 16 bytes
+        // of one pixel, so a store instruction of the shared epilogue writes 64-byte pieces of 16 different pixel rows (measured:
+        // 231 us; with the statistics' vmcnt(0) drain per tile 391 us).  Here a fragment's 16 pixels x Cout channels go through
+        // a wave-private LDS image and leave as whole rows -- 1 KB contiguous per store instruction: 198 us -- and the
+        // GroupNorm statistics are summed from the registers BEFORE any store is issued (no drain, no store hazard: 234 us with
+        // them; a fill of the same bytes takes 79 us, the general nine-step path 370).  Two channel passes for a third wave per
+        // SIMD and the next tile's loads issued ahead of the stores were tried: 313 us, not kept.
+        float st[MT][2];
+        float4 bq[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            st[i][0] = 0.f; st[i][1] = 0.f;
+            bq[i] = p.bias ? *(const float4*)(p.bias + i * 16 + fchunk * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        char* stage = sStage + wv * (16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float v0 = acc[i][j][0] + bq[i].x, v1 = acc[i][j][1] + bq[i].y, v2 = acc[i][j][2] + bq[i].z, v3 = acc[i][j][3] + bq[i].w;
+                st[i][0] += (v0 + v1) + (v2 + v3);
+                st[i][1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                *(float4*)(stage + frow * ROWB + i * 64 + fchunk * 16) = make_float4(v0, v1, v2, v3);
+            }
+            __builtin_amdgcn_wave_barrier();
+            char* out = (char*)p.y32 + ((size_t)m0 + j * 16) * (size_t)(MT * 64);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int lin = t * 1024 + lane * 16;          // byte offset inside the fragment's 16 x (MT * 64) output block
+                const int row = lin / (MT * 64), col = lin - row * (MT * 64);
+                const float4 v = *(const float4*)(stage + row * ROWB + col);
+                *(float4*)(out + lin) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (p.gn_part != nullptr) {
+            const int qpg = p.gn_cpg >> 2;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float v = st[i][k];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                    if (qpg >= 2) v += __shfl_xor(v, 16, 64);
+                    if (qpg == 4) v += __shfl_xor(v, 32, 64);
+                    st[i][k] = v;
+                }
+            if (frow == 0 && (fchunk & (qpg - 1)) == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int g = (i * 16 + fchunk * 4) / p.gn_cpg;
+                    *(float2*)(p.gn_part + ((size_t)(m0 / 64) * 32 + g) * 2) = make_float2(st[i][0], st[i][1]);
+                }
+            }
+        }
+    }
+}
+
+// x f32 [B][H][W][ldx >= 3] (the dataloader's image), w_packed the general forward pack [9][Cout][8] (adap_pack_conv_weight of
+// the 3-channel OIHW weight), Cout in {32, 64, 128} -> y32 / y16 [B][H][W][Cout]; honours adap_conv2d_next_gn_partial.
+extern "C" int adap_conv3x3_rgb(const float* x_hwc, long ldx, const void* w_packed, const float* bias, float* y32, void* y16, int B,
+                                int H, int W, int Cout, void* stream) {
+    float* const gn_next = g_gn_next;
+    const int gn_next_cpg = g_gn_next_cpg;
+    g_gn_next = nullptr;
+    g_gn_last_chunks = 0;
+    ADAP_REQUIRE(x_hwc && w_packed && (y32 || y16), ADAP_ERR_SHAPE, "conv3x3_rgb: null pointer");
+    ADAP_REQUIRE(B > 0 && H > 0 && W > 0 && ldx >= 3 && (Cout == 32 || Cout == 64 || Cout == 128), ADAP_ERR_UNSUPPORTED,
+                 "conv3x3_rgb: B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
+    ADAP_REQUIRE(!y32 || ((uintptr_t)y32 % 16) == 0, ADAP_ERR_ALIGN, "conv3x3_rgb: y32 alignment");
+    ADAP_REQUIRE(!y16 || ((uintptr_t)y16 % 8) == 0, ADAP_ERR_ALIGN, "conv3x3_rgb: y16 alignment");
+    ADAP_REQUIRE(!bias || ((uintptr_t)bias % 16) == 0, ADAP_ERR_ALIGN, "conv3x3_rgb: bias alignment");
+    const long M = (long)B * H * W;
+    ADAP_REQUIRE(M < (1L << 31) && M * Cout * 4 < (1L << 32), ADAP_ERR_SHAPE, "conv3x3_rgb: output larger than 4 GiB");
+    ConvParams p = {};
+    p.x = x_hwc; p.ldx = ldx; p.w = (const uint16_t*)w_packed; p.bias = bias;
+    p.y32 = y32; p.ldy32 = Cout; p.y16 = (uint16_t*)y16; p.ldy16 = Cout;
+    p.B = B; p.Hin = H; p.Win = W; p.Cin = 8; p.Hout = H; p.Wout = W; p.Cout = Cout;
+    p.KH = 3; p.KW = 3; p.stride = 1; p.pad = 1; p.alpha = 1.0f; p.ksplit = 1;
+    if (gn_next && gn_next_cpg * 32 == Cout && gn_next_cpg % 4 == 0 && (H * W) % 256 == 0) {
+        p.gn_part = gn_next;
+        p.gn_cpg = gn_next_cpg;
+        g_gn_last_chunks = H * W / 64;
+    }
+    const dim3 grid((unsigned)((M + 256 * RGB_TILES - 1) / (256 * RGB_TILES)));
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout == 128) hipLaunchKernelGGL(conv3x3_rgb_kernel<8>, grid, dim3(256), 0, s, p);
+    else if (Cout == 64) hipLaunchKernelGGL(conv3x3_rgb_kernel<4>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_rgb_kernel<2>, grid, dim3(256), 0, s, p);
+    g_last_variant = 6000 + Cout;
+    return adap_check_launch("conv3x3_rgb");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight packing: OIHW f32 (the checkpoint layout) -> bf16 [tap][Cout'][Cin'].
 //   mode 0: forward     out[t][o][i]      = w[o][i][ky][kx],  t = ky*KW + kx   (Cin padded to cin_pad with zeros)
 //   mode 1: data-grad   out[t][i][o]      = w[o][i][KH-1-ky][KW-1-kx]          (roles of Cin/Cout swapped, taps flipped)

@@ -213,9 +213,18 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
 
     // ---- conv_in on the 3 -> 8 channel padded bf16 image (model.py:426, 468)
     ConvW cin_w = conv_w(cur);
-    if ((rc = adap_pad_cast_bf16(x_hwc, 3, 3, x16, 8, 8, px0, (void*)s))) return rc;
     int xc = 0;                    // statistics records per image the producer of h left in c.partB (0: none)
-    if ((rc = conv_stats_any(c, x16, 1, H, W, 8, cin_w, p.ch, 1, 1, H, W, nullptr, hA, nullptr, c.partB, &xc))) return rc;
+    if (p.ch == 32 || p.ch == 64 || p.ch == 128) {
+        // the 27-column single-K-step kernel straight from the f32 image (conv_gemm.hip conv3x3_rgb_kernel; the Python mirror's
+        // rule: model.py Encoder.forward_nhwc)
+        const bool want = stats_from_epilogue(B, H, W, p.ch);
+        if (want && (rc = adap_conv2d_next_gn_partial(c.partB, p.ch / 32))) return rc;
+        if ((rc = adap_conv3x3_rgb(x_hwc, 3, cin_w.w, cin_w.b, hA, nullptr, B, H, W, p.ch, (void*)s))) return rc;
+        if (want) xc = adap_conv2d_last_gn_chunks();
+    } else {
+        if ((rc = adap_pad_cast_bf16(x_hwc, 3, 3, x16, 8, 8, px0, (void*)s))) return rc;
+        if ((rc = conv_stats_any(c, x16, 1, H, W, 8, cin_w, p.ch, 1, 1, H, W, nullptr, hA, nullptr, c.partB, &xc))) return rc;
+    }
     float* h = hA;
     float* other = hB;
     int hh = H, ww = W, cin = p.ch;

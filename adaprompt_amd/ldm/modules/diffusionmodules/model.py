@@ -178,8 +178,13 @@ class Encoder(nn.Module):
             raise RuntimeError("adaprompt_amd Encoder runs on the MI355X HIP kernels only; got a CPU tensor")
         wc = self._wc
         cin = wc.get("conv_in", self.conv_in.weight, self.conv_in.bias)
-        x16 = ops.pad_cast_bf16(x_hwc.contiguous().float(), cin.I8)
-        h, _ = ops.conv2d(x16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias, gn_stats=gn_stats_from_epilogue(*x16.shape[:3], cin.O4))
+        xf = x_hwc.contiguous().float()
+        if cin.O4 in (32, 64, 128) and cin.I == 3:
+            # the 3 x 3 x 3 patch as one K step, straight from the f32 image (adap_conv3x3_rgb; the same rule in csrc/vae.hip)
+            h = ops.conv3x3_rgb(xf, cin.fwd, cin.O4, bias=cin.bias, gn_stats=gn_stats_from_epilogue(*xf.shape[:3], cin.O4))
+        else:
+            x16 = ops.pad_cast_bf16(xf, cin.I8)
+            h, _ = ops.conv2d(x16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias, gn_stats=gn_stats_from_epilogue(*x16.shape[:3], cin.O4))
         for i_level in range(self.num_resolutions):
             for blk in self.down[i_level].block:
                 h = blk(h)

@@ -233,6 +233,28 @@ def conv2d(x, w_packed, Cout, KH=1, stride=1, pad=0, up=0, out_hw=None, bias=Non
     return y32, y16
 
 
+def conv3x3_rgb(x_hwc, w_packed, Cout, bias=None, gn_stats=False):
+    """conv3x3 stride 1 pad 1 on an RGB image [B,H,W,3] f32 with ``PackedConv.fwd`` of its [Cout,3,3,3] weight ([9][Cout][8]);
+    Cout in (32, 64, 128) -> f32 [B,H,W,Cout] (``adap_conv3x3_rgb``: the whole patch as one K step).  ``gn_stats`` as ``conv2d``."""
+    B, H, W, C3 = x_hwc.shape
+    assert x_hwc.dtype == F32 and x_hwc.is_contiguous() and C3 == 3 and tuple(w_packed.shape) == (9, Cout, 8)
+    y = torch.empty(B, H, W, Cout, device=x_hwc.device, dtype=F32)
+    e0 = TIMER.start() if TIMER is not None else None
+    part = None
+    if gn_stats and Cout % 32 == 0 and (H * W) % 256 == 0:
+        part = torch.empty(B, H * W // 64, 32, 2, device=x_hwc.device, dtype=F32)
+        _lib.call("adap_conv2d_next_gn_partial", part.data_ptr(), Cout // 32)
+    _lib.call("adap_conv3x3_rgb", x_hwc.data_ptr(), 3, w_packed.data_ptr(), _ptr(bias), y.data_ptr(), 0, B, H, W, Cout, _stream())
+    if part is not None:
+        chunks = _lib.call_long("adap_conv2d_last_gn_chunks")
+        if chunks > 0:
+            setattr(y, GN_STATS_ATTR, (part, chunks, y._version, tuple(y.shape)))
+    if e0 is not None:
+        # (family = the kernel's symbol, as conv2d does; the name starts with "conv": bench.py's contraction families)
+        TIMER.stop(f"conv3x3_rgb_kernel<{Cout // 16}>", 2.0 * B * H * W * Cout * 27, e0, f"M={B * H * W} N={Cout} K=3x9 rgb f32")
+    return y
+
+
 def linear(x, w_packed, Cout, bias=None, residual=None, out_f32=True, out_bf16=False, alpha=1.0):
     """x [..., Cin] -> [..., Cout] through the 1x1 path."""
     shp = x.shape

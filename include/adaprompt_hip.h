@@ -98,6 +98,13 @@ int adap_conv2d_debug_force(int kind, int bn);
 int adap_conv2d_next_gn_partial(float* partial, int channels_per_group);
 int adap_conv2d_last_gn_chunks(void);
 
+/* conv3x3 (stride 1, pad 1) on an RGB image -- the VAE encoder's conv_in (model.py:426, 468) -- with the whole 3 x 3 x 3 patch of a
+ * pixel as ONE K step of the matrix core (k = 3 * tap + channel) instead of nine steps of a channel dimension padded 3 -> 64.
+ * x_hwc f32 [B][H][W][ldx >= 3]; w_packed = adap_pack_conv_weight's forward pack [9][Cout][8] of the [Cout][3][3][3] weight;
+ * Cout in {32, 64, 128}; y32 and / or y16 [B][H][W][Cout].  Honours adap_conv2d_next_gn_partial (Cout = 128, H * W % 256 == 0). */
+int adap_conv3x3_rgb(const float* x_hwc, long ldx, const void* w_packed, const float* bias, float* y32, void* y16, int B,
+                     int H, int W, int Cout, void* stream);
+
 /* One UNet ResBlock (openaimodel.py:259-279: GroupNorm+SiLU -> conv3x3 + emb -> GroupNorm+SiLU -> conv3x3 + skip) issued from
  * ONE call, forward and data gradient: the launches of adap_groupnorm_fwd/bwd and adap_conv2d_nhwc in the order and with the
  * arguments of the per-op sequence, so the numbers are bit-identical to it -- what changes is the host: one call instead of 5-6

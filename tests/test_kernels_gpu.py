@@ -96,6 +96,31 @@ def test_conv2d(case):
     assert rel(nchw(y16.float())[:, :Cout], ref) < 4e-3
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 64, 64, 128), (1, 24, 40, 64), (3, 16, 16, 32), (1, 512, 512, 128)])
+def test_conv3x3_rgb_single_k_step(B, H, W, Cout):
+    """``adap_conv3x3_rgb`` (the VAE encoder's conv_in, model.py:426, 468: the 3 x 3 x 3 patch as ONE K step, straight from the f32
+    image) against F.conv2d on the bf16-rounded operands, and against the general path (pad 3 -> 8 channels, nine K steps): same
+    products, another summation order.  With Cout = 128 the epilogue's GroupNorm statistics records against the output's sums."""
+    x = rnd(B, H, W, 3, seed=1)
+    w = rnd(Cout, 3, 3, 3, seed=2, scale=27 ** -0.5)
+    bias = rnd(Cout, seed=3)
+    pk = ops.PackedConv(w, bias)
+    stats = Cout == 128 and (H * W) % 256 == 0
+    y = ops.conv3x3_rgb(x, pk.fwd, Cout, bias=pk.bias, gn_stats=stats)
+    ref = F.conv2d(bf(x).permute(0, 3, 1, 2), bf(w), bias, padding=1).permute(0, 2, 3, 1)
+    assert rel(y, ref) < 2e-5, rel(y, ref)
+    y_gen, _ = ops.conv2d(ops.pad_cast_bf16(x, 8), pk.fwd, Cout, 3, 1, 1, bias=pk.bias)
+    assert rel(y, y_gen) < 2e-6
+    if stats:
+        part, chunks = getattr(y, ops.GN_STATS_ATTR)[:2]
+        assert chunks == H * W // 64
+        g = y.double().view(B, H * W // 64, 64, 32, Cout // 32)
+        want = torch.stack([g.sum(dim=(2, 4)), (g * g).sum(dim=(2, 4))], dim=-1)
+        assert rel(part.double(), want) < 1e-5
+    else:
+        assert getattr(y, ops.GN_STATS_ATTR, None) is None
+
+
 def test_conv2d_epilogue_and_splitk():
     B, Cin, Cout, H = 2, 640, 320, 8
     x = bf(rnd(B, Cin, H, H, seed=1))
