@@ -433,6 +433,14 @@ def main():
         return loss
 
     run_steps(0, args.warmup)
+    if lanes is not None and ld.batch_idx % 2 == 1:
+        # an odd warm-up ends in the middle of an accumulation window: close it here, untimed (clip + optimiser step on the one
+        # micro-batch it holds), so that the timed region is whole windows -- K micro-batches and K / 2 optimiser steps either way
+        reducer.wait()
+        opt.step(clip_norm=ld.grad_clip)
+        reducer.zero()
+        sched.step()
+        ld.batch_idx += 1
     sync()
     t0 = time.perf_counter()
     loss = run_steps(0, args.steps)
