@@ -413,6 +413,44 @@ extern "C" int adap_pad_cast_bf16(const float* in, long ldi, int Cin, void* out,
 }
 
 // ---------------------------------------------------------------------------------------------
+// nearest-neighbour x2 upsample with the cast to bf16: f32 [B][H][W][C] -> bf16 [B][2H][2W][C] (Upsample, openaimodel.py:95-123:
+// F.interpolate(scale_factor=2, mode="nearest") in front of its conv3x3).  The conv then reads a plain bf16 image and takes
+// the stencil-window kernel instead of the register-staged gather variant.  One thread = 8 channels of one SOURCE pixel: two
+// 16-byte loads, four 16-byte stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2x_bf16_kernel(const float* __restrict__ in, long ldi, uint16_t* __restrict__ out, int B,
+                                                              int H, int W, int C) {
+    const int octs = C >> 3;
+    const long total = (long)B * H * W * octs;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int o = (int)(idx % octs);
+        long pxl = idx / octs;
+        const int xx = (int)(pxl % W);
+        pxl /= W;
+        const int yy = (int)(pxl % H);
+        const int b = (int)(pxl / H);
+        const float4* src = (const float4*)(in + ((size_t)(b * H + yy) * W + xx) * ldi + 8 * o);
+        const float4 a = src[0], c = src[1];
+        float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        const uint4 q = pack_bf16x8(v);
+        uint16_t* dst = out + (((size_t)b * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C + 8 * o;
+        *(uint4*)dst = q;
+        *(uint4*)(dst + C) = q;
+        *(uint4*)(dst + (size_t)2 * W * C) = q;
+        *(uint4*)(dst + (size_t)2 * W * C + C) = q;
+    }
+}
+
+extern "C" int adap_upsample2x_bf16(const float* in, long ldi, void* out, int B, int H, int W, int C, void* stream) {
+    ADAP_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0, ADAP_ERR_SHAPE, "upsample2x_bf16: bad args");
+    ADAP_REQUIRE(C % 8 == 0 && ldi % 4 == 0 && ldi >= C && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, ADAP_ERR_ALIGN,
+                 "upsample2x_bf16: C=%d ldi=%ld", C, ldi);
+    hipLaunchKernelGGL(upsample2x_bf16_kernel, dim3(grid_for((long)B * H * W * (C >> 3), 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       ldi, (uint16_t*)out, B, H, W, C);
+    return adap_check_launch("upsample2x_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------
 // batched bf16 transpose [R][C] -> [C][R] through a 64x64 LDS tile (V^T for the VAE mid attention)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R,

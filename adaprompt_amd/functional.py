@@ -914,6 +914,9 @@ class SpatialTransformerFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # Downsample / Upsample / head / concat
 # ---------------------------------------------------------------------------------------------
+UPSAMPLE_BF16 = os.environ.get("ADAP_UPSAMPLE_BF16", "1") != "0"
+
+
 class ConvFn(torch.autograd.Function):
     """conv3x3 on the f32 residual stream: stride 1 (mode 'same'), UNet Downsample (stride 2, pad 1;
     openaimodel.py:138-164) or Upsample (nearest x2 then conv; openaimodel.py:95-123)."""
@@ -926,7 +929,12 @@ class ConvFn(torch.autograd.Function):
         if mode == "down":
             y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 2, 1, bias=pk.bias)
         elif mode == "up":
-            y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias)
+            if UPSAMPLE_BF16 and train is None and not F32_STORAGE and x.dtype == torch.float32 and x.shape[-1] % 64 == 0:
+                # the interpolate as its own small kernel (f32 -> bf16, x2 nearest), the conv on a plain bf16 image: the
+                # stencil-window kernel instead of the register-staged gather variant (same bf16 operand values either way)
+                y, _ = ops.conv2d(ops.upsample2x_bf16(x), pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
+            else:
+                y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias)
         else:
             y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
         return y
@@ -934,7 +942,9 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         pk, mode = ctx.pk, ctx.mode
-        if mode == "same":
+        if mode == "same" or (mode == "up" and ctx.train is None and not F32_STORAGE):
+            # the bf16 side copy the gradient's producer left (the same values, rounded the way the f32 path rounds them in
+            # registers): the data-gradient conv then takes the stencil-window kernel instead of the register-staged one
             g = _operand(g)
         if ctx.train is not None:
             (x,) = ctx.saved_tensors

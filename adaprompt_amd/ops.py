@@ -250,8 +250,9 @@ def conv3x3_rgb(x_hwc, w_packed, Cout, bias=None, gn_stats=False):
         if chunks > 0:
             setattr(y, GN_STATS_ATTR, (part, chunks, y._version, tuple(y.shape)))
     if e0 is not None:
-        # (family = the kernel's symbol, as conv2d does; the name starts with "conv": bench.py's contraction families)
-        TIMER.stop(f"conv3x3_rgb_kernel<{Cout // 16}>", 2.0 * B * H * W * Cout * 27, e0, f"M={B * H * W} N={Cout} K=3x9 rgb f32")
+        # an HBM-bound kernel (7 GFLOP against 537 MB of output at 512 x 512): its work is counted in algorithmic BYTES
+        # (read the image, write the output), like the GroupNorms, not in FLOPs
+        TIMER.stop("hbm:rgb_conv_in", float(B * H * W) * (12 + 4 * Cout), e0, f"M={B * H * W} N={Cout} K=3x9 rgb f32")
     return y
 
 
@@ -727,6 +728,16 @@ def pad_cast_bf16(x, Cout=None):
     Cout = Cin if Cout is None else Cout
     out = torch.empty(tuple(x.shape[:-1]) + (Cout,), device=x.device, dtype=BF16)
     _lib.call("adap_pad_cast_bf16", x.data_ptr(), ldi, Cin, out.data_ptr(), Cout, Cout, rows, _stream())
+    return out
+
+
+def upsample2x_bf16(x):
+    """x f32 [B,H,W,C] -> bf16 [B,2H,2W,C], nearest neighbour (``adap_upsample2x_bf16``)."""
+    B, H, W, C = x.shape
+    assert x.dtype == F32 and x.stride(-1) == 1
+    _, ldi = _rows_ld(x)
+    out = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=BF16)
+    _lib.call("adap_upsample2x_bf16", x.data_ptr(), ldi, out.data_ptr(), B, H, W, C, _stream())
     return out
 
 

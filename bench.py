@@ -501,7 +501,7 @@ def main():
                                                 "ms_per_step": round(call["ms"], 3),
                                                 "achieved": round(call["work"] / (call["ms"] * 1e-3) / 1e12, 1), "unit": "TFLOP/s"},
                     "others": {**{k: fam(v, "TFLOP/s") for k, v in summ.items() if k != dom and (k.startswith("conv") or "attention" in k)},
-                               **{k: fam(v, "GB/s") for k, v in summ.items() if k.startswith("groupnorm")}}}
+                               **{k: fam(v, "GB/s") for k, v in summ.items() if k.startswith("groupnorm") or k.startswith("hbm:")}}}
 
     # ---- the north star's two named aggregates, measured in isolation on the step's own modules (HIP events, 20
     # launches each): self-attention at the 64x64 level against the bf16 MFMA peak, and one 320->320 ResBlock at

@@ -408,6 +408,9 @@ int adap_sumpool2x2(const float* in, float* out, int B, int H, int W, int C, voi
 
 /* f32 [rows][Cin] -> bf16 [rows][Cout >= Cin], zero padded (image 3->8 / latent 4->8 channels, or a plain cast). */
 int adap_pad_cast_bf16(const float* in, long ldi, int Cin, void* out, long ldo, int Cout, long rows, void* stream);
+/* nearest x2 upsample + cast: f32 [B][H][W][C] (row stride ldi) -> bf16 [B][2H][2W][C] -- the interpolate in front of Upsample's
+ * conv3x3 (openaimodel.py:95-123), so that the conv reads a plain bf16 image.  C % 8 == 0. */
+int adap_upsample2x_bf16(const float* in, long ldi, void* out, int B, int H, int W, int C, void* stream);
 
 /* batched bf16 transpose [R][C] -> [C][R] (V^T of the VAE mid attention, model.py:236-239). */
 int adap_transpose_bf16(const void* in, void* out, int batch, int R, int C, void* stream);

@@ -121,6 +121,32 @@ def test_conv3x3_rgb_single_k_step(B, H, W, Cout):
         assert getattr(y, ops.GN_STATS_ATTR, None) is None
 
 
+def test_upsample2x_bf16_and_upsample_conv_paths_agree():
+    """``adap_upsample2x_bf16`` = F.interpolate(nearest, x2) + bf16 rounding, exactly; and Upsample's conv on that image (the
+    stencil-window kernel) against the fused-gather form ``conv2d(up=1)`` on the f32 tensor: same operands, another summation order."""
+    from adaprompt_amd import functional as HF
+    x = rnd(2, 16, 16, 640, seed=1)
+    up = ops.upsample2x_bf16(x)
+    ref = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1).to(torch.bfloat16)
+    assert torch.equal(up, ref)
+    pk = ops.PackedConv(rnd(640, 640, 3, 3, seed=2, scale=(9 * 640) ** -0.5), rnd(640, seed=3))
+    y_new, _ = ops.conv2d(up, pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias)
+    y_old, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias)
+    assert rel(y_new, y_old) < 2e-6
+    # and through the block Function, both switches
+    outs = []
+    for flag in (True, False):
+        old, HF.UPSAMPLE_BF16 = HF.UPSAMPLE_BF16, flag
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = HF.ConvFn.apply(xi, pk, "up")
+            y.backward(rnd(*y.shape, seed=4))
+            outs.append((y.detach(), xi.grad.detach()))
+        finally:
+            HF.UPSAMPLE_BF16 = old
+    assert rel(outs[0][0], outs[1][0]) < 2e-6 and rel(outs[0][1], outs[1][1]) < 2e-6
+
+
 def test_conv2d_epilogue_and_splitk():
     B, Cin, Cout, H = 2, 640, 320, 8
     x = bf(rnd(B, Cin, H, H, seed=1))
