@@ -942,7 +942,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         pk, mode = ctx.pk, ctx.mode
-        if mode == "same" or (mode == "up" and ctx.train is None and not F32_STORAGE):
+        if mode == "same" or (mode in ("up", "down") and ctx.train is None and not F32_STORAGE):
             # the bf16 side copy the gradient's producer left (the same values, rounded the way the f32 path rounds them in
             # registers): the data-gradient conv then takes the stencil-window kernel instead of the register-staged one
             g = _operand(g)
