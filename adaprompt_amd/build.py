@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadaprompt_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "adaprompt_hip.h")
-SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip", "wgrad.hip", "vae.hip", "comm.hip", "regloss.hip", "blocks.hip"]
+SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip", "wgrad.hip", "vae.hip", "comm.hip", "regloss.hip", "blocks.hip", "stage2loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -1066,6 +1066,34 @@ class CosineRowsFn(torch.autograd.Function):
         return (None if dx is None else dx.reshape(xs)), (None if dr is None else dr.reshape(rs)), None, None, None, None
 
 
+class ElasticMatchFn(torch.autograd.Function):
+    """Stage 2's elastic matching loss of one layer (ldm/util.py:2241-2368) as one C call each way (csrc/stage2loss.hip):
+    (q [4, Cq, N], f [4, Cf, N], fg f32 [N]) -> (map_align, sc_ss_fg, sc_mc_bg, sc_below [1, 1, N], mc_below [1, 1, N]).
+    Fixed-order sums: two runs are bit-equal (the torch expressions went through a vendor GEMM and were not)."""
+
+    @staticmethod
+    def forward(ctx, q, f, fg, cutoff, gs_q, gs_feat, gs_mix):
+        q4, f4 = q.float().contiguous(), f.float().contiguous()
+        fgf = fg.reshape(-1).float().contiguous()
+        P2, RT, tok, out = ops.elastic_match_fwd(q4, f4, fgf, cutoff)
+        ctx.save_for_backward(q4, f4, fgf, P2, RT, tok, out)
+        ctx.cfg = (float(cutoff), float(gs_q), float(gs_feat), float(gs_mix), q.shape, f.shape)
+        ctx.set_materialize_grads(False)
+        N = fgf.numel()
+        return (out[0], out[1], out[2], tok[ops.EM_SC_BELOW].view(1, 1, N), tok[ops.EM_MC_BELOW].view(1, 1, N))
+
+    @staticmethod
+    def backward(ctx, g_map, g_fg, g_bg, g_scb, g_mcb):
+        q4, f4, fgf, P2, RT, tok, out = ctx.saved_tensors
+        cutoff, gs_q, gs_feat, gs_mix, qs, fs = ctx.cfg
+        sc = lambda g: None if g is None else g.reshape(1).float()
+        vec = lambda g: None if g is None else g.reshape(-1).float().contiguous()
+        dq, df = ops.elastic_match_bwd(q4, f4, fgf, cutoff, gs_q, gs_feat, gs_mix, P2, RT, tok, out, sc(g_map), sc(g_fg),
+                                       sc(g_bg), vec(g_scb), vec(g_mcb))
+        return (dq.reshape(qs) if ctx.needs_input_grad[0] else None, df.reshape(fs) if ctx.needs_input_grad[1] else None,
+                None, None, None, None, None)
+
+
 class OrthoRowsFn(torch.autograd.Function):
     """``ortho_subtract`` over the last dim (ldm/util.py:280): one HIP launch forward and one backward instead of ~8 + ~15
     element-wise / reduction torch launches (Stage 2 calls it ~60 times per micro-batch)."""

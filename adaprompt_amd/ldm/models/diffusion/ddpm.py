@@ -688,6 +688,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         ind_N = it1.repeat(4)
         mix_gs = gen_gradient_scaler(0.02)
         l_map, l_scss, l_scmc, l_sbg, l_mbg = [], [], [], [], []
+        pooled_masks = {}               # per feature-map size: (pooled mask of the single instance, whether it has foreground)
         for li, ca_outfeat in ca_outfeats.items():
             if li not in w_layers:
                 continue
@@ -705,12 +706,16 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             pool = (lambda x: F.avg_pool2d(x, 4, stride=2)) if ca_outfeat.shape[-1] > 8 else (lambda x: x)
             q_p = pool(q).reshape(*q.shape[:2], -1)
             f_p = pool(ca_outfeat).reshape(*ca_outfeat.shape[:2], -1)
-            m4 = resize_mask_for_feat_or_attn(ca_outfeat, fg_mask_4b, "fg_mask_4b", num_spatial_dims=2, mode="nearest|bilinear")
-            m_p = pool(m4).chunk(4)[0]
-            m_p = m_p.reshape(*m_p.shape[:2], -1)
+            size = tuple(ca_outfeat.shape[2:])
+            if size not in pooled_masks:            # the same mask at every layer of one resolution: resized and counted once
+                m4 = resize_mask_for_feat_or_attn(ca_outfeat, fg_mask_4b, "fg_mask_4b", num_spatial_dims=2, mode="nearest|bilinear")
+                m_p = pool(m4).chunk(4)[0]
+                m_p = m_p.reshape(*m_p.shape[:2], -1)
+                pooled_masks[size] = (m_p, bool((m_p != 0).any().item()))
+            m_p, fg_any = pooled_masks[size]
             lm, lf, lb, sc_below, mc_below = calc_elastic_matching_loss(q_p, f_p, m_p, fg_bg_cutoff_prob=0.25,
                                                                         single_q_grad_scale=0.1, single_feat_grad_scale=0.01,
-                                                                        mix_feat_grad_scale=0.05)
+                                                                        mix_feat_grad_scale=0.05, fg_any=fg_any)
             l_map.append(lm * w)
             l_scss.append(lf * w)
             l_scmc.append(lb * w)

@@ -202,16 +202,25 @@ def convert_attn_to_spatial_weight(flat_attn, BS, out_spatial_shape, reversed=Tr
     return w / w.mean(dim=(2, 3), keepdim=True), attn
 
 
+ELASTIC_FUSED = True      # CUDA tensors take the one-call HIP form (functional.ElasticMatchFn); False: the torch expressions
+                          # below (what CPU tensors always take) -- the tests compare the two
+
+
 def calc_elastic_matching_loss(ca_q, ca_outfeat, fg_mask, fg_bg_cutoff_prob=0.25, single_q_grad_scale=0.1,
-                               single_feat_grad_scale=0.01, mix_feat_grad_scale=0.05):
+                               single_feat_grad_scale=0.01, mix_feat_grad_scale=0.05, fg_any=None):
     """ca_q, ca_outfeat [4 blocks (subject single, subject comp, mix single, mix comp), C, N]; fg_mask [1, 1, N] of the
     single instances.  Soft correspondence comp -> single by the queries' dot products (softmax over the comp tokens);
     -> (|P_subj - P_mix| on foreground pairs, cosine loss of the comp features carried onto the single foreground vs the
     single foreground features, cosine loss between subject-comp and mix-comp features on the tokens that map to no
     foreground, and the two soft background weights [1, 1, N])."""
     fg = fg_mask.bool().squeeze(1)
-    if fg.sum() == 0:
+    if not (fg.any().item() if fg_any is None else fg_any):      # (``fg_any``: the caller already knows -- no host sync here)
         return 0, 0, 0, None, None
+    if ca_q.is_cuda and ELASTIC_FUSED:
+        from .. import functional as HF
+        assert ca_q.shape[0] == 4 and ca_outfeat.shape[0] == 4, "the four blocks of ONE instance (ddpm.py:3041: BLOCK_SIZE 1)"
+        return HF.ElasticMatchFn.apply(ca_q, ca_outfeat, fg, fg_bg_cutoff_prob, single_q_grad_scale, single_feat_grad_scale,
+                                       mix_feat_grad_scale)
     q_gs, feat_gs = gen_gradient_scaler(single_q_grad_scale), gen_gradient_scaler(single_feat_grad_scale)
     ss_q, sc_q, ms_q, mc_q = ca_q.chunk(4)
     # softmax over the comp tokens (dim 1 of [1, N_comp, N_single]), taken on the transposed product so that it runs over the
@@ -226,7 +235,7 @@ def calc_elastic_matching_loss(ca_q, ca_outfeat, fg_mask, fg_bg_cutoff_prob=0.25
     loss_map_align = masked_mean((sc_map_ss_prob - mc_map_ms_prob).abs(), fg_hw)
     loss_sc_ss_fg = calc_ref_cosine_loss(sc_recon_ss_fg, ss_fg_feat, exponent=2, do_demean_first=False,
                                          first_n_dims_to_flatten=2, ref_grad_scale=1)
-    fgf = fg.float().unsqueeze(2)
+    fgf = fg.to(sc_map_ss_prob.dtype).unsqueeze(2)
     sc_fg_prob = torch.matmul(sc_map_ss_prob, fgf).permute(0, 2, 1)
     mc_fg_prob = torch.matmul(mc_map_ms_prob, fgf).permute(0, 2, 1)
     sc_below = torch.clamp(fg_bg_cutoff_prob - sc_fg_prob, min=0)

@@ -863,6 +863,44 @@ def cosine_rows(x, r, demean, align, ref_grad_scale=1.0, gl=None, want_dx=True, 
     return dx, dr
 
 
+EM_TOK_ROWS, EM_OUT_FLOATS, EM_COEF_ROWS = 11, 8, 10          # include/adaprompt_hip.h ADAP_EM_*
+EM_SC_BELOW, EM_MC_BELOW = 8, 9
+
+
+def elastic_match_fwd(q, f, fg, cutoff):
+    """q f32 [4, Cq, N], f f32 [4, Cf, N] (subject single / subject comp / mix single / mix comp of one instance), fg f32 [N]
+    -> (P2 [2, N, N], RT [Cf, N], tok [EM_TOK_ROWS, N], out [EM_OUT_FLOATS]): ldm/util.py:2241-2368 in fixed-order f32 sums
+    (csrc/stage2loss.hip).  out[:3] = (map_align, sc_ss_fg, sc_mc_bg); tok[EM_SC_BELOW], tok[EM_MC_BELOW] the weight vectors."""
+    assert q.dtype == F32 and f.dtype == F32 and fg.dtype == F32 and q.is_contiguous() and f.is_contiguous() and fg.is_contiguous()
+    assert q.dim() == 3 and f.dim() == 3 and q.shape[0] == 4 and f.shape[0] == 4 and q.shape[2] == f.shape[2] == fg.numel()
+    Cq, N, Cf = q.shape[1], q.shape[2], f.shape[1]
+    P2 = torch.empty(2, N, N, device=q.device, dtype=F32)
+    RT = torch.empty(Cf, N, device=q.device, dtype=F32)
+    tok = torch.empty(EM_TOK_ROWS, N, device=q.device, dtype=F32)
+    out = torch.empty(EM_OUT_FLOATS, device=q.device, dtype=F32)
+    _lib.call("adap_elastic_match_fwd", q.data_ptr(), Cq, f.data_ptr(), Cf, fg.data_ptr(), N, float(cutoff), P2.data_ptr(),
+              RT.data_ptr(), tok.data_ptr(), out.data_ptr(), _stream())
+    return P2, RT, tok, out
+
+
+def elastic_match_bwd(q, f, fg, cutoff, gs_q, gs_feat, gs_mix, P2, RT, tok, out, g_map, g_fg, g_bg, g_scb, g_mcb):
+    """gradients of sum(g * outputs) of ``elastic_match_fwd`` (any g may be None = zero) -> (dq [4, Cq, N], df [4, Cf, N])."""
+    Cq, N, Cf = q.shape[1], q.shape[2], f.shape[1]
+    for g in (g_map, g_fg, g_bg):
+        assert g is None or (g.dtype == F32 and g.numel() == 1)
+    for g in (g_scb, g_mcb):
+        assert g is None or (g.dtype == F32 and g.numel() == N and g.is_contiguous())
+    dS2 = torch.empty(2, N, N, device=q.device, dtype=F32)
+    dRT = torch.empty(Cf, N, device=q.device, dtype=F32)
+    coef = torch.empty(EM_COEF_ROWS, N, device=q.device, dtype=F32)
+    dq, df = torch.empty_like(q), torch.empty_like(f)
+    _lib.call("adap_elastic_match_bwd", q.data_ptr(), Cq, f.data_ptr(), Cf, fg.data_ptr(), N, float(cutoff), float(gs_q),
+              float(gs_feat), float(gs_mix), P2.data_ptr(), RT.data_ptr(), tok.data_ptr(), out.data_ptr(), _ptr(g_map), _ptr(g_fg),
+              _ptr(g_bg), _ptr(g_scb), _ptr(g_mcb), dS2.data_ptr(), dRT.data_ptr(), coef.data_ptr(), dq.data_ptr(), df.data_ptr(),
+              _stream())
+    return dq, df
+
+
 def ortho_rows(a, b, g=None, want_da=True, want_db=True):
     """a, b f32 [R, D] (rows contiguous).  g None: -> a - <a,b>/(<b,b>+1e-6) b per row (ldm/util.py:280 ortho_subtract).
     g f32 [R, D] = the gradient of the result: -> (da, db)."""

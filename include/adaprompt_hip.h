@@ -511,6 +511,31 @@ int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const f
 int adap_ortho_rows(const float* a, long lda, const float* b, long ldb, const float* g, long ldg, float* out, long ldo,
                     float* da, long ldda, float* db, long lddb, long R, int D, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Stage-2 elastic matching loss of ONE distillation layer, value and gradient (ldm/util.py:2241-2368
+ * calc_elastic_matching_loss; caller ddpm.py:4389-4551).  The batch is the four blocks (subject single, subject comp, mix
+ * single, mix comp) of one instance:  q f32 [4][Cq][N] pooled queries, f f32 [4][Cf][N] pooled output features, fg f32 [N]
+ * (non-zero = foreground token of the single instance).  All sums run in a fixed order (no split K, no atomics): two runs are
+ * bit-equal.  Forward fills
+ *   P2  f32 [2][N][N]  the two correspondence softmaxes P[z][i][j] (i single token, j comp token; z = 0 subject, 1 mix),
+ *   RT  f32 [Cf][N]    the comp features carried onto the single tokens,
+ *   tok f32 [ADAP_EM_TOK_ROWS][N]   per-token records (rows below; SC_BELOW / MC_BELOW are the two returned weight vectors),
+ *   out f32 [ADAP_EM_OUT_FLOATS]    the three losses, the weight sum and the foreground count.
+ * Backward takes device pointers to the incoming gradients of the three losses (scalars) and of the two `below` vectors
+ * ([N]); NULL = zero.  Scratch: dS2 [2][N][N], dRT [Cf][N], coef [ADAP_EM_COEF_ROWS][N].  Results: dq [4][Cq][N], df [4][Cf][N]
+ * with the reference's gradient scales applied (gs_q on the single queries, gs_feat on the single features, gs_mix on the
+ * mix-comp features). */
+enum { ADAP_EM_P_SC, ADAP_EM_P_MC, ADAP_EM_DOT_FG, ADAP_EM_NA_FG, ADAP_EM_NB_FG, ADAP_EM_DOT_BG, ADAP_EM_NA_BG, ADAP_EM_NB_BG,
+       ADAP_EM_SC_BELOW, ADAP_EM_MC_BELOW, ADAP_EM_ROWPART, ADAP_EM_TOK_ROWS };
+enum { ADAP_EM_OUT_MAP, ADAP_EM_OUT_FG, ADAP_EM_OUT_BG, ADAP_EM_OUT_W, ADAP_EM_OUT_NFG, ADAP_EM_OUT_FLOATS = 8 };
+enum { ADAP_EM_COEF_ROWS = 10 };
+int adap_elastic_match_fwd(const float* q, int Cq, const float* f, int Cf, const float* fg, int N, float cutoff, float* P2,
+                           float* RT, float* tok, float* out, void* stream);
+int adap_elastic_match_bwd(const float* q, int Cq, const float* f, int Cf, const float* fg, int N, float cutoff, float gs_q,
+                           float gs_feat, float gs_mix, const float* P2, const float* RT, const float* tok, const float* out,
+                           const float* g_map, const float* g_fg, const float* g_bg, const float* g_scb, const float* g_mcb,
+                           float* dS2, float* dRT, float* coef, float* dq, float* df, void* stream);
+
 /* The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for L same-resolution layers:
  * S / G f32 [L][B][H][N] = per-head score maps of the subject / background tokens (element stride `estride`: they
  * are columns of a token-map tensor; G NULL = subject-only, calc_fg_mb_suppress_loss), fmask f32 [B][N] in {0,1},
