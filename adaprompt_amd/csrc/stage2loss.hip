@@ -384,3 +384,219 @@ extern "C" int adap_elastic_match_bwd(const float* q, int Cq, const float* f, in
     em_gemm(false, true, d, 2, s);
     return adap_check_launch("elastic_match_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// calc_prompt_mix_loss's per-layer terms on the subject tokens' score maps (ddpm.py:3714-3930; ldm/util.py:543-594
+// calc_delta_alignment_loss "feat_to_ref" with the cosine of exponent 3, and the L1 between mean scores).
+//   a f32 [4][H][N] = (ss, sc, ms, mc) score maps summed over the subject tokens, one instance, H heads.  Per head:
+//     src = ss - c1 ms, c1 = <ss,ms> / (<ms,ms> + 1e-6);   tgt = sc - c2 mc, c2 = <sc,mc> / (<mc,mc> + 1e-6)
+//     delta = 1 - cos(tgt, src^3)            norm = |mean sc - mean mc| + |mean ss - mean ms|
+//   out[0] = mean_h delta, out[1] = mean_h norm.  The mix maps (ms, mc) carry gradient scaled by gs_mix (0.05).
+// One workgroup walks the heads in order: fixed summation order, one launch each way.  rec f32 [H][ADAP_PM_REC] is the forward's
+// record for the backward.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_THREADS) void pm_attnterms_fwd_kernel(const float* __restrict__ a, int H, int N,
+                                                                      float* __restrict__ rec, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    const long HN = (long)H * N;
+    float ld = 0.f, ln = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const float* ss = a + (long)h * N;
+        const float* sc = ss + HN;
+        const float* ms = ss + 2 * HN;
+        const float* mc = ss + 3 * HN;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int n = t; n < N; n += EM_THREADS) {
+            const float x0 = ss[n], x1 = sc[n], x2 = ms[n], x3 = mc[n];
+            v[0] += x0 * x2; v[1] += x2 * x2; v[2] += x1 * x3; v[3] += x3 * x3;
+            v[4] += x0; v[5] += x1; v[6] += x2; v[7] += x3;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = em_block_sum(v[k], red);
+        const float c1 = v[0] / (v[1] + 1e-6f), c2 = v[2] / (v[3] + 1e-6f);
+        float P = 0.f, A = 0.f, B = 0.f;
+        for (int n = t; n < N; n += EM_THREADS) {
+            const float src = ss[n] - c1 * ms[n], tgt = sc[n] - c2 * mc[n], tt = src * src * src;
+            P += tgt * tt; A += tgt * tgt; B += tt * tt;
+        }
+        P = em_block_sum(P, red);
+        A = em_block_sum(A, red) + 1e-12f;
+        B = em_block_sum(B, red) + 1e-12f;
+        const float m0 = v[4] / N, m1 = v[5] / N, m2 = v[6] / N, m3 = v[7] / N;
+        ld += 1.0f - P / sqrtf(A * B);
+        ln += fabsf(m1 - m3) + fabsf(m0 - m2);
+        if (t == 0) {
+            float* r = rec + (long)h * ADAP_PM_REC;
+            r[0] = c1; r[1] = c2; r[2] = P; r[3] = A; r[4] = B; r[5] = m1 - m3; r[6] = m0 - m2; r[7] = v[1] + 1e-6f; r[8] = v[3] + 1e-6f;
+        }
+    }
+    if (t == 0) { out[0] = ld / H; out[1] = ln / H; }
+}
+
+__global__ __launch_bounds__(EM_THREADS) void pm_attnterms_bwd_kernel(const float* __restrict__ a, int H, int N,
+                                                                      const float* __restrict__ rec, const float* __restrict__ g_delta,
+                                                                      const float* __restrict__ g_norm, float gs_mix,
+                                                                      float* __restrict__ da) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    const long HN = (long)H * N;
+    const float gd = (g_delta ? *g_delta : 0.f) / H, gn = (g_norm ? *g_norm : 0.f) / H;
+    for (int h = 0; h < H; ++h) {
+        const float* ss = a + (long)h * N;
+        const float* sc = ss + HN;
+        const float* ms = ss + 2 * HN;
+        const float* mc = ss + 3 * HN;
+        const float* r = rec + (long)h * ADAP_PM_REC;
+        const float c1 = r[0], c2 = r[1], P = r[2], A = r[3], B = r[4], bb1 = r[7], bb2 = r[8];
+        const float inv = 1.0f / sqrtf(A * B);
+        // g_tgt = gd (-inv t + (P/A) inv tgt);  g_src = gd (-inv tgt + (P/B) inv t) 3 src^2
+        float q1 = 0.f, q2 = 0.f;                    // <g_src, ms>, <g_tgt, mc>
+        for (int n = t; n < N; n += EM_THREADS) {
+            const float src = ss[n] - c1 * ms[n], tgt = sc[n] - c2 * mc[n], tt = src * src * src;
+            const float gt = gd * (-inv * tt + (P / A) * inv * tgt);
+            const float gs = gd * (-inv * tgt + (P / B) * inv * tt) * 3.0f * src * src;
+            q1 += gs * ms[n];
+            q2 += gt * mc[n];
+        }
+        q1 = em_block_sum(q1, red);
+        q2 = em_block_sum(q2, red);
+        const float s1 = q1 / bb1, s2 = q2 / bb2;
+        const float sg_c = r[5] > 0.f ? 1.f : (r[5] < 0.f ? -1.f : 0.f), sg_s = r[6] > 0.f ? 1.f : (r[6] < 0.f ? -1.f : 0.f);
+        const float nc = gn * sg_c / N, ns = gn * sg_s / N;
+        for (int n = t; n < N; n += EM_THREADS) {
+            const float x0 = ss[n], x1 = sc[n], x2 = ms[n], x3 = mc[n];
+            const float src = x0 - c1 * x2, tgt = x1 - c2 * x3, tt = src * src * src;
+            const float gt = gd * (-inv * tt + (P / A) * inv * tgt);
+            const float gs = gd * (-inv * tgt + (P / B) * inv * tt) * 3.0f * src * src;
+            da[(long)h * N + n] = gs - s1 * x2 + ns;
+            da[HN + (long)h * N + n] = gt - s2 * x3 + nc;
+            da[2 * HN + (long)h * N + n] = gs_mix * (-c1 * gs - s1 * (x0 - 2.0f * c1 * x2) - ns);
+            da[3 * HN + (long)h * N + n] = gs_mix * (-c2 * gt - s2 * (x1 - 2.0f * c2 * x3) - nc);
+        }
+    }
+}
+
+extern "C" int adap_promptmix_attn_terms(const float* a, int H, int N, float gs_mix, float* rec, float* out,
+                                         const float* g_delta, const float* g_norm, float* da, void* stream) {
+    ADAP_REQUIRE(a && rec && (out || da), ADAP_ERR_SHAPE, "promptmix_attn_terms: null pointer");
+    ADAP_REQUIRE(H >= 1 && N >= 1, ADAP_ERR_SHAPE, "promptmix_attn_terms: H %d N %d", H, N);
+    if (out) hipLaunchKernelGGL(pm_attnterms_fwd_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a, H, N, rec, out);
+    else hipLaunchKernelGGL(pm_attnterms_bwd_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a, H, N, rec, g_delta, g_norm,
+                            gs_mix, da);
+    return adap_check_launch("promptmix_attn_terms");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// convert_attn_to_spatial_weight (ldm/util.py:1718) for one instance whose score map already has the feature map's
+// resolution: a_n = mean over heads; w_n = min(exp(-(a_n - mean) / max(std + 0.001, mean / 2)), 1) / mean(w)  (std unbiased;
+// `reversed`: small where the subject attends).  Up to two sources; sw = their average (ddpm.py:3869-3872 uses (mix + subj) / 2).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_THREADS) void pm_spatial_weight_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                                       int H, int N, int reversed, float* __restrict__ sw) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    const int nsrc = a1 ? 2 : 1;
+    for (int s = 0; s < nsrc; ++s) {
+        const float* a = s ? a1 : a0;
+        auto val = [&](int n) {
+            float v = 0.f;
+            for (int h = 0; h < H; ++h) v += a[(long)h * N + n];
+            return v / H;
+        };
+        float m = 0.f;
+        for (int n = t; n < N; n += EM_THREADS) m += val(n);
+        m = em_block_sum(m, red) / N;
+        float q = 0.f;
+        for (int n = t; n < N; n += EM_THREADS) { const float d = val(n) - m; q += d * d; }
+        q = em_block_sum(q, red);
+        const float sd = sqrtf(q / (N > 1 ? N - 1 : 1));
+        const float den = fmaxf(sd + 0.001f, m * 0.5f);
+        const float sgn = reversed ? -1.f : 1.f;
+        float ws = 0.f;
+        for (int n = t; n < N; n += EM_THREADS) ws += fminf(expf(sgn * (val(n) - m) / den), 1.f);
+        ws = em_block_sum(ws, red) / N;
+        for (int n = t; n < N; n += EM_THREADS) {
+            const float w = fminf(expf(sgn * (val(n) - m) / den), 1.f) / ws / nsrc;
+            sw[n] = s ? sw[n] + w : w;
+        }
+    }
+}
+
+extern "C" int adap_attn_spatial_weight(const float* a0, const float* a1, int H, int N, int reversed, float* sw, void* stream) {
+    ADAP_REQUIRE(a0 && sw && H >= 1 && N >= 1, ADAP_ERR_SHAPE, "attn_spatial_weight: arguments");
+    hipLaunchKernelGGL(pm_spatial_weight_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a0, a1, H, N, reversed, sw);
+    return adap_check_launch("attn_spatial_weight");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two background-suppression terms of calc_comp_fg_bg_preserve_loss (ddpm.py:4520-4545): masked means of the comp
+// instances' positive subject scores under the elastic matching's `below` weights,
+//   l_s = sum_{h,n} max(sc_a, 0) scb[n] / max(H sum scb, 1e-6),   l_m likewise with (mc_a, mcb), d mc_a scaled by gs_mix (0.02).
+// a f32 [4][H][N] (blocks 1 and 3 are used), scb / mcb f32 [N].  col f32 [2][N] = per-token sums over heads (kept for the backward),
+// out f32 [4] = (l_s, l_m, H sum scb, H sum mcb).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EM_THREADS) void bgs_fwd_kernel(const float* __restrict__ a, const float* __restrict__ scb,
+                                                             const float* __restrict__ mcb, int H, int N, float* __restrict__ col,
+                                                             float* __restrict__ out) {
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    const long HN = (long)H * N;
+    float s1 = 0.f, s2 = 0.f, w1 = 0.f, w2 = 0.f;
+    for (int n = t; n < N; n += EM_THREADS) {
+        float c1 = 0.f, c2 = 0.f;
+        for (int h = 0; h < H; ++h) {
+            c1 += fmaxf(a[HN + (long)h * N + n], 0.f);
+            c2 += fmaxf(a[3 * HN + (long)h * N + n], 0.f);
+        }
+        col[n] = c1;
+        col[N + n] = c2;
+        s1 += c1 * scb[n]; s2 += c2 * mcb[n];
+        w1 += scb[n]; w2 += mcb[n];
+    }
+    s1 = em_block_sum(s1, red); s2 = em_block_sum(s2, red);
+    w1 = em_block_sum(w1, red) * H; w2 = em_block_sum(w2, red) * H;
+    if (t == 0) {
+        out[0] = s1 / fmaxf(w1, 1e-6f);
+        out[1] = s2 / fmaxf(w2, 1e-6f);
+        out[2] = w1;
+        out[3] = w2;
+    }
+}
+
+__global__ __launch_bounds__(EM_THREADS) void bgs_bwd_kernel(const float* __restrict__ a, const float* __restrict__ scb,
+                                                             const float* __restrict__ mcb, int H, int N, const float* __restrict__ col,
+                                                             const float* __restrict__ out, const float* __restrict__ g_s,
+                                                             const float* __restrict__ g_m, float gs_mix, float* __restrict__ da,
+                                                             float* __restrict__ dscb, float* __restrict__ dmcb) {
+    const int n = blockIdx.x * EM_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const long HN = (long)H * N;
+    const float gs = g_s ? *g_s : 0.f, gm = g_m ? *g_m : 0.f;
+    const float w1 = out[2], w2 = out[3];
+    const float c1 = fmaxf(w1, 1e-6f), c2 = fmaxf(w2, 1e-6f);
+    // d l / d weight[n] = colsum[n] / cnt - l H / cnt (the count's clamp passes the gradient where the raw count >= 1e-6)
+    dscb[n] = gs * (col[n] / c1 - (w1 >= 1e-6f ? out[0] * H / c1 : 0.f));
+    dmcb[n] = gm * (col[N + n] / c2 - (w2 >= 1e-6f ? out[1] * H / c2 : 0.f));
+    const float k1 = gs * scb[n] / c1, k2 = gs_mix * gm * mcb[n] / c2;
+    for (int h = 0; h < H; ++h) {
+        const long e = (long)h * N + n;
+        da[e] = 0.f;
+        da[HN + e] = a[HN + e] >= 0.f ? k1 : 0.f;
+        da[2 * HN + e] = 0.f;
+        da[3 * HN + e] = a[3 * HN + e] >= 0.f ? k2 : 0.f;
+    }
+}
+
+extern "C" int adap_bg_suppress(const float* a, const float* scb, const float* mcb, int H, int N, float gs_mix, float* col, float* out,
+                                const float* g_s, const float* g_m, float* da, float* dscb, float* dmcb, void* stream) {
+    ADAP_REQUIRE(a && scb && mcb && col && out, ADAP_ERR_SHAPE, "bg_suppress: null pointer");
+    ADAP_REQUIRE(H >= 1 && N >= 1, ADAP_ERR_SHAPE, "bg_suppress: H %d N %d", H, N);
+    if (!da) hipLaunchKernelGGL(bgs_fwd_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a, scb, mcb, H, N, col, out);
+    else {
+        ADAP_REQUIRE(dscb && dmcb, ADAP_ERR_SHAPE, "bg_suppress: backward needs dscb and dmcb");
+        hipLaunchKernelGGL(bgs_bwd_kernel, dim3((N + EM_THREADS - 1) / EM_THREADS), dim3(EM_THREADS), 0, (hipStream_t)stream, a, scb, mcb,
+                           H, N, col, out, g_s, g_m, gs_mix, da, dscb, dmcb);
+    }
+    return adap_check_launch("bg_suppress");
+}

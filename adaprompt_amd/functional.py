@@ -1094,6 +1094,51 @@ class ElasticMatchFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+class SubjAttnTermsFn(torch.autograd.Function):
+    """calc_prompt_mix_loss's two per-layer terms on the subject tokens' score maps (ddpm.py:3714-3930: the delta alignment of
+    ldm/util.py:543-594 with the cosine of exponent 3, and the L1 between mean scores), one launch each way:
+    a [4, H, N] -> (subj_attn_delta_align, subj_attn_norm_distill) of the layer."""
+
+    @staticmethod
+    def forward(ctx, a, gs_mix):
+        a4 = a.float().contiguous()
+        out, rec = ops.promptmix_attn_terms(a4, gs_mix)
+        ctx.save_for_backward(a4, rec)
+        ctx.cfg = (float(gs_mix), a.shape)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_delta, g_norm):
+        a4, rec = ctx.saved_tensors
+        gs_mix, shape = ctx.cfg
+        sc = lambda g: None if g is None else g.reshape(1).float()
+        return ops.promptmix_attn_terms(a4, gs_mix, rec, sc(g_delta), sc(g_norm)).reshape(shape), None
+
+
+class BgSuppressFn(torch.autograd.Function):
+    """the two background-suppression terms of calc_comp_fg_bg_preserve_loss (ddpm.py:4520-4545), one launch each way:
+    (a [4, H, N], sc_below [.., N], mc_below [.., N]) -> (comp_subj_bg_attn_suppress, comp_mix_bg_attn_suppress) of the layer."""
+
+    @staticmethod
+    def forward(ctx, a, scb, mcb, gs_mix):
+        a4 = a.float().contiguous()
+        s1, m1 = scb.reshape(-1).float().contiguous(), mcb.reshape(-1).float().contiguous()
+        out, col = ops.bg_suppress(a4, s1, m1, gs_mix)
+        ctx.save_for_backward(a4, s1, m1, out, col)
+        ctx.cfg = (float(gs_mix), a.shape, scb.shape, mcb.shape)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_s, g_m):
+        a4, s1, m1, out, col = ctx.saved_tensors
+        gs_mix, sa, ss, sm = ctx.cfg
+        sc = lambda g: None if g is None else g.reshape(1).float()
+        da, dscb, dmcb = ops.bg_suppress(a4, s1, m1, gs_mix, (out, col), sc(g_s), sc(g_m))
+        return da.reshape(sa), dscb.reshape(ss), dmcb.reshape(sm), None
+
+
 class OrthoRowsFn(torch.autograd.Function):
     """``ortho_subtract`` over the last dim (ldm/util.py:280): one HIP launch forward and one backward instead of ~8 + ~15
     element-wise / reduction torch launches (Stage 2 calls it ~60 times per micro-batch)."""

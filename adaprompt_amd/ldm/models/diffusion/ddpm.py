@@ -30,6 +30,9 @@ from ...modules.distributions.distributions import DiagonalGaussianDistribution
 from ...util import default, instantiate_from_config
 from .conditioning import ConditioningMixin
 
+STAGE2_FUSED = True       # CUDA tensors take the one-launch HIP forms of the Stage-2 per-layer terms (csrc/stage2loss.hip); False:
+                          # the torch expressions (what CPU tensors always take) -- tests/test_stage2loss_gpu.py compares the two
+
 # the recon iteration's attention regularisers as one call of the HIP library (LatentDiffusion.fused_token_map_losses);
 # ADAP_FUSED_REG=0 runs the host expressions instead (the checker of the fused form in tests/)
 FUSED_REG_LOSSES = os.environ.get("ADAP_FUSED_REG", "1") != "0"
@@ -636,6 +639,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
           * subj_attn_delta_align: the same for the subject tokens' score maps (cosine, exponent 3);
           * subj_attn_norm_distill: L1 between the mean subject scores of the subject and the mix instances.
         Mix-side gradients are scaled by 0.1 (features) / 0.05 (scores).  -> the three sums over layers (normalised weights)."""
+        from .... import functional as HF
         from ...stage2 import calc_delta_alignment_loss, convert_attn_to_spatial_weight, double_token_indices, ortho_l2loss
         from ...util import gen_gradient_scaler, normalize_dict_values, normalized_sum, ortho_subtract
         w_layers = normalize_dict_values(dict(LatentDiffusion.MIX_LAYER_WEIGHTS))
@@ -652,16 +656,27 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             score = ca_attnscores[li].permute(0, 3, 1, 2)                                   # [4B, 77, heads, N]
             subj_attn_4b = score[fg_indices_4b].reshape(BLOCK_SIZE * 4, K_fg, *score.shape[2:]).sum(dim=1)
             ss_attn, sc_attn, ms_attn, mc_attn = subj_attn_4b.chunk(4)
-            mc_attn_gs, ms_attn_gs = attn_gs(mc_attn), attn_gs(ms_attn)
-            d = calc_delta_alignment_loss(ss_attn, sc_attn, ms_attn, mc_attn, ref_grad_scale=0.05, feat_base_grad_scale=1,
-                                          use_cosine_loss=True, cosine_exponent=3, delta_types=["feat_to_ref"])
-            l_attn_delta.append(d["feat_to_ref"] * w)
-            l_attn_norm.append(((sc_attn.mean(dim=-1) - mc_attn_gs.mean(dim=-1)).abs().mean()
-                                + (ss_attn.mean(dim=-1) - ms_attn_gs.mean(dim=-1)).abs().mean()) * w)
             hw = ca_outfeat.shape[2:]
-            sw_mix, _ = convert_attn_to_spatial_weight(mc_attn, BLOCK_SIZE, hw, reversed=True)
-            sw_subj, _ = convert_attn_to_spatial_weight(sc_attn, BLOCK_SIZE, hw, reversed=True)
-            feat = ca_outfeat * ((sw_mix + sw_subj) / 2)
+            fused = STAGE2_FUSED and subj_attn_4b.is_cuda and BLOCK_SIZE == 1
+            if fused:                          # one launch each way for the two score-map terms (csrc/stage2loss.hip)
+                d_align, d_norm = HF.SubjAttnTermsFn.apply(subj_attn_4b, 0.05)
+                l_attn_delta.append(d_align * w)
+                l_attn_norm.append(d_norm * w)
+            else:
+                mc_attn_gs, ms_attn_gs = attn_gs(mc_attn), attn_gs(ms_attn)
+                d = calc_delta_alignment_loss(ss_attn, sc_attn, ms_attn, mc_attn, ref_grad_scale=0.05, feat_base_grad_scale=1,
+                                              use_cosine_loss=True, cosine_exponent=3, delta_types=["feat_to_ref"])
+                l_attn_delta.append(d["feat_to_ref"] * w)
+                l_attn_norm.append(((sc_attn.mean(dim=-1) - mc_attn_gs.mean(dim=-1)).abs().mean()
+                                    + (ss_attn.mean(dim=-1) - ms_attn_gs.mean(dim=-1)).abs().mean()) * w)
+            if fused and subj_attn_4b.shape[-1] == hw[0] * hw[1]:        # the maps already have the features' resolution
+                sub = subj_attn_4b.detach().float().contiguous()
+                sw = ops.attn_spatial_weight(sub[3], sub[1], reversed=True).view(1, 1, *hw)
+                feat = ca_outfeat * sw
+            else:
+                sw_mix, _ = convert_attn_to_spatial_weight(mc_attn, BLOCK_SIZE, hw, reversed=True)
+                sw_subj, _ = convert_attn_to_spatial_weight(sc_attn, BLOCK_SIZE, hw, reversed=True)
+                feat = ca_outfeat * ((sw_mix + sw_subj) / 2)
             k, st = LatentDiffusion.FEAT_SIZE2POOLER[feat.shape[-1]]
             feat_2d = F.avg_pool2d(feat, k, stride=st).reshape(feat.shape[0], -1)
             ss_f, sc_f, ms_f, mc_f = feat_2d.chunk(4)
@@ -676,6 +691,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         queries / output features of every layer) + suppression of the subject tokens' scores on what the matching calls
         background.  -> (comp_single_map_align, sc_ss_fg_match, mc_ms_fg_match (= 0, disabled in the reference),
         sc_mc_bg_match, comp_subj_bg_attn_suppress, comp_mix_bg_attn_suppress)."""
+        from .... import functional as HF
         from ...stage2 import calc_elastic_matching_loss
         from ...util import gen_gradient_scaler, masked_mean, normalize_dict_values, normalized_sum, resize_mask_for_feat_or_attn
         if fg_mask is None or batch_have_fg_mask.sum() == 0:
@@ -728,6 +744,11 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             if a_hw.shape[2:] != ca_outfeat.shape[2:]:
                 a_hw = F.interpolate(a_hw, size=ca_outfeat.shape[2:], mode="bilinear", align_corners=False)
             a_p = pool(a_hw).reshape(*a_hw.shape[:2], -1)
+            if STAGE2_FUSED and a_p.is_cuda and BLOCK_SIZE == 1:                # one launch each way (csrc/stage2loss.hip)
+                ls, lx = HF.BgSuppressFn.apply(a_p, sc_below, mc_below, 0.02)
+                l_sbg.append(ls * w)
+                l_mbg.append(lx * w)
+                continue
             _, sc_a, _, mc_a = a_p.chunk(4)
             l_sbg.append(masked_mean(sc_a.clamp(min=0), sc_below) * w)
             l_mbg.append(masked_mean(mix_gs(mc_a).clamp(min=0), mc_below) * w)

@@ -901,6 +901,62 @@ def elastic_match_bwd(q, f, fg, cutoff, gs_q, gs_feat, gs_mix, P2, RT, tok, out,
     return dq, df
 
 
+PM_REC = 16           # include/adaprompt_hip.h ADAP_PM_REC
+
+
+def promptmix_attn_terms(a, gs_mix, rec=None, g_delta=None, g_norm=None):
+    """a f32 [4, H, N] (subject single / subject comp / mix single / mix comp subject score maps of one instance).
+    rec None: forward -> (out [2] = (subj_attn_delta_align, subj_attn_norm_distill) of the layer, rec).  rec given: backward for
+    the two incoming gradients (f32 scalars or None) -> da [4, H, N]  (ddpm.py:3714-3930, csrc/stage2loss.hip)."""
+    assert a.dtype == F32 and a.dim() == 3 and a.shape[0] == 4 and a.is_contiguous()
+    H, N = a.shape[1], a.shape[2]
+    if rec is None:
+        rec = torch.empty(H, PM_REC, device=a.device, dtype=F32)
+        out = torch.empty(2, device=a.device, dtype=F32)
+        _lib.call("adap_promptmix_attn_terms", a.data_ptr(), H, N, float(gs_mix), rec.data_ptr(), out.data_ptr(), 0, 0, 0, _stream())
+        return out, rec
+    for g in (g_delta, g_norm):
+        assert g is None or (g.dtype == F32 and g.numel() == 1)
+    da = torch.empty_like(a)
+    _lib.call("adap_promptmix_attn_terms", a.data_ptr(), H, N, float(gs_mix), rec.data_ptr(), 0, _ptr(g_delta), _ptr(g_norm),
+              da.data_ptr(), _stream())
+    return da
+
+
+def attn_spatial_weight(a0, a1=None, reversed=True):
+    """a0 (and a1) f32 [H, N] subject score maps of one instance at the feature map's resolution -> f32 [N]: the mean-1 spatial
+    weight of ldm/util.py:1718 convert_attn_to_spatial_weight, averaged over the sources."""
+    assert a0.dtype == F32 and a0.dim() == 2 and a0.is_contiguous()
+    assert a1 is None or (a1.dtype == F32 and a1.shape == a0.shape and a1.is_contiguous())
+    H, N = a0.shape
+    sw = torch.empty(N, device=a0.device, dtype=F32)
+    _lib.call("adap_attn_spatial_weight", a0.data_ptr(), _ptr(a1), H, N, int(bool(reversed)), sw.data_ptr(), _stream())
+    return sw
+
+
+def bg_suppress(a, scb, mcb, gs_mix, saved=None, g_s=None, g_m=None):
+    """a f32 [4, H, N] pooled subject score maps, scb / mcb f32 [N].  saved None: forward -> (out [4], col [2, N]); out[:2] =
+    (comp_subj_bg_attn_suppress, comp_mix_bg_attn_suppress) of the layer.  saved = (out, col): backward -> (da, dscb, dmcb)."""
+    assert a.dtype == F32 and a.dim() == 3 and a.shape[0] == 4 and a.is_contiguous()
+    H, N = a.shape[1], a.shape[2]
+    for v in (scb, mcb):
+        assert v.dtype == F32 and v.numel() == N and v.is_contiguous()
+    if saved is None:
+        out = torch.empty(4, device=a.device, dtype=F32)
+        col = torch.empty(2, N, device=a.device, dtype=F32)
+        _lib.call("adap_bg_suppress", a.data_ptr(), scb.data_ptr(), mcb.data_ptr(), H, N, float(gs_mix), col.data_ptr(), out.data_ptr(),
+                  0, 0, 0, 0, 0, _stream())
+        return out, col
+    out, col = saved
+    for g in (g_s, g_m):
+        assert g is None or (g.dtype == F32 and g.numel() == 1)
+    da = torch.empty_like(a)
+    dscb, dmcb = torch.empty(N, device=a.device, dtype=F32), torch.empty(N, device=a.device, dtype=F32)
+    _lib.call("adap_bg_suppress", a.data_ptr(), scb.data_ptr(), mcb.data_ptr(), H, N, float(gs_mix), col.data_ptr(), out.data_ptr(),
+              _ptr(g_s), _ptr(g_m), da.data_ptr(), dscb.data_ptr(), dmcb.data_ptr(), _stream())
+    return da, dscb, dmcb
+
+
 def ortho_rows(a, b, g=None, want_da=True, want_db=True):
     """a, b f32 [R, D] (rows contiguous).  g None: -> a - <a,b>/(<b,b>+1e-6) b per row (ldm/util.py:280 ortho_subtract).
     g f32 [R, D] = the gradient of the result: -> (da, db)."""

@@ -536,6 +536,25 @@ int adap_elastic_match_bwd(const float* q, int Cq, const float* f, int Cf, const
                            const float* g_map, const float* g_fg, const float* g_bg, const float* g_scb, const float* g_mcb,
                            float* dS2, float* dRT, float* coef, float* dq, float* df, void* stream);
 
+/* calc_prompt_mix_loss's per-layer terms on the subject tokens' score maps (ddpm.py:3714-3930; calc_delta_alignment_loss
+ * ldm/util.py:543-594 "feat_to_ref", cosine exponent 3; and the L1 between mean scores): a f32 [4][H][N] = the (subject single,
+ * subject comp, mix single, mix comp) maps of one instance.  out != NULL: forward, out[0] = subj_attn_delta_align,
+ * out[1] = subj_attn_norm_distill of this layer, rec f32 [H][ADAP_PM_REC] the record for the backward.  out == NULL: backward
+ * for the two losses' incoming gradients (device scalars, NULL = 0) -> da [4][H][N], the mix maps' share scaled by gs_mix. */
+enum { ADAP_PM_REC = 16 };
+int adap_promptmix_attn_terms(const float* a, int H, int N, float gs_mix, float* rec, float* out, const float* g_delta,
+                              const float* g_norm, float* da, void* stream);
+/* convert_attn_to_spatial_weight (ldm/util.py:1718) for one instance at the feature map's own resolution: a0 (and a1, or NULL)
+ * f32 [H][N] subject score maps -> sw f32 [N] = average over the sources of min(exp(-+(a - mean) / max(std + 0.001, mean / 2)), 1)
+ * normalised to mean 1 (a = mean over heads; `reversed` != 0: small where the subject attends). */
+int adap_attn_spatial_weight(const float* a0, const float* a1, int H, int N, int reversed, float* sw, void* stream);
+/* The two background-suppression terms of calc_comp_fg_bg_preserve_loss (ddpm.py:4520-4545): a f32 [4][H][N] pooled subject
+ * score maps, scb / mcb f32 [N] the elastic matching's `below` weights.  da == NULL: forward, out f32 [4] = (comp_subj_bg_attn_
+ * suppress, comp_mix_bg_attn_suppress, the two mask counts), col f32 [2][N] kept for the backward.  da != NULL: backward for the
+ * two incoming gradients (device scalars, NULL = 0) -> da [4][H][N] (mix share scaled by gs_mix), dscb, dmcb [N]. */
+int adap_bg_suppress(const float* a, const float* scb, const float* mcb, int H, int N, float gs_mix, float* col, float* out,
+                     const float* g_s, const float* g_m, float* da, float* dscb, float* dmcb, void* stream);
+
 /* The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for L same-resolution layers:
  * S / G f32 [L][B][H][N] = per-head score maps of the subject / background tokens (element stride `estride`: they
  * are columns of a token-map tensor; G NULL = subject-only, calc_fg_mb_suppress_loss), fmask f32 [B][N] in {0,1},

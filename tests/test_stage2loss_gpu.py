@@ -73,3 +73,70 @@ def test_elastic_match_fused_equals_the_torch_expressions_in_f64(Cq, Cf, N, qsca
     # the same call again: bit-equal values and gradients
     out2, dq2, df2 = _run(q.to(d), f.to(d), m.to(d), [w.to(d) for w in gw], fused=True)
     assert all(torch.equal(a, b) for a, b in zip(out, out2)) and torch.equal(dq, dq2) and torch.equal(df, df2)
+
+
+# ---- the other per-layer terms: torch expressions (STAGE2_FUSED = False, float64 on the CPU) against the one-launch forms ---------
+def _prompt_mix_inputs(H, N, C, hw, seed):
+    g = torch.Generator().manual_seed(seed)
+    score = torch.rand(4, hw * hw, 77, H, generator=g) * 0.2           # [4B, N, 77, heads] as captured; permuted inside
+    score = score.permute(0, 3, 1, 2).contiguous()                     # ca_attnscores[li]: [4B, heads, N, 77]
+    feat = torch.randn(4, C, hw, hw, generator=g)
+    feat[1] = 0.7 * feat[1] + 0.3 * feat[3]
+    feat[0] = 0.7 * feat[0] + 0.3 * feat[2]
+    return score, feat
+
+
+def _run_prompt_mix(ld_cls, score, feat, idx, li, fused):
+    import adaprompt_amd.ldm.models.diffusion.ddpm as D
+    score, feat = score.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    old = D.STAGE2_FUSED
+    D.STAGE2_FUSED = fused
+    try:
+        outs = ld_cls.calc_prompt_mix_loss(None, {li: feat}, None, {li: score}, idx, 1)
+    finally:
+        D.STAGE2_FUSED = old
+    (outs[0] * 0.9 + outs[1] * 1.1 + outs[2] * 0.7).backward()
+    return [o.detach() for o in outs], score.grad, feat.grad
+
+
+@pytest.mark.parametrize("H,C,hw,li", [(8, 320, 64, 23), (8, 640, 32, 20), (8, 1280, 16, 17), (8, 1280, 8, 12)])
+def test_prompt_mix_terms_fused_equal_the_torch_expressions_in_f64(H, C, hw, li):
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    score, feat = _prompt_mix_inputs(H, hw * hw, C, hw, 3000 + hw)
+    idx2 = (torch.tensor([0] * 4 + [1] * 4), torch.tensor([5, 6, 7, 8] * 2))           # subject tokens of the (single, comp) pair
+    ref, ref_ds, ref_df = _run_prompt_mix(LatentDiffusion, score.double(), feat.double(), idx2, li, fused=False)
+    d = dev()
+    idx_d = tuple(t.to(d) for t in idx2)
+    out, ds, df = _run_prompt_mix(LatentDiffusion, score.to(d), feat.to(d), idx_d, li, fused=True)
+    for k in range(3):
+        assert abs(float(out[k]) - float(ref[k])) <= 3e-5 * abs(float(ref[k])) + 1e-9, (k, float(out[k]), float(ref[k]))
+    rel = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())
+    assert rel(ds, ref_ds) < 3e-4, rel(ds, ref_ds)
+    assert rel(df, ref_df) < 3e-4, rel(df, ref_df)
+    out2, ds2, df2 = _run_prompt_mix(LatentDiffusion, score.to(d), feat.to(d), idx_d, li, fused=True)
+    assert all(torch.equal(a, b) for a, b in zip(out, out2)) and torch.equal(ds, ds2) and torch.equal(df, df2)
+
+
+@pytest.mark.parametrize("H,N", [(8, 961), (8, 225), (8, 49), (5, 64)])
+def test_bg_suppress_fused_equals_masked_means(H, N):
+    from adaprompt_amd import functional as HF
+    from adaprompt_amd.ldm.util import gen_gradient_scaler, masked_mean
+    g = torch.Generator().manual_seed(4000 + N)
+    a = torch.randn(4, H, N, generator=g)
+    scb, mcb = torch.rand(1, 1, N, generator=g).clamp(min=0.3) - 0.3, torch.rand(1, 1, N, generator=g).clamp(min=0.5) - 0.5
+
+    def torch_form(a, scb, mcb):
+        _, sc_a, _, mc_a = a.chunk(4)
+        return masked_mean(sc_a.clamp(min=0), scb), masked_mean(gen_gradient_scaler(0.02)(mc_a).clamp(min=0), mcb)
+
+    ins = [t.double().requires_grad_(True) for t in (a, scb, mcb)]
+    r = torch_form(*ins)
+    (r[0] * 0.8 + r[1] * 1.2).backward()
+    d = dev()
+    ind = [t.to(d).requires_grad_(True) for t in (a, scb, mcb)]
+    o = HF.BgSuppressFn.apply(*ind, 0.02)
+    (o[0] * 0.8 + o[1] * 1.2).backward()
+    for k in range(2):
+        assert abs(float(o[k].detach()) - float(r[k].detach())) <= 1e-5 * abs(float(r[k].detach())) + 1e-9
+    for x, y in zip(ind, ins):
+        assert float((x.grad.cpu().double() - y.grad).norm() / y.grad.norm()) < 1e-5
