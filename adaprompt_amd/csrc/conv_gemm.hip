@@ -1588,11 +1588,35 @@ static int choose_ksplit_halo(int B, int H, int W, int Cin, int Cout) {
 
 // split-K plan: a launch needs >> 256 workgroups to fill the chip; the UNet's 32x32 .. 8x8 levels have few pixel
 // tiles but very long K (up to 9*2560), so split K until there are ~2 workgroups per CU (1 per CU for the big tile).
-static int choose_ksplit(long M, int Cout, int ktiles_total, bool big) {
+// `g_ksplit_scale` (percent, adap_conv_ksplit_scale): the targets are for a launch that has the chip to itself; a caller that keeps
+// two streams busy (the micro-batch lanes) asks for fewer, longer workgroups -- the other stream fills the CUs, and the slab
+// traffic and the reduce launch go away (measured under lanes: 35 % -> -0.2 ms per micro-batch; alone: +0.8 ms).  The workspace
+// query always sizes for 100 %, the largest plan, so sizes cached by a caller stay valid whatever the scale is later.
+static int g_ksplit_scale = -1;
+static int ksplit_scale() {
+    if (g_ksplit_scale < 0) {
+        const char* e = getenv("ADAP_KSPLIT_SCALE");
+        int v = e ? atoi(e) : 100;
+        g_ksplit_scale = v < 0 ? 0 : (v > 100 ? 100 : v);
+    }
+    return g_ksplit_scale;
+}
+
+extern "C" int adap_conv_ksplit_scale(int percent) {
+    const int prev = ksplit_scale();
+    if (percent >= 0) g_ksplit_scale = percent > 100 ? 100 : percent;
+    return prev;
+}
+
+static int choose_ksplit(long M, int Cout, int ktiles_total, bool big, int scale = -1) {
     int bn = choose_bn(Cout);
     int bm = big ? BMB : BM;
     long blocks = ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     long enough = big ? 200 : 384, target = big ? 256 : 512;
+    if (scale < 0) scale = ksplit_scale();
+    if (scale <= 0) return 1;
+    enough = enough * scale / 100;
+    target = target * scale / 100;
     // Few workgroups: besides idle CUs, every workgroup then streams a large slice of (cold, HBM-resident) weights
     // through ONE CU's ~10 B/clk fetch path.  Spread the K loop over more workgroups -- but only for long-K layers:
     // for short K the slab reduce pass costs what the split saves (measured both ways on the UNet's 1x1 layers).
@@ -1609,8 +1633,8 @@ static int choose_ksplit(long M, int Cout, int ktiles_total, bool big) {
 extern "C" long adap_conv2d_workspace_floats(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW) {
     long M = (long)B * Hout * Wout;
     int kt = KH * KW * ((Cin + BK - 1) / BK);
-    int ks0 = choose_ksplit(M, Cout, kt, false);
-    int ks1 = choose_big(M, Cout, kt, 1, 1, 0) ? choose_ksplit(M, Cout, kt, true) : 1;
+    int ks0 = choose_ksplit(M, Cout, kt, false, 100);
+    int ks1 = choose_big(M, Cout, kt, 1, 1, 0) ? choose_ksplit(M, Cout, kt, true, 100) : 1;
     int ks = ks0 > ks1 ? ks0 : ks1;
     if (KH == 3 && KW == 3 && halo_shape(Hout, Wout) != 0 && Cout > 64 && Cin >= 64) {
         int ks2 = choose_ksplit_halo(B, Hout, Wout, Cin, Cout);

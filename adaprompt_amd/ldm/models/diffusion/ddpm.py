@@ -1532,7 +1532,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             lanes = None               # the conditioning side runs inside shared_step: it cannot be kept on lane 0 (see below)
         import contextlib
         from .... import functional as HF
-        side_lane_was = HF.SIDE_LANE
+        side_lane_was, ksplit_was = HF.SIDE_LANE, None
         if lanes is not None:
             lanes.window_start()       # the weights (and whatever else lane 0 has queued so far) as the side lanes' starting point
             # a block's side lane (functional.side_lane: work off its dependency chain on a second stream) fills CUs the chain
@@ -1540,11 +1540,17 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             # stream the five streams outnumber the hardware queues, and the blocks' fork / join events then cost more than the
             # lanes buy (measured: 26.9 vs 26.4 ms per micro-batch; with a hardware queue per stream 34 ms)
             HF.SIDE_LANE = HF.SIDE_LANE and os.environ.get("ADAP_SIDE_LANE_WITH_LANES", "0") == "1"
+            # split K less while two lanes keep the chip busy: the other lane fills the CUs a short grid leaves idle, and the slab
+            # traffic + reduce launches go away (35 % of the lone-stream target: -0.2 ms per micro-batch; alone it costs +0.8 ms)
+            if "ADAP_KSPLIT_SCALE" not in os.environ:
+                ksplit_was = ops._lib.call_long("adap_conv_ksplit_scale", int(os.environ.get("ADAP_LANES_KSPLIT_SCALE", "35")))
         try:
             return self._training_window(batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward,
                                          contextlib, after_backward)
         finally:
             HF.SIDE_LANE = side_lane_was
+            if ksplit_was is not None:
+                ops._lib.call_long("adap_conv_ksplit_scale", ksplit_was)
 
     @staticmethod
     def _window_has_conds(step_kwargs, n):

@@ -45,6 +45,10 @@ int adap_device_info(char* name, int name_cap, int* num_cus, char* arch, int arc
  * (tests/test_parallel_gpu.py: the single-launch GroupNorm next to it).  sink: any device float or NULL. */
 int adap_debug_occupy(int blocks, int threads, int usec, float* sink, void* stream);
 
+/* Split-K planning scale in percent (default 100, clamped to 0..100; 0 = never split): the plan aims at ~2 workgroups per CU for
+ * a launch that has the chip to itself; a caller that keeps two streams busy (the micro-batch lanes) sets a smaller target.
+ * percent < 0 only reads.  Returns the previous value.  adap_conv2d_workspace_floats always sizes for 100. */
+int adap_conv_ksplit_scale(int percent);
 /* ---------------------------------------------------------------------------------------------
  * Contractions: nn.Conv2d 3x3 / 1x1 and nn.Linear on the matrix cores (implicit GEMM).
  * Replaces: ResBlock convs openaimodel.py:205-236,259-279; Downsample :138-164 (stride 2, pad 1);

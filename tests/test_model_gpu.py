@@ -4,6 +4,7 @@ same inputs.  Tolerances: matrix-core operands are bf16 (fp32 accumulate, fp32 r
 fp32 norm / softmax statistics); the north-star bar is <= 1e-3 relative on the eps-prediction
 MSE loss, per-tensor errors are reported and bounded at the bf16 level."""
 import math
+import os
 
 import pytest
 import torch
@@ -560,8 +561,9 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
     ``training_step`` called on the same four micro-batches one after the other: two optimiser steps, regularisers on the
     captured token maps included.  With the GroupNorms held to their two-launch form in both runs (the single-launch exchange
     belongs to one stream per device, so lane 1 always runs two-pass) every kernel is bit-reproducible and the two loops must
-    agree BIT FOR BIT -- losses, Prodigy's d, the parameters.  With the default GroupNorm mode the difference is the
-    summation order of the GroupNorm statistics: <= 1e-4 on the losses (measured 1.5e-5)."""
+    agree BIT FOR BIT -- losses, Prodigy's d, the parameters -- when the window also keeps the lone-stream split-K plans
+    (``ADAP_LANES_KSPLIT_SCALE=100``; by default a window on lanes splits K less, see ``training_window``).  In the shipped mode
+    the difference is the summation order of the GroupNorm statistics and of the K slabs, carried through an optimiser step: <= 3e-4 on the losses (measured 1.1e-4; the north-star bar is 1e-3)."""
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion, MicroBatchLanes
     from adaprompt_amd.ldm.prodigy import Prodigy
     from adaprompt_amd.ldm.util import prodigy_linear_schedule
@@ -598,6 +600,8 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
             mbs.append((batch, kw))
         torch.cuda.synchronize()
         ops.gn_two_pass(two_pass)
+        if two_pass:
+            os.environ["ADAP_LANES_KSPLIT_SCALE"] = "100"
         try:
             losses = []
             if mode == "steps":
@@ -613,6 +617,7 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
             torch.cuda.synchronize()
         finally:
             ops.gn_two_pass(False)
+            os.environ.pop("ADAP_LANES_KSPLIT_SCALE", None)
         assert ld.batch_idx == 4 and opt.device_state()["k"] == 2
         return ([float(x) for x in losses], opt.device_state()["d"], [p.detach().cpu().clone() for p in params])
 
@@ -624,7 +629,7 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
     assert all(math.isfinite(v) for v in la) and float((pa[0] - pb[0]).abs().max()) == 0.0
     lc, dc, pc = run("window", False)                # the shipped mode: lane 0 single-launch GroupNorm, lane 1 two-pass
     for u, v in zip(la, lc):
-        assert abs(u - v) <= 1e-4 * abs(u), (la, lc)
+        assert abs(u - v) <= 3e-4 * abs(u), (la, lc)
     assert abs(da - dc) <= 1e-3 * abs(da)
 
 
