@@ -237,6 +237,9 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
     const long rows = (long)B * N, crows = (long)B * M;
     const bool same_ctx = flags & ADAP_STB_SAME_CTX, compact = flags & ADAP_STB_COMPACT, tok = flags & ADAP_STB_TOKGRAD;
     const bool want_gk = flags & ADAP_STB_WANT_GK, want_gv = flags & ADAP_STB_WANT_GV, g_bf16 = flags & ADAP_STB_G_BF16;
+    // the block's input needs no gradient (the UNet's first transformer block: nothing trainable lies before it): stop after the
+    // cross attention -- the context gradient is all that is wanted; the self attention, proj_in and the GroupNorm are skipped
+    const bool no_gx = flags & ADAP_STB_NO_GX;
     const float scale2 = (float)pow((double)d, -0.5), scale1 = (flags & ADAP_STB_Q1_PRESCALED) ? 0.0f : scale2;
     const void* gop = t[ADAP_STG_GOP];
     const float* g32 = (const float*)t[ADAP_STG_G32];
@@ -259,8 +262,8 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
     float* sk_ws = (float*)t[ADAP_STG_SK_WS];
     float* sk_ws_lane = (float*)t[ADAP_STG_SK_WS_LANE];
     float* at_ws = (float*)t[ADAP_STG_ATTN_WS];
-    ADAP_REQUIRE(gop && g32 && x && gn_stats && tres && ln_stats && qkv1 && obuf && lse && hh && kv2 && gx && gx16 && dkv2 && s32 && s16 &&
-                 gn_ws && at_ws, ADAP_ERR_SHAPE, "stblock_bwd: null tensor");
+    ADAP_REQUIRE(gop && g32 && x && gn_stats && tres && ln_stats && qkv1 && obuf && lse && hh && kv2 && (no_gx || (gx && gx16)) && dkv2 &&
+                 s32 && s16 && gn_ws && at_ws, ADAP_ERR_SHAPE, "stblock_bwd: null tensor");
     ADAP_REQUIRE(!compact || (kv1c && t[ADAP_STG_INV_PERM] && t[ADAP_STG_KEY_COUNT]), ADAP_ERR_SHAPE, "stblock_bwd: key compaction inputs");
     ADAP_REQUIRE(!tok || (t[ADAP_STG_D_TOKMAP] && t[ADAP_STG_TOK_W] && t[ADAP_STG_TOK_PREP] && G >= 1 && G <= 4), ADAP_ERR_SHAPE,
                  "stblock_bwd: token-map gradient inputs");
@@ -309,8 +312,10 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
         ST_TRY(adap_attention_bwd(q2, C, kv2, 2 * C, kv2 + C, 2 * C, nullptr, nullptr, o2, C, go, C, lse2, at_ws, nullptr, dq2, C, nullptr, dkv2,
                                   2 * C, nullptr, dkv2 + C, 2 * C, B, heads, N, M, d, scale2, stream));
     }
-    ST_TRY(lin(dq2, 1, C, wb[ADAP_STWB_Q2], nullptr, nullptr, gn, nullptr, 0, rows, C, C, sk_ws, stream));
-    ST_TRY(adap_layernorm_bwd(gn, C, t1, C, (const float*)wb[ADAP_STWB_LN2_G], l2m, l2r, gt, C, 1, gth, C, rows, C, stream));
+    if (!no_gx) {
+        ST_TRY(lin(dq2, 1, C, wb[ADAP_STWB_Q2], nullptr, nullptr, gn, nullptr, 0, rows, C, C, sk_ws, stream));
+        ST_TRY(adap_layernorm_bwd(gn, C, t1, C, (const float*)wb[ADAP_STWB_LN2_G], l2m, l2r, gt, C, 1, gth, C, rows, C, stream));
+    }
     // the context gradient is an output of the block, not an input of anything in it: beside the self-attention backward
     const bool ctx_grads = want_gk || want_gv;
     if (ctx_grads) {
@@ -326,6 +331,10 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
                 ST_TRY(lin(dkv2 + C, 1, 2 * C, wb[ADAP_STWB_V2], nullptr, nullptr, (float*)t[ADAP_STG_G_CV], nullptr, 0, crows, C, Cctx,
                            sk_side, side));
         }
+    }
+    if (no_gx) {
+        if (ctx_grads && lane) ST_TRY(hand_over(lane, stream));
+        return ADAP_OK;
     }
     // self attention
     ST_TRY(lin(gth, 1, C, wb[ADAP_STWB_OUT1], nullptr, nullptr, nullptr, go, C, rows, C, C, sk_ws, stream));

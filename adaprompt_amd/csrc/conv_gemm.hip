@@ -1558,6 +1558,11 @@ static int choose_bn_halo(int Cout) {
 // the ROUNDS the grid needs on the chip's CUs -- a split that pushes the grid just past one round (280 workgroups on 256
 // CUs) nearly doubles the launch, which is what the old "ceil(256 / tiles)" rule did at 32^2 and 16^2 -- plus, when split,
 // the reduce pass: its own boundary and (splits + 1.5) x the f32 output through L2 at ~5 TB/s.
+static double halo_split_penalty() {          // tuning: extra us charged to a split plan (ADAP_HALO_SPLIT_PENALTY)
+    static const double v = getenv("ADAP_HALO_SPLIT_PENALTY") ? atof(getenv("ADAP_HALO_SPLIT_PENALTY")) : 0.0;
+    return v;
+}
+
 static void choose_halo_plan(int B, int H, int W, int Cin, int Cout, int* bn_out, int* ks_out) {
     const int nchunks = (Cin + BK - 1) / BK;
     const long M = (long)B * H * W;
@@ -1572,7 +1577,7 @@ static void choose_halo_plan(int B, int H, int W, int Cin, int Cout, int* bn_out
             if ((nchunks + per - 1) / per != ks) continue;                 // (the dispatcher would round it to this anyway)
             const long rounds = (blocks * ks + ncu - 1) / ncu;
             double t = 4.0 + (8.0 + per * 9 * step_us) * (double)rounds;
-            if (ks > 1) t += 4.0 + (double)M * Cout * 4.0 * (ks + 1.5) / 5.0e6;
+            if (ks > 1) t += 4.0 + (double)M * Cout * 4.0 * (ks + 1.5) / 5.0e6 + halo_split_penalty();
             if (t < best) { best = t; best_bn = bn; best_ks = ks; }
         }
     }

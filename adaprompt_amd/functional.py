@@ -480,11 +480,12 @@ class ResBlockFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # the frozen SpatialTransformer block issued from one C call each way (csrc/blocks.hip adap_stblock_fwd / _bwd)
 STBLOCK_C = os.environ.get("ADAP_STBLOCK_C", "1") != "0"
-STB_CALLS = [0, 0]                    # forward / backward calls that took the C path (tests assert it is taken)
+STB_CALLS = [0, 0, 0]                  # forward / backward calls that took the C path, backward calls that skipped the input gradient
 _STB_WS = {}
 # include/adaprompt_hip.h: ADAP_STB_* flags
-_STB_SAME_CTX, _STB_COMPACT, _STB_CAPTURE, _STB_Q1_PRESCALED, _STB_TOKGRAD, _STB_WANT_GK, _STB_WANT_GV, _STB_G_BF16 = \
-    1, 2, 4, 8, 16, 32, 64, 128
+_STB_SAME_CTX, _STB_COMPACT, _STB_CAPTURE, _STB_Q1_PRESCALED, _STB_TOKGRAD, _STB_WANT_GK, _STB_WANT_GV, _STB_G_BF16, _STB_NO_GX = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256
+STB_PRUNE_GX = os.environ.get("ADAP_STB_PRUNE_GX", "1") != "0"     # A/B switch: skip the input-gradient half where it is not needed
 
 
 def _stb_sizes(B, N, C, Cctx, M, heads, G):
@@ -730,12 +731,15 @@ class SpatialTransformerFn(torch.autograd.Function):
         kc = ctx.key_compaction
         want_gk = bool(ctx.needs_input_grad[1] or (same_ctx and ctx.needs_input_grad[2]))
         want_gv = bool(not same_ctx and ctx.needs_input_grad[2])
+        # nothing before this block needs a gradient (the UNet's first transformer block when the UNet is frozen): only the
+        # context gradient is wanted, and the call stops after the cross attention
+        no_gx = STB_PRUNE_GX and not ctx.needs_input_grad[0]
         flags = ((_STB_SAME_CTX if same_ctx else 0) | (_STB_COMPACT if kc is not None else 0) | (_STB_TOKGRAD if tok else 0)
                  | (_STB_Q1_PRESCALED if P.get("q1_prescaled") else 0) | (_STB_WANT_GK if want_gk else 0)
-                 | (_STB_WANT_GV if want_gv else 0) | (_STB_G_BF16 if gop.dtype == BF16 else 0))
+                 | (_STB_WANT_GV if want_gv else 0) | (_STB_G_BF16 if gop.dtype == BF16 else 0) | (_STB_NO_GX if no_gx else 0))
         e = torch.empty
-        gx = e(B, H, W, C, device=dev, dtype=torch.float32)
-        gx16 = e(B, H, W, C, device=dev, dtype=BF16)
+        gx = None if no_gx else e(B, H, W, C, device=dev, dtype=torch.float32)
+        gx16 = None if no_gx else e(B, H, W, C, device=dev, dtype=BF16)
         dkv2 = e(B, M, 2 * C, device=dev, dtype=BF16)
         g_ck = e(B, M, Cctx, device=dev, dtype=torch.float32) if want_gk else None
         g_cv = e(B, M, Cctx, device=dev, dtype=torch.float32) if want_gv else None
@@ -756,12 +760,15 @@ class SpatialTransformerFn(torch.autograd.Function):
                                       qkv1.data_ptr(), obuf.data_ptr(), lse.data_ptr(), hh.data_ptr(), dp(kv1c), kv2.data_ptr(),
                                       0 if (km is None or kc is not None) else km.data_ptr(), 0 if kc is None else kc.inv_perm.data_ptr(),
                                       0 if kc is None else kc.count.data_ptr(), dp(g_tokmap) if tok else 0,
-                                      ctx.tok_w.data_ptr() if tok else 0, prep_p if tok else 0, gx.data_ptr(), gx16.data_ptr(),
+                                      ctx.tok_w.data_ptr() if tok else 0, prep_p if tok else 0, dp(gx), dp(gx16),
                                       dkv2.data_ptr(), dp(g_ck), dp(g_cv), p32, s16.data_ptr(), at_p, gn_p, sk_p if sk_n else 0,
                                       (sk_p + 4 * sk_n) if sk_n else 0, ops.gn_sync_buffer(dev))
         cfg = (ctypes.c_int * 11)(B, H, W, C, heads, M, Cctx, flags, G, ldg, ldg32)
         ops._lib.call("adap_stblock_bwd", cfg, bw, tens, 0 if lane is None else lane.side.cuda_stream, ops._stream())
         STB_CALLS[1] += 1
+        if no_gx:
+            STB_CALLS[2] += 1
+            return None, g_ck, g_cv, None, None, None, None, None, None
         return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None
 
     @staticmethod

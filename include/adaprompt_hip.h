@@ -151,7 +151,8 @@ int adap_resblock_bwd(const void* g, int g_dtype, const float* g32, const float*
  *     bwd in : GOP = d out as bf16 (ADAP_STB_G_BF16) or f32, G32 = the f32 gradient (added to dx); the forward's saved tensors;
  *              INV_PERM; D_TOKMAP f32 [B][heads][N][G] + TOK_W + TOK_PREP (adap_attention_tokmap_prep_workspace_floats floats
  *              of scratch) with ADAP_STB_TOKGRAD
- *     bwd out: GX f32 / GX16 bf16 [rows][C]; DKV2 bf16 [B][M][2C]; G_CK (G_CV) f32 [B][M][Cctx] with ADAP_STB_WANT_GK / _GV
+ *     bwd out: GX f32 / GX16 bf16 [rows][C] (not with ADAP_STB_NO_GX); DKV2 bf16 [B][M][2C]; G_CK (G_CV) f32 [B][M][Cctx] with
+ *              ADAP_STB_WANT_GK / _GV
  *     scratch: SCRATCH32 f32 2 * rows * C; SCRATCH16 bf16 17 * rows * C; ATTN_WS max of adap_attention_bwd_workspace_floats over
  *              the self (M = N) and cross attention; GN_WS, SK_WS, SK_WS_LANE, GN_SYNC as above */
 #define ADAP_STB_SAME_CTX 1
@@ -162,6 +163,7 @@ int adap_resblock_bwd(const void* g, int g_dtype, const float* g32, const float*
 #define ADAP_STB_WANT_GK 32
 #define ADAP_STB_WANT_GV 64
 #define ADAP_STB_G_BF16 128
+#define ADAP_STB_NO_GX 256          /* bwd: the block's input needs no gradient -- stop after the cross attention (GX / GX16 may be NULL) */
 enum { ADAP_STW_GN_G, ADAP_STW_GN_B, ADAP_STW_PIN_W, ADAP_STW_PIN_B, ADAP_STW_LN1_G, ADAP_STW_LN1_B, ADAP_STW_QKV, ADAP_STW_OUT1_W,
        ADAP_STW_OUT1_B, ADAP_STW_LN2_G, ADAP_STW_LN2_B, ADAP_STW_Q2, ADAP_STW_KV2, ADAP_STW_V2, ADAP_STW_OUT2_W, ADAP_STW_OUT2_B,
        ADAP_STW_LN3_G, ADAP_STW_LN3_B, ADAP_STW_FF1G_W, ADAP_STW_FF1G_B, ADAP_STW_FF2_W, ADAP_STW_FF2_B, ADAP_STW_POUT_W,

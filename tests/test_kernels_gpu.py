@@ -417,14 +417,14 @@ def test_transformer_block_one_c_call_equals_the_per_op_sequence(B, H, C, heads,
     gt = rnd(B, heads, H * H, G, seed=5)
     blk = st.transformer_blocks[0]
 
-    def run(c_call):
+    def run(c_call, x_grad=True):
         old = HF.STBLOCK_C
         HF.STBLOCK_C = c_call
         try:
             blk.attn2.save_attn_vars = capture
             blk.attn2.token_weights = tok_w if capture else None
             blk.attn2.tokmap_only = capture
-            xi = x.clone().requires_grad_(True)
+            xi = x.clone().requires_grad_(x_grad)
             cki, cvi = ck.clone().requires_grad_(True), cv.clone().requires_grad_(True)
             ctx_arg = (cvi, cki) if split_ctx else cki
             HF.MODEL_STAMP = None
@@ -437,17 +437,28 @@ def test_transformer_block_one_c_call_equals_the_per_op_sequence(B, H, C, heads,
                 roots.append(tm)
                 grads.append(gt)
             torch.autograd.backward(roots, grads)
-            gx16 = HF._operand(xi.grad)           # (the bf16 side copy the block left for its predecessor)
             torch.cuda.synchronize()
+            if not x_grad:
+                assert xi.grad is None
+                return (out.detach(), None if tm is None else tm.detach().clone(), None, None, cki.grad.detach().clone(),
+                        None if cvi.grad is None else cvi.grad.detach().clone())
+            gx16 = HF._operand(xi.grad)           # (the bf16 side copy the block left for its predecessor)
             return (out.detach(), None if tm is None else tm.detach().clone(), xi.grad.detach().clone(),
                     None if gx16 is xi.grad else gx16.clone(), cki.grad.detach().clone(),
                     None if cvi.grad is None else cvi.grad.detach().clone())
         finally:
             HF.STBLOCK_C = old
+    names_all = ("out", "tokmap", "gx", "gx16", "g_ck", "g_cv")
     a = run(False)
     n0 = list(HF.STB_CALLS)
     b = run(True)
-    assert HF.STB_CALLS == [n0[0] + 1, n0[1] + 1], "the C path was not taken"
+    assert HF.STB_CALLS == [n0[0] + 1, n0[1] + 1, n0[2]], "the C path was not taken"
+    # the block's input needs no gradient (the UNet's first transformer block): the call stops after the cross attention
+    # (ADAP_STB_NO_GX) -- same output, same token maps, bit-identical context gradients
+    c = run(True, x_grad=False)
+    assert HF.STB_CALLS == [n0[0] + 2, n0[1] + 2, n0[2] + 1], "the pruned backward was not taken"
+    for i in (0, 1, 4, 5):
+        assert (b[i] is None) == (c[i] is None) and (b[i] is None or torch.equal(b[i], c[i])), names_all[i]
     names = ("out", "tokmap", "gx", "gx16", "g_ck", "g_cv")
     for n, u, v in zip(names, a, b):
         assert (u is None) == (v is None), n
