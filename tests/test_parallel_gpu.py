@@ -162,6 +162,8 @@ def test_groupnorm_beside_a_resident_collective_kernel():
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 8
                 table.append(f"{H}x{H}x{C} {which} (variant {variant}) beside {blocks}: {us:.0f} us")
-                assert us * 8 < RESIDENT_US / 4, table[-1]          # not held up for anything like the resident kernel's 4 ms
+                # not held up for anything like the resident kernel's 4 ms (a call that waited for it would make the 8 cost >= 4 ms;
+                # the two-launch 960-channel backward, 190 MB of traffic on 3/4 of the CUs, has been seen at 184 us)
+                assert us * 8 < RESIDENT_US / 2, table[-1]
     print("; ".join(table))
     assert not ops.gn_sync_poisoned()
