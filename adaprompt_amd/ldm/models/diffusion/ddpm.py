@@ -1532,7 +1532,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             lanes = None               # the conditioning side runs inside shared_step: it cannot be kept on lane 0 (see below)
         import contextlib
         from .... import functional as HF
-        side_lane_was, ksplit_was = HF.SIDE_LANE, None
+        side_lane_was, ksplit_was, gn_owner_was = HF.SIDE_LANE, None, None
         if lanes is not None:
             lanes.window_start()       # the weights (and whatever else lane 0 has queued so far) as the side lanes' starting point
             # a block's side lane (functional.side_lane: work off its dependency chain on a second stream) fills CUs the chain
@@ -1544,6 +1544,10 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             # traffic + reduce launches go away (35 % of the lone-stream target: -0.2 ms per micro-batch; alone it costs +0.8 ms)
             if "ADAP_KSPLIT_SCALE" not in os.environ:
                 ksplit_was = ops._lib.call_long("adap_conv_ksplit_scale", int(os.environ.get("ADAP_LANES_KSPLIT_SCALE", "35")))
+            gn_lane = int(os.environ.get("ADAP_GN_OWNER_LANE", "0"))
+            if gn_lane and gn_lane < len(lanes.streams):
+                gn_owner_was = (lanes.main.device, ops.gn_single_launch_stream(lanes.main.device))
+                ops.set_gn_single_launch_stream(lanes.main.device, lanes.streams[gn_lane].cuda_stream)
         try:
             return self._training_window(batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward,
                                          contextlib, after_backward)
@@ -1551,6 +1555,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             HF.SIDE_LANE = side_lane_was
             if ksplit_was is not None:
                 ops._lib.call_long("adap_conv_ksplit_scale", ksplit_was)
+            if gn_owner_was is not None:
+                ops.set_gn_single_launch_stream(*gn_owner_was)
 
     @staticmethod
     def _window_has_conds(step_kwargs, n):

@@ -330,6 +330,14 @@ def set_gn_single_launch_stream(device, raw_stream):
     _GN_SYNC_STREAM[device.index] = raw_stream
 
 
+def gn_single_launch_stream(device):
+    """the raw stream that owns the single-launch GroupNorm path on ``device`` (the default stream unless set)."""
+    owner = _GN_SYNC_STREAM.get(device.index)
+    if owner is None:
+        owner = _GN_SYNC_STREAM[device.index] = torch.cuda.default_stream(device).cuda_stream
+    return owner
+
+
 def gn_sync_buffer(device):
     """-> data pointer of the zero-initialised arrival-counter buffer of the single-launch GroupNorm kernels, or 0.
 

@@ -32,12 +32,16 @@ def submit(i):
 for i in range(4):
     submit(i)
 rows = []
+hrows = []
 
 
 def window(i, record):
     ev = {}
 
+    hs = {}
+
     def mark(name):
+        hs[name] = time.perf_counter()                # host clock at the moment the mark is ISSUED
         if record:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -56,6 +60,7 @@ def window(i, record):
     host = 1e3 * (time.perf_counter() - th0)
     if record:
         rows.append((ev, host))
+        hrows.append({n: 1e3 * (t - th0) for n, t in hs.items()})
 
 
 for w in range(3):
@@ -73,3 +78,5 @@ for ev, _ in rows:
         acc[n] += ev["start"].elapsed_time(ev[n])
 print("GPU time since the window's start (ms, mean of 8 windows):", {n: round(acc[n] / len(rows), 2) for n in names})
 print("host issue time per window (ms):", round(sum(h for _, h in rows) / len(rows), 2))
+print("host clock when each mark was issued (ms since the window call, mean):",
+      {n: round(sum(h[n] for h in hrows) / len(hrows), 2) for n in ["start"] + names})
