@@ -48,3 +48,22 @@ def test_product_package_does_not_import_oracle():
     start = bench_src.index("def cpu_baseline(")
     end = bench_src.index("\ndef ", start + 1)
     assert len(uses) == 1 and start < uses[0] < end, "bench.py may use the oracle inside cpu_baseline() only"
+
+
+def test_ksplit_scale_switch_and_workspace_query_sized_for_the_largest_plan():
+    """``adap_conv_ksplit_scale`` (the micro-batch lanes lower the split-K target while two streams keep the chip busy): returns
+    the previous value, clamps to 0..100, a negative argument only reads -- and ``adap_conv2d_workspace_floats`` does not follow
+    it (always the 100 % plan), so sizes a caller cached stay valid whatever the scale becomes.  Pure host code: no GPU needed."""
+    lib = _lib.load()
+    was = lib.adap_conv_ksplit_scale(-1)
+    try:
+        assert 0 <= was <= 100
+        q = lambda: lib.adap_conv2d_workspace_floats(1, 1024, 1, 5120, 1280, 1, 1)      # FF2 at the 16 x 16 level: long K, few tiles
+        lib.adap_conv_ksplit_scale(100)
+        full = q()
+        assert full > 0 and full % (1024 * 1280) == 0 and full // (1024 * 1280) >= 2
+        assert lib.adap_conv_ksplit_scale(35) == 100 and q() == full
+        assert lib.adap_conv_ksplit_scale(0) == 35 and q() == full
+        assert lib.adap_conv_ksplit_scale(1000) == 0 and lib.adap_conv_ksplit_scale(-1) == 100
+    finally:
+        lib.adap_conv_ksplit_scale(was)
