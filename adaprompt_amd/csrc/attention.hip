@@ -1831,21 +1831,31 @@ __global__ __launch_bounds__(256) void attn_capture_kernel(const uint16_t* __res
 // walks all M keys while most of the workgroup idles (G d = 80 at d = 40): the keys are dealt over KS thread slices instead
 // (item (s, p) sums the keys m = s, s + KS, ...) and the slices are summed in a fixed order -- measured 9.4 -> 5.0 us for the
 // kw kernel and 15.5 -> 11.4 us for the forward at 64 x 64 (tools/microbench/tokmap_family.hip); KS = 1 is the plain walk.
-__device__ __forceinline__ void tokmap_kw_phase(float* part, float* out_lds, const float* __restrict__ w,
+// The keys' head slice [M][d] bf16 and the weights [M][G] are staged in LDS first (`stage`: M d bf16 + M G floats, dynamic): read
+// straight from memory every thread walked the M keys with one 2-byte load per key -- a chain of ~10 cold-memory latencies
+// (20-50 us inside the training step at d = 160, where G d = 320 outputs leave no slices to deal the keys over); staged, the
+// whole slice arrives in one round of 8-byte loads.
+__device__ __forceinline__ void tokmap_kw_phase(float* part, float* out_lds, char* stage, const float* __restrict__ w,
                                                 const uint16_t* __restrict__ k, long ldk, int b, int head, int M, int d, int G,
                                                 float scale) {
+    uint16_t* sK = (uint16_t*)stage;                            // [M][d]
+    float* sW = (float*)(stage + (((size_t)M * d * 2 + 15) & ~(size_t)15));   // [M][G]
+    const int cpr = d >> 2;                                     // 8-byte chunks per key row (d % 4 == 0, rows 8-byte aligned: callers)
+    for (int idx = threadIdx.x; idx < M * cpr; idx += 256) {
+        const int m = idx / cpr, c4 = idx - m * cpr;
+        *(uint2*)(sK + m * d + 4 * c4) = *(const uint2*)(k + ((size_t)b * M + m) * ldk + head * d + 4 * c4);
+    }
+    for (int idx = threadIdx.x; idx < M * G; idx += 256) sW[idx] = w[(size_t)b * M * G + idx];
+    __syncthreads();
     const int P = G * d;
     int KS = 512 / P;
     KS = KS < 1 ? 1 : (KS > 8 ? 8 : KS);
     if (KS == 1) {
         for (int idx = threadIdx.x; idx < P; idx += 256) {
             const int g = idx / d, c = idx - g * d;
-            // branch-free and unrolled: a skip of the zero weights would chain the keys' loads one behind the other
             float a = 0.f;
-            const float* wp = w + (size_t)b * M * G + g;
-            const uint16_t* kp = k + (size_t)b * M * ldk + head * d + c;
 #pragma unroll 8
-            for (int m = 0; m < M; ++m) a = fmaf(wp[(size_t)m * G], bf16_to_f32(kp[(size_t)m * ldk]), a);
+            for (int m = 0; m < M; ++m) a = fmaf(sW[m * G + g], bf16_to_f32(sK[m * d + c]), a);
             out_lds[idx] = a * scale;
         }
         __syncthreads();
@@ -1854,8 +1864,7 @@ __device__ __forceinline__ void tokmap_kw_phase(float* part, float* out_lds, con
     for (int idx = threadIdx.x; idx < P * KS; idx += 256) {
         const int s = idx / P, p = idx - s * P, g = p / d, c = p - g * d;
         float a = 0.f;
-        for (int m = s; m < M; m += KS)
-            a = fmaf(w[((size_t)b * M + m) * G + g], bf16_to_f32(k[((size_t)b * M + m) * ldk + head * d + c]), a);
+        for (int m = s; m < M; m += KS) a = fmaf(sW[m * G + g], bf16_to_f32(sK[m * d + c]), a);
         part[idx] = a;
     }
     __syncthreads();
@@ -1866,6 +1875,11 @@ __device__ __forceinline__ void tokmap_kw_phase(float* part, float* out_lds, con
     }
     __syncthreads();
 }
+static size_t tokmap_kw_lds(int M, int d, int G) { return (((size_t)M * d * 2 + 15) & ~(size_t)15) + (size_t)M * G * 4; }
+template <typename K>
+static void tokmap_allow_lds(K kernel, size_t bytes) {          // beyond the 64 KB a kernel gets without asking (M = 192, d = 160)
+    if (bytes > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 
 __global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __restrict__ q, long ldq,
                                                               const uint16_t* __restrict__ k, long ldk,
@@ -1873,9 +1887,10 @@ __global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __
                                                               int G, int H, int N, int M, int d, float scale) {
     __shared__ float sKW[TOK_MAXP];                 // [G <= 4][d <= 160]
     __shared__ float sPart[512];                    // the key slices' partial sums (G d <= 256: tokmap_kw_phase)
+    extern __shared__ __attribute__((aligned(16))) char tok_stage[];
     const int tid = threadIdx.x;
     const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
-    tokmap_kw_phase(sPart, sKW, tok_w, k, ldk, b, head, M, d, G, scale);
+    tokmap_kw_phase(sPart, sKW, tok_stage, tok_w, k, ldk, b, head, M, d, G, scale);
     const int n = blockIdx.x * TOKF_ROWS + tid;
     if (n >= N) return;
     const uint16_t* qr = q + ((size_t)b * N + n) * ldq + head * d;
@@ -1905,8 +1920,10 @@ extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, lo
     ADAP_REQUIRE(M >= 1 && M <= 192, ADAP_ERR_UNSUPPORTED, "attention_capture: M=%d (cross-attention only, <= 192)", M);
     ADAP_REQUIRE(d >= 1 && d <= 160, ADAP_ERR_UNSUPPORTED, "attention_capture: d=%d", d);
     ADAP_REQUIRE(d % 4 == 0, ADAP_ERR_UNSUPPORTED, "attention_capture: d must be a multiple of 4");
-    if (tokmap && !attnscore && !attn && !q_scaled && ldq % 4 == 0 && ((uintptr_t)q & 7) == 0 && (long)B * H <= 65535) {
-        hipLaunchKernelGGL(attn_tokmap_fwd_kernel, dim3((N + TOKF_ROWS - 1) / TOKF_ROWS, B * H), dim3(256), 0,
+    if (tokmap && !attnscore && !attn && !q_scaled && ldq % 4 == 0 && ((uintptr_t)q & 7) == 0 && ldk % 4 == 0 &&
+        ((uintptr_t)k & 7) == 0 && (long)B * H <= 65535) {
+        tokmap_allow_lds(attn_tokmap_fwd_kernel, tokmap_kw_lds(M, d, G));
+        hipLaunchKernelGGL(attn_tokmap_fwd_kernel, dim3((N + TOKF_ROWS - 1) / TOKF_ROWS, B * H), dim3(256), tokmap_kw_lds(M, d, G),
                            (hipStream_t)stream, (const uint16_t*)q, ldq, (const uint16_t*)k, ldk, tok_w, tokmap, G, H, N, M, d,
                            scale);
         return adap_check_launch("attention_capture");
@@ -2067,8 +2084,9 @@ __global__ __launch_bounds__(256) void attn_tokmap_kw_kernel(const float* __rest
                                                              long ldk, float* __restrict__ kw, int H, int M, int d, int G) {
     __shared__ float sKW[TOK_MAXP];
     __shared__ float sPart[512];
+    extern __shared__ __attribute__((aligned(16))) char tok_stage[];
     const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
-    tokmap_kw_phase(sPart, sKW, tok_w, k, ldk, b, head, M, d, G, 1.f);
+    tokmap_kw_phase(sPart, sKW, tok_stage, tok_w, k, ldk, b, head, M, d, G, 1.f);
     for (int p = threadIdx.x; p < G * d; p += 256) kw[(size_t)bh * G * d + p] = sKW[p];
 }
 
@@ -2127,16 +2145,30 @@ __global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __
     if (rl < RL) {
         const float* dtb = dt + (((size_t)b * H + head) * N + n0) * G;
         const uint16_t* qb = q + ((size_t)b * N + n0) * ldq + head * d + 8 * o;
-        for (int r = rl; r < rows; r += RL) {
-            float x[8];
-            unpack_bf16x8(*(const uint4*)(qb + (size_t)r * ldq), x);
+        // four rows' loads are issued before the first is used: at d = 160 a lane walks 11 rows, and one load per trip was a
+        // chain of 11 memory latencies (q is cold in the backward)
+        for (int r0 = rl; r0 < rows; r0 += 4 * RL) {
+            uint4 raw[4];
+            float t[4][TOK_MAXG];
 #pragma unroll
-            for (int g = 0; g < TOK_MAXG; ++g)
-                if (g < G) {
-                    const float t = dtb[(size_t)r * G + g];
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u * RL;
+                const bool ok = r < rows;
+                raw[u] = ok ? *(const uint4*)(qb + (size_t)r * ldq) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(t, x[e], acc[g][e]);
-                }
+                for (int g = 0; g < TOK_MAXG; ++g) t[u][g] = (ok && g < G) ? dtb[(size_t)r * G + g] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float x[8];
+                unpack_bf16x8(raw[u], x);
+#pragma unroll
+                for (int g = 0; g < TOK_MAXG; ++g)
+                    if (g < G) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(t[u][g], x[e], acc[g][e]);
+                    }
+            }
         }
 #pragma unroll
         for (int g = 0; g < TOK_MAXG; ++g)
@@ -2191,6 +2223,7 @@ __global__ __launch_bounds__(256) void attn_tokmap_gq_reduce_kernel(const float*
     const long bh = i / Gd;
     const int e = (int)(i - bh * Gd);
     float a = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nchunks; ++k) a += part[(bh * nchunks + k) * Gd + e];
     gq[i] = a;
 }
@@ -2215,7 +2248,10 @@ extern "C" int adap_attention_tokmap_prep(const float* d_tokmap, const float* to
     float* kw = workspace;
     float* gq = workspace + bhgd;
     float* part = workspace + 2 * bhgd;
-    hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), 0, s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
+    ADAP_REQUIRE(d % 4 == 0 && ldk % 4 == 0 && ((uintptr_t)k & 7) == 0, ADAP_ERR_ALIGN, "attention_tokmap: k rows must be 8-byte aligned");
+    ADAP_REQUIRE(tokmap_kw_lds(M, d, G) <= 150 * 1024, ADAP_ERR_UNSUPPORTED, "attention_tokmap: M=%d keys x d=%d do not fit the LDS stage", M, d);
+    tokmap_allow_lds(attn_tokmap_kw_kernel, tokmap_kw_lds(M, d, G));
+    hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), tokmap_kw_lds(M, d, G), s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
     ADAP_REQUIRE(ldq % 8 == 0 && ((uintptr_t)q % 16) == 0, ADAP_ERR_ALIGN, "attention_tokmap_prep: q alignment");
     hipLaunchKernelGGL(attn_tokmap_bwd_gq_kernel, dim3(nchunks, B * H), dim3(256), tokmap_gq_lds(d, G), s, d_tokmap, (const uint16_t*)q,
                        ldq, part, B, H, N, d, G);
@@ -2239,7 +2275,10 @@ extern "C" int adap_attention_tokmap_bwd(const float* d_tokmap, const float* tok
     const int nchunks = (N + CAPB_ROWS - 1) / CAPB_ROWS;
     ADAP_REQUIRE(d % 8 == 0 && lddq % 8 == 0 && ((uintptr_t)dq16 % 16) == 0, ADAP_ERR_ALIGN, "attention_tokmap_bwd: dq alignment");
     float* kw = workspace + (size_t)B * H * nchunks * G * d;
-    hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), 0, s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
+    ADAP_REQUIRE(d % 4 == 0 && ldk % 4 == 0 && ((uintptr_t)k & 7) == 0, ADAP_ERR_ALIGN, "attention_tokmap: k rows must be 8-byte aligned");
+    ADAP_REQUIRE(tokmap_kw_lds(M, d, G) <= 150 * 1024, ADAP_ERR_UNSUPPORTED, "attention_tokmap: M=%d keys x d=%d do not fit the LDS stage", M, d);
+    tokmap_allow_lds(attn_tokmap_kw_kernel, tokmap_kw_lds(M, d, G));
+    hipLaunchKernelGGL(attn_tokmap_kw_kernel, dim3(B * H), dim3(256), tokmap_kw_lds(M, d, G), s, tok_w, (const uint16_t*)k, ldk, kw, H, M, d, G);
     {
         const long tot = (long)B * N * H * (d / 8);
         long g = (tot + 255) / 256;
