@@ -1429,7 +1429,15 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnParams p) {
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int sp = 0; sp < p.qsplit; ++sp) {
+            int sp = 0;
+            for (; sp + 3 < p.qsplit; sp += 4) {          // four partials requested before the first is added (same order of sums)
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(p.part + (((size_t)(sp + u) * 2 + which) * rows + row) * C + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; sp < p.qsplit; ++sp) {
                 float4 v = *(const float4*)(p.part + (((size_t)sp * 2 + which) * rows + row) * C + c);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }

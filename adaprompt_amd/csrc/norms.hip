@@ -270,14 +270,22 @@ __global__ __launch_bounds__(1024) void gn_finish_kernel(const float* __restrict
     const int tid = threadIdx.x, b = blockIdx.x;
     const int v = tid & 63, part = tid >> 6;                        // v = group * 2 + statistic
     const float* pp = partial + (size_t)b * nchunks * 64 + v;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;                   // four loads in flight per thread (a fixed order all the same)
+    // sixteen loads in flight per thread (a fixed order all the same): with four, the 4096 records per image of the 512 x 512
+    // level were 64 dependent rounds of memory latency for the 4 workgroups of this launch
+    double a[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = 0.0;
     int c = part;
-    for (; c + 48 < nchunks; c += 64) {
-        const float x0 = pp[(size_t)c * 64], x1 = pp[(size_t)(c + 16) * 64], x2 = pp[(size_t)(c + 32) * 64], x3 = pp[(size_t)(c + 48) * 64];
-        a0 += (double)x0; a1 += (double)x1; a2 += (double)x2; a3 += (double)x3;
+    for (; c + 240 < nchunks; c += 256) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = pp[(size_t)(c + 16 * u) * 64];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] += (double)x[u];
     }
-    for (; c < nchunks; c += 16) a0 += (double)pp[(size_t)c * 64];
-    acc[part][v] = (a0 + a1) + (a2 + a3);
+    for (; c < nchunks; c += 16) a[0] += (double)pp[(size_t)c * 64];
+    acc[part][v] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+                   (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
     __syncthreads();
     if (tid < GN_G) {
         double su = 0.0, sq = 0.0;
