@@ -1883,7 +1883,10 @@ __device__ __forceinline__ void tokmap_kw_phase(float* part, float* out_lds, cha
     }
     __syncthreads();
 }
-static size_t tokmap_kw_lds(int M, int d, int G) { return (((size_t)M * d * 2 + 15) & ~(size_t)15) + (size_t)M * G * 4; }
+static size_t tokmap_kw_lds(int M, int d, int G) {          // (at least 4 KB: the forward kernel reuses the area for 256 x G row partials)
+    const size_t n = (((size_t)M * d * 2 + 15) & ~(size_t)15) + (size_t)M * G * 4;
+    return n < 4096 ? 4096 : n;
+}
 template <typename K>
 static void tokmap_allow_lds(K kernel, size_t bytes) {          // beyond the 64 KB a kernel gets without asking (M = 192, d = 160)
     if (bytes > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1903,16 +1906,26 @@ __global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __
     if (n >= N) return;
     const uint16_t* qr = q + ((size_t)b * N + n) * ldq + head * d;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < d; c += 4) {                // d % 4 == 0 and 8-byte aligned rows: checked by the caller
-        const uint2 raw = *(const uint2*)(qr + c);
-        const float x0 = __builtin_bit_cast(float, raw.x << 16), x1 = __builtin_bit_cast(float, raw.x & 0xffff0000u);
-        const float x2 = __builtin_bit_cast(float, raw.y << 16), x3 = __builtin_bit_cast(float, raw.y & 0xffff0000u);
+    // eight of the row's 8-byte chunks are requested before the first is used: one load per trip was a chain of d / 4 = 10 .. 40
+    // cold-memory latencies per row inside the step (d % 4 == 0 and 8-byte aligned rows: checked by the caller)
+    for (int c0 = 0; c0 < d; c0 += 32) {
+        uint2 raw[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (g < G) {
-                const float* kw = sKW + g * d + c;  // the same address in every lane: an LDS broadcast
-                acc[g] += (x0 * kw[0] + x1 * kw[1]) + (x2 * kw[2] + x3 * kw[3]);
+        for (int u = 0; u < 8; ++u) raw[u] = c0 + 4 * u < d ? *(const uint2*)(qr + c0 + 4 * u) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + 4 * u;
+            if (c < d) {
+                const float x0 = __builtin_bit_cast(float, raw[u].x << 16), x1 = __builtin_bit_cast(float, raw[u].x & 0xffff0000u);
+                const float x2 = __builtin_bit_cast(float, raw[u].y << 16), x3 = __builtin_bit_cast(float, raw[u].y & 0xffff0000u);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g < G) {
+                        const float* kw = sKW + g * d + c;  // the same address in every lane: an LDS broadcast
+                        acc[g] += (x0 * kw[0] + x1 * kw[1]) + (x2 * kw[2] + x3 * kw[3]);
+                    }
             }
+        }
     }
     float* out = tokmap + ((size_t)bh * N + n) * G;
 #pragma unroll
