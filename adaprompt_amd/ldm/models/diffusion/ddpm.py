@@ -1015,9 +1015,24 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         return t
 
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
-    def shared_step(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
-                    num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
-                    trim_to_half_batch=True, batched_student=True, teacher_out=None, anneal_t=False):
+    def shared_step(self, batch, **kwargs):
+        """One micro-batch's forward half -> (loss, grad, model_output, aux); arguments: ``_shared_step_gen``.  The plain recon
+        iteration's UNet pass is a REQUEST of that generator (``x_start, noise, t, cond`` -> ``guided_denoise``), served here at
+        once; ``training_window`` serves the requests of a window's micro-batches with ONE batched pass instead."""
+        gen = self._shared_step_gen(batch, **kwargs)
+        try:
+            req = next(gen)
+        except StopIteration as done:                  # an iteration that runs its own passes (distillation, stage 2)
+            return done.value
+        try:
+            gen.send(self.guided_denoise(*req))
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError("shared_step: a second denoising request")
+
+    def _shared_step_gen(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
+                         num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
+                         trim_to_half_batch=True, batched_student=True, teacher_out=None, anneal_t=False):
         """``x_start``: a latent already encoded for this batch (e.g. by ``LatentPrefetcher`` on a side stream while
         the previous micro-batch's UNet pass was running); otherwise the batch is encoded here.
 
@@ -1110,7 +1125,9 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if FUSED_REG_LOSSES and CAPTURE_TOKEN_MAPS_ONLY and extra_info.get("subj_indices") is not None:
             # the regularisers of this iteration read the distillation layers through their token maps (recon_regularizers)
             extra_info["capture_token_maps_only"] = True
-        model_output, x_noisy = self.guided_denoise(x_start, noise, t, (c_emb, c_in, extra_info))
+        # the UNet pass: a request to whoever drives this generator (shared_step: guided_denoise at once; training_window: the
+        # window's micro-batches in one batched pass, this one's captures sliced back into ITS extra_info)
+        model_output, x_noisy = yield (x_start, noise, t, (c_emb, c_in, extra_info))
         loss, grad = self.calc_recon_loss(model_output, noise, img_mask, fg_mask, 1.0, self.bg_pixel_weight)
         aux = {"x_start": x_start, "x_noisy": x_noisy, "t": t, "extra_info": extra_info}
         reg, parts = self.recon_regularizers(extra_info, B, do_static_prompt_delta_reg=do_static_delta, fg_mask=fg_mask,
@@ -1272,6 +1289,12 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         """``manual_backward(loss)`` (ddpm.py:595) for the pair shared_step returns: the masked-MSE gradient enters at
         ``model_output`` (computed by the loss kernel, not by autograd) and the regularisers' scalar at its own root, in
         ONE pass over the tape, so the UNet's backward runs once and receives the attnscore gradients on the way."""
+        roots, grads = LatentDiffusion._backward_roots(model_output, grad, aux)
+        if roots:
+            torch.autograd.backward(roots, grads)
+
+    @staticmethod
+    def _backward_roots(model_output, grad, aux=None):
         roots, grads = [], []
         if model_output is None:                    # a compositional iteration: the whole loss is the auxiliary scalar
             pass
@@ -1293,8 +1316,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                 if o.requires_grad:
                     roots.append(o)
                     grads.append(g)
-        if roots:
-            torch.autograd.backward(roots, grads)
+        return roots, grads
 
     def ensure_empty_contexts(self):
         """ddpm.py:827-835 (``on_train_batch_start`` at global step 0): the empty prompt's context for the guidance passes of
@@ -1509,7 +1531,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             scheduler.step()                               # ddpm.py:629-633
 
     def training_window(self, batches, optimizer, reducer=None, scheduler=None, lanes=None, auto_iteration=None,
-                        step_kwargs=None, after_forward=None, after_backward=None):
+                        step_kwargs=None, after_forward=None, after_backward=None, fuse=None):
         """The micro-batches of ONE accumulation window (``manual_accumulate_grad_batches`` of them: ddpm.py:591-633
         accumulates their gradients and steps once) issued forward-first -- F0 F1 .. B0 B1 .. step -- and, with ``lanes``
         (``MicroBatchLanes``), each on its own HIP stream.  All of a window's micro-batches read the SAME weights, so they
@@ -1522,6 +1544,13 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         ``step_kwargs``: one dict per micro-batch, one for all, or a callable ``k -> dict`` evaluated on the micro-batch's
         lane right before its forward (RNG draws, a prefetched latent); ``after_forward(k)`` / ``after_backward(k)``: called on
         the lane once its forward / backward is issued (e.g. to submit the next VAE encode to a ``LatentPrefetcher``).
+        ``fuse``: a window whose micro-batches are all plain recon iterations goes through the UNet as ONE batched pass
+        (``_training_window_fused``: the same per-micro-batch fronts, losses and gradients; one forward, one backward at n times
+        the batch).  Default (None): when the window cannot run on lanes -- no ``lanes`` given, or the conditioning side runs
+        inside ``shared_step`` -- since a batch of 8 on one stream beats two batches of 4 one after the other (166 vs 130 images/s);
+        with lanes available the lanes win (the hook's forward / backward and the losses of the two micro-batches then overlap the
+        other lane instead of queueing behind one stream: 24.9 vs 26.3 ms per micro-batch), ``ADAP_WINDOW_FUSE=1`` or
+        ``fuse=True`` forces it.  Windows that start with a distillation / compositional micro-batch always take the lanes path.
         -> [(loss, aux), ...]"""
         n = len(batches)
         assert n == self.manual_accumulate_grad_batches and self.batch_idx % n == 0, \
@@ -1530,6 +1559,16 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             lanes = None               # the UNet's own gradients are written through raw pointers during the whole backward
         if lanes is not None and self.cond_fn is None and not self._window_has_conds(step_kwargs, len(batches)):
             lanes = None               # the conditioning side runs inside shared_step: it cannot be kept on lane 0 (see below)
+        if fuse is None:
+            env = os.environ.get("ADAP_WINDOW_FUSE")
+            fuse = (lanes is None and torch.cuda.is_available()) if env is None else env != "0"
+        pre_kws = None
+        if fuse and n >= 2 and not any(p.requires_grad for p in self.model.parameters()):
+            done = self._training_window_fused(batches, optimizer, reducer, scheduler, auto_iteration, step_kwargs, after_forward,
+                                               after_backward)
+            if not isinstance(done, dict):
+                return done
+            pre_kws = done                 # {0: kwargs of micro-batch 0}: it is not a plain recon iteration -- the lanes take the window
         import contextlib
         from .... import functional as HF
         side_lane_was, ksplit_was, gn_owner_was = HF.SIDE_LANE, None, None
@@ -1550,7 +1589,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                 ops.set_gn_single_launch_stream(lanes.main.device, lanes.streams[gn_lane].cuda_stream)
         try:
             return self._training_window(batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward,
-                                         contextlib, after_backward)
+                                         contextlib, after_backward, pre_kws)
         finally:
             HF.SIDE_LANE = side_lane_was
             if ksplit_was is not None:
@@ -1565,8 +1604,145 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         kws = step_kwargs if isinstance(step_kwargs, (list, tuple)) else [step_kwargs] * n
         return all(isinstance(kw, dict) and kw.get("cond") is not None for kw in kws)
 
+    def _window_kwargs(self, k, step_kwargs, auto_iteration, cond=None):
+        """micro-batch k's ``shared_step`` arguments: the caller's (a callable is evaluated NOW: RNG draws, a prefetched latent),
+        then the iteration-type draw -- once per micro-batch, in order, as in the sequential loop."""
+        kw = dict(step_kwargs(k) if callable(step_kwargs) else
+                  step_kwargs[k] if isinstance(step_kwargs, (list, tuple)) else (step_kwargs or {}))
+        if cond is not None and kw.get("cond") is None:
+            kw["cond"] = cond
+        if auto_iteration is not None:
+            self._iteration_preamble(auto_iteration, kw)
+        return kw
+
+    @staticmethod
+    def _is_plain_recon(kw):
+        return (not kw.get("use_arc2face_as_target") and int(kw.get("num_denoising_steps", 1) or 1) == 1
+                and kw.get("teacher_out") is None)
+
+    _FUSE_FLAGS = ("use_layerwise_context", "use_conv_attn_kernel_size", "iter_type", "is_training", "capture_distill_attn",
+                   "capture_token_maps_only", "debug_attn")
+
+    def _denoise_fusable(self, reqs):
+        """can these ``guided_denoise`` requests (x_start, noise, t, (c_emb, c_in, extra_info)) go through the UNet as one batch?"""
+        x0, c0, e0 = reqs[0][0], reqs[0][3][0], reqs[0][3][2]
+        for x, _n, _t, (c, _ci, ei) in reqs:
+            if not (torch.is_tensor(c) and torch.is_tensor(c0)) or c.shape[1:] != c0.shape[1:] or c.dtype != c0.dtype:
+                return False
+            if x.shape[1:] != x0.shape[1:] or ei.get("placeholder2indices") is not None:
+                return False
+            if any(ei.get(f) != e0.get(f) for f in self._FUSE_FLAGS):
+                return False
+            if any((ei.get(f) is None) != (e0.get(f) is None) for f in ("img_mask", "subj_indices", "bg_indices")):
+                return False
+        return True
+
+    def _denoise_fused(self, reqs):
+        """the requests' UNet passes as ONE: inputs concatenated along the batch dim (a layerwise context keeps an instance's 16
+        layers together, so the contexts concatenate too), the (instance, token) index sets shifted onto the merged batch, and what
+        the UNet captured sliced back into each request's own ``extra_info`` (views: their gradients meet in the one tape).
+        -> [(model_output, x_noisy), ...] per request."""
+        sizes = [r[0].shape[0] for r in reqs]
+        offs = [sum(sizes[:k]) for k in range(len(sizes))]
+        eis = [r[3][2] for r in reqs]
+        ei = {f: eis[0][f] for f in self._FUSE_FLAGS if f in eis[0]}
+        ei["placeholder2indices"] = None
+        if eis[0].get("img_mask") is not None:
+            ei["img_mask"] = torch.cat([e["img_mask"] for e in eis])
+        for f in ("subj_indices", "bg_indices"):
+            if eis[0].get(f) is not None:
+                ei[f] = self._merged_indices([e[f] for e in eis], offs)
+        c_ins = [r[3][1] for r in reqs]
+        c_in = sum((list(c) for c in c_ins), []) if all(isinstance(c, (list, tuple)) for c in c_ins) else c_ins[0]
+        out, x_noisy = self.guided_denoise(torch.cat([r[0] for r in reqs]), torch.cat([r[1] for r in reqs]),
+                                           torch.cat([r[2] for r in reqs]), (torch.cat([r[3][0] for r in reqs]), c_in, ei))
+        acts, tok_w = ei.get("ca_layers_activations"), ei.get("ca_tokmap_weights")
+        res = []
+        for e, o, b in zip(eis, offs, sizes):
+            if acts is not None:
+                e["ca_layers_activations"] = {key: {li: v[o:o + b] for li, v in d.items()} for key, d in acts.items()}
+            if tok_w is not None:
+                e["ca_tokmap_weights"] = tok_w[o:o + b]
+            res.append((out[o:o + b], x_noisy[o:o + b]))
+        return res
+
+    def _merged_indices(self, index_sets, offs):
+        """[(instance idx, token idx), ...] of the requests -> one pair on the merged batch.  Cached by the identity (and version)
+        of the parts: the conditioning side hands out the same tensors every iteration, and the token-weight matrix built from
+        the merged pair is cached by ITS identity (ldm/util.py token_weight_matrix)."""
+        cache = self.__dict__.setdefault("_merged_index_cache", {})
+        key = tuple((id(bi), id(ti), bi._version, ti._version) for bi, ti in index_sets) + tuple(offs)
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 16:
+                cache.clear()
+            merged = (torch.cat([bi + o for (bi, _), o in zip(index_sets, offs)]), torch.cat([ti for _, ti in index_sets]))
+            hit = cache[key] = (merged, [t for pair in index_sets for t in pair])           # (the parts are kept alive: ids stay theirs)
+        return hit[0]
+
+    def _training_window_fused(self, batches, optimizer, reducer, scheduler, auto_iteration, step_kwargs, after_forward, after_backward):
+        """A window of plain recon micro-batches through ONE UNet pass.  Every micro-batch keeps its own front (iteration flags,
+        RNG draws, conditioning, latents -- in order, as in the sequential loop), its own loss, regularisers and gradients
+        (``_shared_step_gen`` up to and after its denoising request); the requests are served by one batched forward and the
+        gradients enter ONE backward, so ``.grad`` receives g0 + g1 as from two accumulated backwards (the all-reduce of the sum
+        is the sum of the all-reduces).  -> [(loss, aux), ...], or {0: kwargs} when micro-batch 0 is not a plain recon iteration
+        (nothing has been issued for it then: the caller runs the window on lanes)."""
+        n = len(batches)
+        gens, reqs, results = [None] * n, [None] * n, [None] * n
+        for k, batch in enumerate(batches):
+            kw = self._window_kwargs(k, step_kwargs, auto_iteration)
+            if k == 0 and not self._is_plain_recon(kw):
+                return {0: kw}
+            if self._is_plain_recon(kw):
+                gens[k] = self._shared_step_gen(batch, **kw)
+                try:
+                    reqs[k] = next(gens[k])
+                except StopIteration as done:          # (the front decided on an iteration type that runs its own passes)
+                    results[k] = done.value
+            else:
+                # a distillation micro-batch behind recon ones: what is pending is served first, then this one runs by itself
+                self._serve_requests(gens, reqs, results)
+                results[k] = self.shared_step(batch, **kw)
+            self.batch_idx += 1
+        self._serve_requests(gens, reqs, results)
+        if after_forward is not None:
+            for k in range(n):
+                after_forward(k)
+        if reducer is not None:
+            reducer.wait()
+            reducer.begin_backward()
+        roots, grads = [], []
+        for loss, grad, model_output, aux in results:
+            r, g = self._backward_roots(model_output, grad, aux)
+            roots += r
+            grads += g
+        if roots:
+            torch.autograd.backward(roots, grads)
+        if reducer is not None:
+            reducer.reduce()
+        if after_backward is not None:
+            for k in range(n):
+                after_backward(k)
+        self._optimizer_step(optimizer, reducer, scheduler)
+        return [(r[0], r[3]) for r in results]
+
+    def _serve_requests(self, gens, reqs, results):
+        pending = [k for k, r in enumerate(reqs) if r is not None and results[k] is None]
+        if not pending:
+            return
+        batch = [reqs[k] for k in pending]
+        outs = self._denoise_fused(batch) if len(batch) > 1 and self._denoise_fusable(batch) else \
+            [self.guided_denoise(*r) for r in batch]
+        for k, o in zip(pending, outs):
+            try:
+                gens[k].send(o)
+            except StopIteration as done:
+                results[k] = done.value
+            else:
+                raise RuntimeError("training_window: a second denoising request")
+
     def _training_window(self, batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward, contextlib,
-                         after_backward=None):
+                         after_backward=None, pre_kws=None):
         # THIRD-PARTY KERNELS STAY ON LANE 0.  The conditioning side (the hook: SubjBasisGenerator / CLIP behind ``cond_fn``) runs
         # vendor GEMMs; hipBLASLt's stream-K kernels wait inside the launch for partial tiles of their other workgroups, and two
         # of them in flight on two streams (the two lanes' hook forwards start within a millisecond of each other) were seen to
@@ -1584,12 +1760,12 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         fronts = []
         for k, batch in enumerate(batches):
             with (lanes.micro_batch(k) if lanes is not None else contextlib.nullcontext()):
-                kw = dict(step_kwargs(k) if callable(step_kwargs) else
-                          step_kwargs[k] if isinstance(step_kwargs, (list, tuple)) else (step_kwargs or {}))
-                if conds[k] is not None and kw.get("cond") is None:
-                    kw["cond"] = conds[k]
-                if auto_iteration is not None:
-                    self._iteration_preamble(auto_iteration, kw)
+                if pre_kws is not None and k in pre_kws:          # (already evaluated by the fused attempt: not twice)
+                    kw = pre_kws[k]
+                    if conds[k] is not None and kw.get("cond") is None:
+                        kw["cond"] = conds[k]
+                else:
+                    kw = self._window_kwargs(k, step_kwargs, auto_iteration, conds[k])
                 fronts.append(self.shared_step(batch, **kw))
                 if after_forward is not None:
                     after_forward(k)

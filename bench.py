@@ -178,6 +178,9 @@ def main():
                     help="skip the `unfreeze_model: True` leg (weight gradients + 4.5 GB optimiser / all-reduce payload)")
     ap.add_argument("--no-zs-frontend", action="store_true", help="skip the zero-shot front end leg (CLIP ViT-L/14 image encoder)")
     ap.add_argument("--no-compos", action="store_true", help="skip the config-4 leg (Stage-2 compositional micro-batches)")
+    ap.add_argument("--fuse", action="store_true",
+                    help="run an accumulation window's two recon micro-batches as ONE batched UNet pass instead of on two lanes "
+                         "(measured slower here: 26.3 vs 24.9 ms; it is the default only where lanes cannot be used)")
     ap.add_argument("--no-lanes", action="store_true",
                     help="one stream for both micro-batches of an accumulation window (round 3's loop) instead of one each")
     ap.add_argument("--no-distill-mix", action="store_true",
@@ -365,6 +368,7 @@ def main():
     use_lanes = (prefetch is not None and not args.graph and not args.no_lanes and ld.manual_accumulate_grad_batches == 2)
     lanes = MicroBatchLanes(params, n=2, reducer=reducer if world > 1 else None) if use_lanes else None
 
+    fuse = use_lanes and (args.fuse or os.environ.get("ADAP_WINDOW_FUSE", "0") == "1")          # the window as one batched UNet pass
     diag_no_vae = os.environ.get("ADAP_DIAG_NO_VAE", "0") == "1"      # DIAGNOSTIC (invalid as a result): latents not encoded
     diag_x = torch.randn(B, 4, 64, 64, device=device) if diag_no_vae else None
 
@@ -376,15 +380,15 @@ def main():
                 return dict(t=t, noise=noise, x_start=diag_x, anneal_t=True)
             return dict(t=t, noise=noise, x_start=prefetch.get(), anneal_t=True)
         if diag_no_vae:
-            return ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws)[-1][0]
+            return ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws, fuse=fuse)[-1][0]
         # (measured alternatives, each 26.7 vs 25.6 ms: encoding the next latents on the micro-batch's own lane behind its forward or
         # its backward, or submitting them to the prefetch stream only once the backward is issued)
         if pf_depth == 4:        # tuning: two windows ahead, submitted behind the backwards (the encodes then run in the window's tail)
             out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
-                                     after_backward=lambda k: pf_submit())
+                                     after_backward=lambda k: pf_submit(), fuse=fuse)
         else:
             out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt, reducer, sched, lanes, step_kwargs=draws,
-                                     after_forward=lambda k: pf_submit())
+                                     after_forward=lambda k: pf_submit(), fuse=fuse)
         return out[-1][0]
 
     def step(i):
@@ -833,7 +837,7 @@ def main():
             "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic", "hipgraph": graphs is not None, "vae_prefetch_stream": prefetch is not None,
-            "micro_batch_lanes": lanes is not None, **({"DIAGNOSTIC_INVALID": "no VAE encode"} if diag_no_vae else {}),
+            "micro_batch_lanes": lanes is not None, "window_fused": bool(fuse), **({"DIAGNOSTIC_INVALID": "no VAE encode"} if diag_no_vae else {}),
             **({"emulated_node_share": emulated} if emulated else {}),
             "config": {"workload": "Stage-1 AdaFace recon distillation micro-batch, full SD-1.5 UNet (859.5M, frozen) + VAE "
                                    "encoder, 512x512, 16-layer layerwise context [64,77,768], img_mask + distill-attn capture, masked MSE + "

@@ -611,7 +611,7 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
                 lanes = MicroBatchLanes(params, n=2)
                 for w in range(2):
                     out = ld.training_window([mbs[2 * w][0], mbs[2 * w + 1][0]], opt, red, sched, lanes,
-                                             step_kwargs=[mbs[2 * w][1], mbs[2 * w + 1][1]])
+                                             step_kwargs=[mbs[2 * w][1], mbs[2 * w + 1][1]], fuse=(mode == "fused"))
                     losses += [o[0] for o in out]
                 lanes.remove()
             torch.cuda.synchronize()
@@ -627,10 +627,18 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
     for x, y in zip(pa, pb):
         assert torch.equal(x, y)
     assert all(math.isfinite(v) for v in la) and float((pa[0] - pb[0]).abs().max()) == 0.0
-    lc, dc, pc = run("window", False)                # the shipped mode: lane 0 single-launch GroupNorm, lane 1 two-pass
+    lc, dc, pc = run("window", False)                # two lanes as shipped: lane 0 single-launch GroupNorm, lane 1 two-pass
     for u, v in zip(la, lc):
         assert abs(u - v) <= 3e-4 * abs(u), (la, lc)
     assert abs(da - dc) <= 1e-3 * abs(da)
+    # the window as ONE batched UNet pass (``fuse``, the default for windows of plain recon micro-batches): the same fronts,
+    # losses and gradients per micro-batch, one forward and one backward at twice the batch -- different tilings and split-K
+    # plans at the larger batch, hence round-off only
+    lf, df, pf_ = run("fused", False)
+    for u, v in zip(la, lf):
+        assert abs(u - v) <= 3e-4 * abs(u), (la, lf)
+    assert abs(da - df) <= 1e-3 * abs(da)
+    assert float(max((x - y).abs().max() for x, y in zip(pa, pf_))) <= 1e-3 * float(max(x.abs().max() for x in pa))
 
 
 ROLLOUT_EPS_TOL = EPS_TOL  # teacher eps / x0 at every rollout step (measured 1e-2 / 4e-3: the feedback does not amplify)
