@@ -1563,7 +1563,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             env = os.environ.get("ADAP_WINDOW_FUSE")
             fuse = (lanes is None and torch.cuda.is_available()) if env is None else env != "0"
         pre_kws = None
-        if fuse and n >= 2 and not any(p.requires_grad for p in self.model.parameters()):
+        if fuse and n >= 2:       # (also with ``unfreeze_model``: one backward at n times the batch = one weight-gradient pass per window)
             done = self._training_window_fused(batches, optimizer, reducer, scheduler, auto_iteration, step_kwargs, after_forward,
                                                after_backward)
             if not isinstance(done, dict):

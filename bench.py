@@ -785,14 +785,36 @@ def main():
                 sched_u.step()
             return loss
 
-        usubmit(0)
+        def uwindow(i):
+            # the window's two micro-batches through the UNet as ONE batched pass (training_window's default where lanes cannot
+            # be used -- weight gradients are written from the start of a backward): one weight-gradient pass per window
+            def draws(k):
+                return dict(t=torch.randint(0, 1000, (B,), device=device, generator=gen),
+                            noise=torch.randn(B, 4, 64, 64, device=device, generator=gen), x_start=pf_u.get(), anneal_t=True)
+            out = ld.training_window([batches[(i + k) % 2] for k in range(2)], opt_u, red_u, sched_u, None, step_kwargs=draws,
+                                     after_backward=lambda k: usubmit(i + 2 + k))
+            return out[-1][0]
+
+        u_fused = ld.manual_accumulate_grad_batches == 2 and not args.no_lanes and os.environ.get("ADAP_WINDOW_FUSE", "1") != "0"
         UW, UK = 2, 6
-        for i in range(UW):
-            ustep(i)
+        if u_fused:
+            ld.batch_idx = 0
+            usubmit(0)
+            usubmit(1)
+            for i in range(0, UW, 2):
+                uwindow(i)
+        else:
+            usubmit(0)
+            for i in range(UW):
+                ustep(i)
         sync()
         t1 = time.perf_counter()
-        for i in range(UW, UW + UK):
-            lu = ustep(i)
+        if u_fused:
+            for i in range(UW, UW + UK, 2):
+                lu = uwindow(i)
+        else:
+            for i in range(UW, UW + UK):
+                lu = ustep(i)
         red_u.wait()
         sync()
         du = time.perf_counter() - t1
@@ -804,6 +826,7 @@ def main():
         unfrozen = {"workload": "config 3, second payload: the same micro-batch with `unfreeze_model: True` -- weight gradients of "
                                 "all 686 UNet tensors, Prodigy over hook + UNet + a 123 M CLIP-text stand-in, all of it all-reduced",
                     "trainable_params": nparam, "grad_allreduce_bytes": 4 * nparam if world > 1 else 0,
+                    "window_fused": bool(u_fused),
                     "steps": UK, "ms_per_step": round(1e3 * du / UK, 2), "images_per_sec": round(world * B * UK / du, 2),
                     "final_loss": round(float(lu), 5), "finite": bool(torch.isfinite(opt_u.param_buffer).all())}
         del opt_u, red_u, sched_u, pf_u, clip_standin, groups, all_u

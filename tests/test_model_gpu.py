@@ -641,6 +641,71 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
     assert float(max((x - y).abs().max() for x, y in zip(pa, pf_))) <= 1e-3 * float(max(x.abs().max() for x in pa))
 
 
+def test_fused_window_with_unfrozen_unet_equals_sequential_steps():
+    """``unfreeze_model: True``: a window cannot run on lanes (the UNet's weight gradients are written through raw pointers from
+    the start of a backward), so ``training_window`` sends its two recon micro-batches through the UNet as ONE batched pass
+    (``fuse``, the default without lanes): one backward at twice the batch = ONE weight-gradient pass per window.  Against two
+    sequential ``training_step``s: the losses, Prodigy's d and every parameter of hook and UNet after the optimiser step."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.ldm.prodigy import Prodigy
+    from adaprompt_amd.ldm.util import prodigy_linear_schedule
+    from adaprompt_amd.parallel import GradReducer
+    from adaprompt_amd.hook_standin import SyntheticSubjBasisGenerator, make_cond_fn
+    ucfg = dict(NARROW)
+    vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
+    B = 2
+    fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
+
+    def run(fused):
+        torch.manual_seed(3)
+        hook = SyntheticSubjBasisGenerator(n_params=3 * 16 * 77 * 128, tokens=77, dim=128, id_dim=32)
+        with torch.no_grad():
+            hook.bases.mul_(20.0)
+        hook = hook.to(dev())
+        ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
+                                      {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg},
+                                      cond_fn=make_cond_fn(hook, capture=True, regs=True))
+        ld.load_state_dict(synth.synthetic_unet_state_dict(ucfg), strict=False)
+        ld = ld.to(dev())
+        for p_ in ld.model.parameters():
+            p_.requires_grad_(True)
+        groups = [{"params": list(hook.parameters())}, {"params": list(ld.model.parameters())}]
+        params = [q for g_ in groups for q in g_["params"]]
+        opt = Prodigy(groups, lr=1.0, betas=(0.9, 0.999), d_coef=2.0, use_bias_correction=True, weight_decay=0.0)
+        red = GradReducer(params, flat=opt.grad_buffer)
+        sched = prodigy_linear_schedule(opt, max_steps=4, warm_up_steps=1, scheduler_cycles=1)
+        mbs = []
+        for mb in range(2):
+            ids = synth.synthetic_input(f"win.ids.{mb}", (B, 32))
+            batch = {"zs_id_embs": ids.to(dev()), "fg_mask": fg64[:, 0].to(dev()), "aug_mask": im64[:, 0].to(dev())}
+            kw = dict(t=torch.tensor([150 + 200 * mb, 900 - 100 * mb]).to(dev()),
+                      noise=synth.synthetic_input(f"win.noise.{mb}", (B, 4, 64, 64)).to(dev()),
+                      x_start=synth.synthetic_input(f"win.x0.{mb}", (B, 4, 64, 64)).to(dev()))
+            mbs.append((batch, kw))
+        before = [p_.detach().clone() for p_ in params]
+        if fused:
+            out = ld.training_window([mbs[0][0], mbs[1][0]], opt, red, sched, None, step_kwargs=[mbs[0][1], mbs[1][1]])
+            losses = [float(o[0]) for o in out]
+        else:
+            losses = [float(ld.training_step(batch, optimizer=opt, reducer=red, scheduler=sched, **kw)[0]) for batch, kw in mbs]
+        torch.cuda.synchronize()
+        assert ld.batch_idx == 2 and opt.device_state()["k"] == 1
+        moved = [(a_.detach() - b_).float().cpu() for a_, b_ in zip(params, before)]
+        return losses, opt.device_state()["d"], moved
+
+    la, da, ma = run(False)
+    lb, db, mb_ = run(True)
+    for u, v in zip(la, lb):
+        assert abs(u - v) <= 3e-4 * abs(u), (la, lb)
+    assert abs(da - db) <= 2e-3 * abs(da), (da, db)
+    num = sum(float((x - y).pow(2).sum()) for x, y in zip(ma, mb_)) ** 0.5
+    den = sum(float(x.pow(2).sum()) for x in ma) ** 0.5
+    # the step's displacement of hook + all 686 UNet tensors.  A FIRST Adam-type step moves every element by ~ lr d sign(g): the
+    # elements whose gradient is at round-off level flip with the summation order of the batch-4 / batch-8 weight-gradient passes
+    # (measured 4 % of the displacement's norm; the 5-step trajectory test allows hip-vs-oracle 10 % for the same reason)
+    assert den > 0 and num <= 8e-2 * den, (num, den)
+
+
 ROLLOUT_EPS_TOL = EPS_TOL  # teacher eps / x0 at every rollout step (measured 1e-2 / 4e-3: the feedback does not amplify)
 DISTILL_LOSS_TOL = LOSS_TOL  # sum over steps of masked MSE(student eps, teacher eps): the north-star bar (measured 2.6e-4)
 
