@@ -46,12 +46,14 @@ def test_committed_bench_line_agrees_with_the_committed_profiles():
     # the dominant kernel is named as rocprofv3 lists it, and the committed stats hold it with a matching duration
     import csv
     tag = os.path.basename(latest("r*_bench_line.json"))[:3]
-    with open(latest(tag + "_bench_kernel_stats*.csv")) as fh:
+    # (the pass with every kernel alone on the chip is the one bench.py's HIP events correspond to, when a round committed one)
+    alone = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats_alone.csv")
+    with open(alone if os.path.exists(alone) else latest(tag + "_bench_kernel_stats*.csv")) as fh:
         rows = {row["Name"]: row for row in csv.DictReader(fh)}
     sym = [n for n in rows if r["kernel"] in n]
     assert sym, r["kernel"]
     avg_us = float(rows[sym[0]]["AverageNs"]) / 1e3
-    assert abs(avg_us - r["avg_launch_us"]) / avg_us < 0.15, (avg_us, r["avg_launch_us"])
+    assert abs(avg_us - r["avg_launch_us"]) / avg_us < 0.10, (avg_us, r["avg_launch_us"])
     with open(latest(tag + "_pmc_traffic.json")) as fh:
         pmc = json.load(fh)
     assert r["kernel"] in pmc["kernels"] and 0.95 < pmc["calibration"]["ratio"] < 1.05
