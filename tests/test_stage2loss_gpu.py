@@ -140,3 +140,55 @@ def test_bg_suppress_fused_equals_masked_means(H, N):
         assert abs(float(o[k].detach()) - float(r[k].detach())) <= 1e-5 * abs(float(r[k].detach())) + 1e-9
     for x, y in zip(ind, ins):
         assert float((x.grad.cpu().double() - y.grad).norm() / y.grad.norm()) < 1e-5
+
+
+# ---- edges -----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,hw", [(8, 64), (8, 32), (5, 16), (1, 8)])
+def test_attn_spatial_weight_equals_convert_attn_to_spatial_weight(H, hw):
+    from adaprompt_amd import ops
+    g = torch.Generator().manual_seed(5000 + hw)
+    a0 = torch.rand(1, H, hw * hw, generator=g) * 0.3 + 0.01
+    a1 = torch.rand(1, H, hw * hw, generator=g) * 0.1
+    a1[..., : hw] += 2.0                                   # a map with a strong peak: the exp is clamped to 1 elsewhere
+    for rev in (True, False):
+        w0, _ = S.convert_attn_to_spatial_weight(a0.double(), 1, torch.Size([hw, hw]), reversed=rev)
+        w1, _ = S.convert_attn_to_spatial_weight(a1.double(), 1, torch.Size([hw, hw]), reversed=rev)
+        ref_pair, ref_one = ((w0 + w1) / 2).reshape(-1), w1.reshape(-1)
+        d = dev()
+        out_pair = ops.attn_spatial_weight(a0[0].to(d).contiguous(), a1[0].to(d).contiguous(), reversed=rev)
+        out_one = ops.attn_spatial_weight(a1[0].to(d).contiguous(), None, reversed=rev)
+        assert torch.allclose(out_pair.cpu().double(), ref_pair, rtol=2e-5, atol=1e-7)
+        assert torch.allclose(out_one.cpu().double(), ref_one, rtol=2e-5, atol=1e-7)
+        assert abs(float(out_one.mean()) - 1.0) < 1e-5
+
+
+def test_bg_suppress_with_empty_masks_is_zero_with_finite_gradients():
+    from adaprompt_amd import functional as HF
+    d = dev()
+    a = torch.randn(4, 8, 225, device=d, requires_grad=True)
+    z = torch.zeros(1, 1, 225, device=d, requires_grad=True)
+    w = torch.rand(1, 1, 225, device=d).requires_grad_(True)
+    ls, lm = HF.BgSuppressFn.apply(a, z, w, 0.02)
+    (ls + lm).backward()
+    assert float(ls.detach()) == 0.0 and float(lm.detach()) > 0.0
+    for t in (a, z, w):
+        assert torch.isfinite(t.grad).all()
+    assert float(a.grad[0].abs().max()) == 0 and float(a.grad[2].abs().max()) == 0 and float(a.grad[1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("nfg", [1, 49])
+def test_elastic_match_with_one_and_with_all_foreground_tokens(nfg):
+    N, C = 49, 24
+    g = torch.Generator().manual_seed(6000 + nfg)
+    q, f = torch.randn(4, C, N, generator=g) * 0.3, torch.randn(4, C, N, generator=g)
+    m = torch.zeros(1, 1, N)
+    m[..., :nfg] = 1.0
+    gw = [torch.tensor(1.0), torch.tensor(1.0), torch.tensor(1.0), torch.rand(1, 1, N, generator=g), torch.rand(1, 1, N, generator=g)]
+    ref_out, ref_dq, ref_df = _run(q.double(), f.double(), m.double(), [w.double() for w in gw], fused=False)
+    d = dev()
+    out, dq, df = _run(q.to(d), f.to(d), m.to(d), [w.to(d) for w in gw], fused=True)
+    for k in range(3):
+        assert abs(float(out[k]) - float(ref_out[k])) <= 2e-5 * abs(float(ref_out[k])) + 1e-7, (k, float(out[k]), float(ref_out[k]))
+    rel = lambda a, b: float((a.cpu().double() - b).norm() / b.norm())
+    assert rel(dq, ref_dq) < 2e-4 and rel(df, ref_df) < 2e-4
+    assert torch.isfinite(dq).all() and torch.isfinite(df).all()
