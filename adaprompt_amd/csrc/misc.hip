@@ -721,6 +721,85 @@ extern "C" int adap_ortho_rows(const float* a, long lda, const float* b, long ld
     return adap_check_launch("ortho_rows");
 }
 
+// Few, very long rows (Stage 2's pooled feature maps: 4 rows of 72 000): one workgroup per row is 4 workgroups walking 72 000
+// elements twice (118 us per call, ~76 calls per compositional micro-batch).  Two launches instead: every row is cut into S
+// slices; stage 1 leaves (<a,b>, <b,b>, <g,b>) per slice, stage 2 sums a row's slices IN ORDER (every workgroup of the row the same
+// way: bit-reproducible) and applies the result to its own slice.
+#define ORTHO_SLICE 2048
+__global__ __launch_bounds__(256) void ortho_rows_partial_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                                 long ldb, const float* __restrict__ g, long ldg,
+                                                                 float* __restrict__ part, int D, int S) {
+    __shared__ float red[4];
+    const long row = blockIdx.y;
+    const int sl = blockIdx.x, t = threadIdx.x;
+    const int i0 = sl * ORTHO_SLICE, i1 = min(D, i0 + ORTHO_SLICE);
+    const float* ar = a + row * lda;
+    const float* br = b + row * ldb;
+    const float* gr = g ? g + row * ldg : nullptr;
+    float ab = 0.f, bb = 0.f, gb = 0.f;
+    for (int i = i0 + t; i < i1; i += 256) {
+        const float bv = br[i];
+        ab += ar[i] * bv; bb += bv * bv;
+        if (gr) gb += gr[i] * bv;
+    }
+    ab = block_sum_256(ab, red);
+    bb = block_sum_256(bb, red);
+    gb = block_sum_256(gb, red);
+    if (t == 0) {
+        float* p = part + (row * S + sl) * 3;
+        p[0] = ab; p[1] = bb; p[2] = gb;
+    }
+}
+
+__global__ __launch_bounds__(256) void ortho_rows_apply_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                               long ldb, const float* __restrict__ g, long ldg, float* __restrict__ out,
+                                                               long ldo, float* __restrict__ da, long ldda, float* __restrict__ db,
+                                                               long lddb, const float* __restrict__ part, int D, int S) {
+    const long row = blockIdx.y;
+    const int sl = blockIdx.x, t = threadIdx.x;
+    float ab = 0.f, bb = 0.f, gb = 0.f;
+    for (int k = 0; k < S; ++k) {                      // the same order in every workgroup of the row
+        const float* p = part + (row * S + k) * 3;
+        ab += p[0]; bb += p[1]; gb += p[2];
+    }
+    bb += 1e-6f;
+    const float c = ab / bb, s = gb / bb;
+    const int i0 = sl * ORTHO_SLICE, i1 = min(D, i0 + ORTHO_SLICE);
+    const float* ar = a + row * lda;
+    const float* br = b + row * ldb;
+    if (!g) {
+        for (int i = i0 + t; i < i1; i += 256) out[row * ldo + i] = ar[i] - c * br[i];
+        return;
+    }
+    const float* gr = g + row * ldg;
+    for (int i = i0 + t; i < i1; i += 256) {
+        const float bv = br[i], gv = gr[i];
+        if (da) da[row * ldda + i] = gv - s * bv;
+        if (db) db[row * lddb + i] = -c * gv - s * (ar[i] - 2.0f * c * bv);
+    }
+}
+
+extern "C" long adap_ortho_rows_workspace_floats(long R, int D) {
+    return D >= 4 * ORTHO_SLICE ? R * ((D + ORTHO_SLICE - 1) / ORTHO_SLICE) * 3 : 0;
+}
+
+// adap_ortho_rows with a workspace of adap_ortho_rows_workspace_floats(R, D) floats: rows of >= 8192 elements are cut into
+// 2048-element slices over two launches (NULL or a short row: the one-workgroup-per-row kernel)
+extern "C" int adap_ortho_rows_ws(const float* a, long lda, const float* b, long ldb, const float* g, long ldg, float* out, long ldo,
+                                  float* da, long ldda, float* db, long lddb, long R, int D, float* workspace, void* stream) {
+    if (!workspace || D < 4 * ORTHO_SLICE || R > 65535)
+        return adap_ortho_rows(a, lda, b, ldb, g, ldg, out, ldo, da, ldda, db, lddb, R, D, stream);
+    ADAP_REQUIRE(a && b && ((!g && out) || (g && (da || db))), ADAP_ERR_SHAPE, "ortho_rows: null pointer");
+    ADAP_REQUIRE(R >= 0 && lda >= D && ldb >= D, ADAP_ERR_SHAPE, "ortho_rows: shape");
+    if (R == 0) return ADAP_OK;
+    const int S = (D + ORTHO_SLICE - 1) / ORTHO_SLICE;
+    hipLaunchKernelGGL(ortho_rows_partial_kernel, dim3(S, (unsigned)R), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, g, ldg,
+                       workspace, D, S);
+    hipLaunchKernelGGL(ortho_rows_apply_kernel, dim3(S, (unsigned)R), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, g, ldg, out,
+                       ldo, da, ldda, db, lddb, workspace, D, S);
+    return adap_check_launch("ortho_rows");
+}
+
 // ---------------------------------------------------------------------------------------------
 // The four mask hinge terms of calc_fg_bg_complementary_loss (ddpm.py:4143-4238) for a stack of same-resolution
 // layers, forward and analytic backward.  S = subject score map, G = background-token score map, [L][B][H][N]

@@ -970,16 +970,18 @@ def ortho_rows(a, b, g=None, want_da=True, want_db=True):
     g f32 [R, D] = the gradient of the result: -> (da, db)."""
     assert a.dtype == F32 and b.dtype == F32 and a.dim() == 2 and a.shape == b.shape and a.stride(1) == 1 and b.stride(1) == 1
     R, D = a.shape
+    nws = _lib.size_query("adap_ortho_rows_workspace_floats", R, D)          # > 0: few very long rows, sliced over two launches
+    ws = torch.empty(nws, device=a.device, dtype=F32) if nws else None
     if g is None:
         out = torch.empty(R, D, device=a.device, dtype=F32)
-        _lib.call("adap_ortho_rows", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 0, 0, out.data_ptr(), D, 0, 0, 0, 0,
-                  R, D, _stream())
+        _lib.call("adap_ortho_rows_ws", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 0, 0, out.data_ptr(), D, 0, 0, 0, 0,
+                  R, D, _ptr(ws), _stream())
         return out
     assert g.dtype == F32 and g.shape == a.shape and g.stride(1) == 1
     da = torch.empty(R, D, device=a.device, dtype=F32) if want_da else None
     db = torch.empty(R, D, device=a.device, dtype=F32) if want_db else None
-    _lib.call("adap_ortho_rows", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), g.data_ptr(), g.stride(0), 0, 0, _ptr(da), D,
-              _ptr(db), D, R, D, _stream())
+    _lib.call("adap_ortho_rows_ws", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), g.data_ptr(), g.stride(0), 0, 0, _ptr(da),
+              D, _ptr(db), D, R, D, _ptr(ws), _stream())
     return da, db
 
 

@@ -516,6 +516,12 @@ int adap_cosine_rows(const float* x, long ldx, const float* r, long ldr, const f
  * (NULL = not wanted):  da = g - s b,  db = -c g - s (a - 2 c b),  s = <g,b> / (<b,b> + 1e-6). */
 int adap_ortho_rows(const float* a, long lda, const float* b, long ldb, const float* g, long ldg, float* out, long ldo,
                     float* da, long ldda, float* db, long lddb, long R, int D, void* stream);
+/* The same with a workspace of adap_ortho_rows_workspace_floats(R, D) floats (0: none needed): rows of >= 8192 elements (Stage 2's
+ * pooled feature maps: 4 rows of 72 000) are cut into 2048-element slices over two launches, the slices' sums added in a fixed
+ * order; shorter rows, or workspace NULL: the one-workgroup-per-row form. */
+long adap_ortho_rows_workspace_floats(long R, int D);
+int adap_ortho_rows_ws(const float* a, long lda, const float* b, long ldb, const float* g, long ldg, float* out, long ldo,
+                       float* da, long ldda, float* db, long lddb, long R, int D, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Stage-2 elastic matching loss of ONE distillation layer, value and gradient (ldm/util.py:2241-2368

@@ -324,7 +324,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, H, W, Cin, Cout, res, bf
     assert getattr(y32, ops.GN_STATS_ATTR, None) is None and _lib.call_long("adap_conv2d_last_gn_chunks") == 0
 
 
-@pytest.mark.parametrize("shape", [(3, 8, 4096), (4, 11520), (2, 16, 77, 768), (1, 5, 33)])
+@pytest.mark.parametrize("shape", [(3, 8, 4096), (4, 11520), (2, 16, 77, 768), (1, 5, 33), (4, 72000), (1, 8193)])
 def test_ortho_subtract_fused_rows(shape):
     """``ortho_subtract`` over the last dim (ldm/util.py:280) as one launch each way (``OrthoRowsFn``) against the torch
     expressions and their autograd: a - <a,b>/(<b,b>+1e-6) b, gradients into both operands."""
