@@ -53,23 +53,32 @@ __global__ __launch_bounds__(EM_THREADS) void em_gemm_kernel(EmGemm g) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this thread's four (m, k) / (k, n) positions of a chunk, and the loads of one chunk into registers
+    int am[4], ak[4], bn_[4], bk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (A_MC) { am[r] = t & 63; ak[r] = (t >> 6) + 4 * r; }
+        else { ak[r] = t & 15; am[r] = (t >> 4) + 16 * r; }
+        if (B_NC) { bn_[r] = t & 63; bk[r] = (t >> 6) + 4 * r; }
+        else { bk[r] = t & 15; bn_[r] = (t >> 4) + 16 * r; }
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ra[r] = (m0 + am[r] < g.M && k0 + ak[r] < g.K) ? A[(long)(m0 + am[r]) * g.sam + (long)(k0 + ak[r]) * g.sak] : 0.f;
+            rb[r] = (n0 + bn_[r] < g.N && k0 + bk[r] < g.K) ? B[(long)(k0 + bk[r]) * g.sbk + (long)(n0 + bn_[r]) * g.sbn] : 0.f;
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < g.K; k0 += 16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int m, k;
-            if (A_MC) { m = t & 63; k = (t >> 6) + 4 * r; }
-            else { k = t & 15; m = (t >> 4) + 16 * r; }
-            float v = 0.f;
-            if (m0 + m < g.M && k0 + k < g.K) v = A[(long)(m0 + m) * g.sam + (long)(k0 + k) * g.sak];
-            sA[k][m] = v;
-            int n, kb;
-            if (B_NC) { n = t & 63; kb = (t >> 6) + 4 * r; }
-            else { kb = t & 15; n = (t >> 4) + 16 * r; }
-            float u = 0.f;
-            if (n0 + n < g.N && k0 + kb < g.K) u = B[(long)(k0 + kb) * g.sbk + (long)(n0 + n) * g.sbn];
-            sB[kb][n] = u;
+            sA[ak[r]][am[r]] = ra[r];
+            sB[bk[r]][bn_[r]] = rb[r];
         }
         __syncthreads();
+        if (k0 + 16 < g.K) fetch(k0 + 16);             // the next chunk's loads are in flight under this chunk's MFMAs
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 4) {
             const int kr = kk + (lane >> 4), c = lane & 15;
@@ -167,11 +176,12 @@ __global__ __launch_bounds__(EM_THREADS) void em_colsum_kernel(const float* __re
 }
 
 // per token (column of [C][N] arrays): <a, t(b)>, |a|^2 + 1e-12, |t(b)|^2 + 1e-12 -> three rows of `dst`
-__global__ __launch_bounds__(EM_THREADS) void em_coscols_kernel(const float* __restrict__ a0, const float* __restrict__ b0,
+#define EM_CS 16                                        // channel slices per workgroup (64 tokens x 16 slices = 1024 threads)
+__global__ __launch_bounds__(64 * EM_CS) void em_coscols_kernel(const float* __restrict__ a0, const float* __restrict__ b0,
                                                                 float* __restrict__ d0, const float* __restrict__ a1,
                                                                 const float* __restrict__ b1, float* __restrict__ d1, int C,
                                                                 int N) {
-    __shared__ float part[3][4][64];
+    __shared__ float part[3][EM_CS][64];
     const int t = threadIdx.x, col = t & 63, sl = t >> 6;
     const int i = blockIdx.x * 64 + col;
     const float* a = blockIdx.y ? a1 : a0;
@@ -179,16 +189,16 @@ __global__ __launch_bounds__(EM_THREADS) void em_coscols_kernel(const float* __r
     float* dst = blockIdx.y ? d1 : d0;
     float P = 0.f, A = 0.f, Bq = 0.f;
     if (i < N)
-        for (int c = sl; c < C; c += 4) {
+        for (int c = sl; c < C; c += EM_CS) {
             const float x = a[(long)c * N + i], r = b[(long)c * N + i], tt = r * fabsf(r);
             P += x * tt; A += x * x; Bq += tt * tt;
         }
     part[0][sl][col] = P; part[1][sl][col] = A; part[2][sl][col] = Bq;
     __syncthreads();
-    if (sl == 0 && i < N) {
-        dst[i] = ((part[0][0][col] + part[0][1][col]) + part[0][2][col]) + part[0][3][col];
-        dst[N + i] = ((part[1][0][col] + part[1][1][col]) + part[1][2][col]) + part[1][3][col] + 1e-12f;
-        dst[2 * (long)N + i] = ((part[2][0][col] + part[2][1][col]) + part[2][2][col]) + part[2][3][col] + 1e-12f;
+    if (sl < 3 && i < N) {                              // slice threads 0, 1, 2 each sum one of the three quantities, in order
+        float v = 0.f;
+        for (int k = 0; k < EM_CS; ++k) v += part[sl][k][col];
+        dst[(long)sl * N + i] = v + (sl ? 1e-12f : 0.f);
     }
 }
 
@@ -342,7 +352,7 @@ extern "C" int adap_elastic_match_fwd(const float* q, int Cq, const float* f, in
     r.A = f + fN; r.B = P2; r.C = RT; r.sam = N; r.sak = 1; r.sbk = 1; r.sbn = N; r.ldc = N;
     r.M = Cf; r.N = N; r.K = N; r.alpha = 1.f; r.accumulate = 0;
     em_gemm(false, false, r, 1, s);
-    hipLaunchKernelGGL(em_coscols_kernel, dim3((N + 63) / 64, 2), dim3(EM_THREADS), 0, s, RT, f, tok + (long)ADAP_EM_DOT_FG * N,
+    hipLaunchKernelGGL(em_coscols_kernel, dim3((N + 63) / 64, 2), dim3(64 * EM_CS), 0, s, RT, f, tok + (long)ADAP_EM_DOT_FG * N,
                        f + fN, f + 3 * fN, tok + (long)ADAP_EM_DOT_BG * N, Cf, N);
     hipLaunchKernelGGL(em_finalize_kernel, dim3(1), dim3(EM_THREADS), 0, s, fg, tok, out, N, cutoff);
     return adap_check_launch("elastic_match_fwd");
@@ -392,16 +402,16 @@ extern "C" int adap_elastic_match_bwd(const float* q, int Cq, const float* f, in
 //     src = ss - c1 ms, c1 = <ss,ms> / (<ms,ms> + 1e-6);   tgt = sc - c2 mc, c2 = <sc,mc> / (<mc,mc> + 1e-6)
 //     delta = 1 - cos(tgt, src^3)            norm = |mean sc - mean mc| + |mean ss - mean ms|
 //   out[0] = mean_h delta, out[1] = mean_h norm.  The mix maps (ms, mc) carry gradient scaled by gs_mix (0.05).
-// One workgroup walks the heads in order: fixed summation order, one launch each way.  rec f32 [H][ADAP_PM_REC] is the forward's
-// record for the backward.
+// One workgroup per head (fixed summation order inside it), the heads averaged in order by a one-thread finish.
+// rec f32 [H][ADAP_PM_REC] is the forward's record for the backward.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EM_THREADS) void pm_attnterms_fwd_kernel(const float* __restrict__ a, int H, int N,
-                                                                      float* __restrict__ rec, float* __restrict__ out) {
+                                                                      float* __restrict__ rec) {
     __shared__ float red[4];
     const int t = threadIdx.x;
     const long HN = (long)H * N;
-    float ld = 0.f, ln = 0.f;
-    for (int h = 0; h < H; ++h) {
+    {
+        const int h = blockIdx.x;                      // one workgroup per head; pm_attnterms_finish_kernel averages them in order
         const float* ss = a + (long)h * N;
         const float* sc = ss + HN;
         const float* ms = ss + 2 * HN;
@@ -424,14 +434,22 @@ __global__ __launch_bounds__(EM_THREADS) void pm_attnterms_fwd_kernel(const floa
         A = em_block_sum(A, red) + 1e-12f;
         B = em_block_sum(B, red) + 1e-12f;
         const float m0 = v[4] / N, m1 = v[5] / N, m2 = v[6] / N, m3 = v[7] / N;
-        ld += 1.0f - P / sqrtf(A * B);
-        ln += fabsf(m1 - m3) + fabsf(m0 - m2);
         if (t == 0) {
             float* r = rec + (long)h * ADAP_PM_REC;
             r[0] = c1; r[1] = c2; r[2] = P; r[3] = A; r[4] = B; r[5] = m1 - m3; r[6] = m0 - m2; r[7] = v[1] + 1e-6f; r[8] = v[3] + 1e-6f;
+            r[9] = 1.0f - P / sqrtf(A * B);
+            r[10] = fabsf(m1 - m3) + fabsf(m0 - m2);
         }
     }
-    if (t == 0) { out[0] = ld / H; out[1] = ln / H; }
+}
+
+__global__ void pm_attnterms_finish_kernel(const float* __restrict__ rec, int H, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float ld = 0.f, ln = 0.f;
+        for (int h = 0; h < H; ++h) { ld += rec[(long)h * ADAP_PM_REC + 9]; ln += rec[(long)h * ADAP_PM_REC + 10]; }
+        out[0] = ld / H;
+        out[1] = ln / H;
+    }
 }
 
 __global__ __launch_bounds__(EM_THREADS) void pm_attnterms_bwd_kernel(const float* __restrict__ a, int H, int N,
@@ -442,7 +460,8 @@ __global__ __launch_bounds__(EM_THREADS) void pm_attnterms_bwd_kernel(const floa
     const int t = threadIdx.x;
     const long HN = (long)H * N;
     const float gd = (g_delta ? *g_delta : 0.f) / H, gn = (g_norm ? *g_norm : 0.f) / H;
-    for (int h = 0; h < H; ++h) {
+    {
+        const int h = blockIdx.x;                      // one workgroup per head
         const float* ss = a + (long)h * N;
         const float* sc = ss + HN;
         const float* ms = ss + 2 * HN;
@@ -481,9 +500,13 @@ extern "C" int adap_promptmix_attn_terms(const float* a, int H, int N, float gs_
                                          const float* g_delta, const float* g_norm, float* da, void* stream) {
     ADAP_REQUIRE(a && rec && (out || da), ADAP_ERR_SHAPE, "promptmix_attn_terms: null pointer");
     ADAP_REQUIRE(H >= 1 && N >= 1, ADAP_ERR_SHAPE, "promptmix_attn_terms: H %d N %d", H, N);
-    if (out) hipLaunchKernelGGL(pm_attnterms_fwd_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a, H, N, rec, out);
-    else hipLaunchKernelGGL(pm_attnterms_bwd_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a, H, N, rec, g_delta, g_norm,
-                            gs_mix, da);
+    if (out) {
+        hipLaunchKernelGGL(pm_attnterms_fwd_kernel, dim3(H), dim3(EM_THREADS), 0, (hipStream_t)stream, a, H, N, rec);
+        hipLaunchKernelGGL(pm_attnterms_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rec, H, out);
+    } else {
+        hipLaunchKernelGGL(pm_attnterms_bwd_kernel, dim3(H), dim3(EM_THREADS), 0, (hipStream_t)stream, a, H, N, rec, g_delta, g_norm,
+                           gs_mix, da);
+    }
     return adap_check_launch("promptmix_attn_terms");
 }
 
@@ -492,9 +515,21 @@ extern "C" int adap_promptmix_attn_terms(const float* a, int H, int N, float gs_
 // resolution: a_n = mean over heads; w_n = min(exp(-(a_n - mean) / max(std + 0.001, mean / 2)), 1) / mean(w)  (std unbiased;
 // `reversed`: small where the subject attends).  Up to two sources; sw = their average (ddpm.py:3869-3872 uses (mix + subj) / 2).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EM_THREADS) void pm_spatial_weight_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
-                                                                       int H, int N, int reversed, float* __restrict__ sw) {
-    __shared__ float red[4];
+#define PM_SW_THREADS 1024
+__device__ __forceinline__ float pm_block_sum16(float v, float* red) {          // 16 waves, combined in a fixed order
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PM_SW_THREADS / 64; ++k) s += red[k];
+    return s;
+}
+
+__global__ __launch_bounds__(PM_SW_THREADS) void pm_spatial_weight_kernel(const float* __restrict__ a0, const float* __restrict__ a1,
+                                                                          int H, int N, int reversed, float* __restrict__ sw) {
+    __shared__ float red[PM_SW_THREADS / 64];
     const int t = threadIdx.x;
     const int nsrc = a1 ? 2 : 1;
     for (int s = 0; s < nsrc; ++s) {
@@ -505,18 +540,18 @@ __global__ __launch_bounds__(EM_THREADS) void pm_spatial_weight_kernel(const flo
             return v / H;
         };
         float m = 0.f;
-        for (int n = t; n < N; n += EM_THREADS) m += val(n);
-        m = em_block_sum(m, red) / N;
+        for (int n = t; n < N; n += PM_SW_THREADS) m += val(n);
+        m = pm_block_sum16(m, red) / N;
         float q = 0.f;
-        for (int n = t; n < N; n += EM_THREADS) { const float d = val(n) - m; q += d * d; }
-        q = em_block_sum(q, red);
+        for (int n = t; n < N; n += PM_SW_THREADS) { const float d = val(n) - m; q += d * d; }
+        q = pm_block_sum16(q, red);
         const float sd = sqrtf(q / (N > 1 ? N - 1 : 1));
         const float den = fmaxf(sd + 0.001f, m * 0.5f);
         const float sgn = reversed ? -1.f : 1.f;
         float ws = 0.f;
-        for (int n = t; n < N; n += EM_THREADS) ws += fminf(expf(sgn * (val(n) - m) / den), 1.f);
-        ws = em_block_sum(ws, red) / N;
-        for (int n = t; n < N; n += EM_THREADS) {
+        for (int n = t; n < N; n += PM_SW_THREADS) ws += fminf(expf(sgn * (val(n) - m) / den), 1.f);
+        ws = pm_block_sum16(ws, red) / N;
+        for (int n = t; n < N; n += PM_SW_THREADS) {
             const float w = fminf(expf(sgn * (val(n) - m) / den), 1.f) / ws / nsrc;
             sw[n] = s ? sw[n] + w : w;
         }
@@ -525,7 +560,7 @@ __global__ __launch_bounds__(EM_THREADS) void pm_spatial_weight_kernel(const flo
 
 extern "C" int adap_attn_spatial_weight(const float* a0, const float* a1, int H, int N, int reversed, float* sw, void* stream) {
     ADAP_REQUIRE(a0 && sw && H >= 1 && N >= 1, ADAP_ERR_SHAPE, "attn_spatial_weight: arguments");
-    hipLaunchKernelGGL(pm_spatial_weight_kernel, dim3(1), dim3(EM_THREADS), 0, (hipStream_t)stream, a0, a1, H, N, reversed, sw);
+    hipLaunchKernelGGL(pm_spatial_weight_kernel, dim3(1), dim3(PM_SW_THREADS), 0, (hipStream_t)stream, a0, a1, H, N, reversed, sw);
     return adap_check_launch("attn_spatial_weight");
 }
 

@@ -8,6 +8,8 @@ Activations are pixel-major; the 512x512x3 image is consumed in the dataloader's
 (ddpm.py:480-481 permutes it to CHW for the reference -- here that permute is the identity).
 The mid AttnBlock (single head, N=4096, C=512) is two batched contractions around a softmax
 kernel that applies the reference's POST-softmax zero fill of fg/bg hetero pairs."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -204,8 +206,13 @@ class Encoder(nn.Module):
             return self.forward_nhwc(x.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)
 
 
+UPSAMPLE_BF16 = os.environ.get("ADAP_VAE_UPSAMPLE_BF16", "1") != "0"       # A/B switch
+
+
 class Upsample(nn.Module):
-    """nearest x2 then conv3x3 (model.py:42-58): the upsample is folded into the conv's gather (``up=1``)."""
+    """nearest x2 then conv3x3 (model.py:42-58).  The x2 copy is made once, as the conv's bf16 operand (``ops.upsample2x_bf16``), so
+    that the conv takes the stencil-window kernel with its statistics epilogue; folded into the conv's gather (``up=1``: every tap
+    re-reads and re-converts the f32 source) the three decoder Upsamples were the slowest launches of a decode (483 us average)."""
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
@@ -217,6 +224,10 @@ class Upsample(nn.Module):
     def forward(self, x):
         pk = self._wc.get("conv", self.conv.weight, self.conv.bias)
         B, H, W, C = x.shape
+        if x.is_cuda and x.dtype == torch.float32 and not HF.F32_STORAGE and UPSAMPLE_BF16:
+            y, _ = ops.conv2d(ops.upsample2x_bf16(x), pk.fwd, pk.O4, 3, 1, 1, bias=pk.bias,
+                              gn_stats=gn_stats_from_epilogue(B, 2 * H, 2 * W, C))
+            return y
         y, _ = ops.conv2d(x, pk.fwd, pk.O4, 3, 1, 1, up=1, bias=pk.bias, gn_stats=gn_stats_from_epilogue(B, 2 * H, 2 * W, C))
         return y
 
