@@ -72,6 +72,7 @@ struct AttnParams {
                                 // of the matrix core in the exp2 domain and, with the reference point / -lse as the accumulator's
                                 // initial value, go into v_exp_f32 as they are -- one VALU instruction per score less
     int qsplit;                 // dK/dV kernel: the query range is cut into qsplit slices (blockIdx.z), f32 partials
+    int xcd;                    // 1: the workgroups of one (batch, head) -- and of neighbouring heads -- share an XCD (attn_wg_coords)
     float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
     // gradient of the cross-attention token maps folded into this backward (adap_attention_bwd_tok): dq += scale * dT . kw,
     // dk += scale * w . gq, with kw = w^T K and gq = dT^T Q from adap_attention_tokmap_prep
@@ -89,6 +90,25 @@ struct AttnParams {
 // denominator (l = 0 -> NaN output); the C ABI documents key_count >= 1 and treats anything smaller as 1
 __device__ __forceinline__ int attn_key_count(const AttnParams& p, int b) {
     return p.mcount ? max(1, min(p.mcount[b], p.M)) : p.M;
+}
+
+// Which (block, batch * head, slice) a workgroup works on.  The grids are (blocks of one head, B * H, slices); the hardware deals
+// workgroups round-robin over the 8 XCDs in launch order, so with the plain blockIdx map the 16-32 blocks of one (batch, head)
+// land on ALL eight XCDs and every XCD's 4 MiB L2 fetches the K / V (dK/dV kernel: Q / dO) of all heads: 2.3x (forward) and
+// 5.2x (dK/dV) the algorithmic bytes at N 4096 (profiles/r04_pmc_traffic.json).  Remapped, workgroup L -> XCD group L % 8,
+// slot L / 8, and an XCD group walks B*H / 8 CONSECUTIVE (batch, head) rows, all blocks of a row before the next: the operands a
+// row's workgroups share are fetched into one L2, and rows that run side by side on an XCD are neighbouring heads of one sample
+// -- their 80-byte head slices of a token's row share 128-byte lines (a head alone touches 1.5 lines per 80 bytes).
+// Placement only changes speed; B*H not a multiple of 8 keeps the plain map.
+__device__ __forceinline__ void attn_wg_coords(const AttnParams& p, int& bx, int& bh, int& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    if (!p.xcd || (gy & 7u)) { bx = blockIdx.x; bh = blockIdx.y; bz = blockIdx.z; return; }
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned grp = L & 7u, slot = L >> 3, per = gx * gz;
+    const unsigned row = slot / per, r = slot - row * per;
+    bh = (int)(grp * (gy >> 3) + row);
+    bz = (int)(r / gx);
+    bx = (int)(r - (unsigned)bz * gx);
 }
 
 #define MAX_SLACK 5.0f          // see attn_fwd_kernel's running reference point
@@ -216,8 +236,10 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-    const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
+    int bx, bh, bz_;
+    attn_wg_coords(p, bx, bh, bz_);
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int q0 = bx * (128 * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
     constexpr bool pre = PRE;
@@ -468,8 +490,10 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = wave >> 2;                          // 0: waves 0-3, 1: waves 4-7 (the SIMD partners), half a tile behind
     const int c = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-    const int q0 = blockIdx.x * 512 + wave * 64 + c;    // query of block qb: q0 + 32 * qb
+    int bx, bh, bz_;
+    attn_wg_coords(p, bx, bh, bz_);
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int q0 = bx * 512 + wave * 64 + c;    // query of block qb: q0 + 32 * qb
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
 
@@ -775,8 +799,10 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 && NW == 4) ? 2 : 1) void attn_fw
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-    const int q0 = blockIdx.x * (32 * NW * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
+    int bx, bh, bz_;
+    attn_wg_coords(p, bx, bh, bz_);
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int q0 = bx * (32 * NW * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
 
@@ -1058,8 +1084,10 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
-    const int q = blockIdx.x * 128 + wave * 32 + c;
+    int bx, bh, bz_;
+    attn_wg_coords(p, bx, bh, bz_);
+    const int b = bh / p.H, head = bh - b * p.H;
+    const int q = bx * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
     constexpr bool pre = PRE;             // (a template parameter: see attn_fwd_kernel)
@@ -1228,11 +1256,13 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.H, head = bh - b * p.H;
+    int bx, bh, bz;
+    attn_wg_coords(p, bx, bh, bz);
+    const int b = bh / p.H, head = bh - b * p.H;
     // Which 128 keys: rotated by the (batch, head) row.  With a key count the workgroups of the LAST key blocks have nothing to
     // do; workgroups are placed round-robin over the CUs in launch order, and with 32 key blocks per row an unrotated map puts
     // all the idle ones on the same CUs (256 = 8 x 32: measured -- no gain at all from 28 % fewer keys).
-    const int kblk = (int)((blockIdx.x + (unsigned)bh) % gridDim.x);
+    const int kblk = (int)(((unsigned)bx + (unsigned)bh) % gridDim.x);
     const int key = kblk * 128 + wave * 32 + c;
     const int d = p.d;
     const float cs = p.scale * 1.4426950408889634f;
@@ -1281,7 +1311,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
         }
     };
     // this workgroup's slice of the query tiles (the whole range unless the grid was too small to fill the chip)
-    const int split = blockIdx.z;
+    const int split = bz;
     const int qt0 = (int)((long)split * ntiles / p.qsplit);
     // a workgroup whose 128 keys all lie beyond the sample's count has nothing to accumulate: it only writes its zeros
     const int qt1 = kblk * 128 >= Mb ? qt0 : (int)((long)(split + 1) * ntiles / p.qsplit);
@@ -1474,6 +1504,7 @@ struct AttnDebug {
     int pp_prio;      // ping-pong kernel: phase at raised priority, 1 = matrix (default), 2 = vector, 0 = neither
     int qb1;          // 1 = one query block per wave even at the 64 x 64 level
     int dkv_qsplit;   // 0 = heuristic, else the dK/dV kernel's query-split factor
+    int xcd;          // AttnParams::xcd (ADAP_ATTN_XCD=0: the plain blockIdx map, for A/B runs)
 };
 static AttnDebug& attn_debug() {
     static AttnDebug d = [] {
@@ -1486,6 +1517,8 @@ static AttnDebug& attn_debug() {
         v.qb1 = getenv("ADAP_ATTN_QB1") ? 1 : 0;
         e = getenv("ADAP_ATTN_DKV_QSPLIT");
         v.dkv_qsplit = e ? atoi(e) : 0;
+        e = getenv("ADAP_ATTN_XCD");
+        v.xcd = e ? atoi(e) : 1;
         return v;
     }();
     return d;
@@ -1651,7 +1684,7 @@ extern "C" int adap_attention_fwd(const void* q, long ldq, const void* k, long l
     AttnParams p = {};
     p.q = (const uint16_t*)q; p.ldq = ldq; p.k = (const uint16_t*)k; p.ldk = ldk; p.v = (const uint16_t*)v; p.ldv = ldv;
     p.kmask = key_mask; p.mcount = key_count; p.o = (uint16_t*)out; p.ldo = ldo; p.lse = lse;
-    p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale; p.xcd = attn_debug().xcd;
     ADAP_REQUIRE(scale >= 0.f, ADAP_ERR_UNSUPPORTED, "attention_fwd: scale %g", (double)scale);
     if (scale == 0.f) {            // q carries d^-1/2 * log2(e) already (see the header): scores arrive in the exp2 domain
         p.pre = 1;
@@ -1694,7 +1727,7 @@ static int attention_bwd_impl(const void* q, long ldq, const void* k, long ldk, 
     p.dq32 = dq32; p.dq16 = (uint16_t*)dq16; p.lddq = lddq;
     p.dk32 = dk32; p.dk16 = (uint16_t*)dk16; p.lddk = lddk;
     p.dv32 = dv32; p.dv16 = (uint16_t*)dv16; p.lddv = lddv;
-    p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale;
+    p.B = B; p.H = H; p.N = N; p.M = M; p.d = d; p.scale = scale; p.xcd = attn_debug().xcd;
     ADAP_REQUIRE(scale >= 0.f && (scale > 0.f || !tok_dt), ADAP_ERR_UNSUPPORTED, "attention_bwd: scale %g", (double)scale);
     if (scale == 0.f) {            // pre-scaled q: dq is the gradient with respect to THAT q, i.e. ln 2 * dS K; dk = ln 2 * dS^T q
         p.pre = 1;

@@ -80,6 +80,7 @@ class _FlatAdam(FlatParams, torch.optim.Optimizer):
         if self._m is None:
             self._init_moments()
         self._clip(clip_norm)
+        self._check_layout()
         st, s = self._state.data_ptr(), _stream()
         for gi, g in enumerate(self.param_groups):
             o, k = self._train_ranges[gi]               # the group's trainable span (flatopt: frozen tensors lie behind it)

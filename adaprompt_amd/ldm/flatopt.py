@@ -61,6 +61,16 @@ class FlatParams:
         self._ws = torch.zeros(_lib.call_long("adap_optim_workspace_doubles", len(groups)), device=dev,
                                dtype=torch.float64)
         self._n = n
+        self._views_trainable = [p.requires_grad for p, _, _ in self._views]
+
+    def _check_layout(self):
+        """the layout fixed ``requires_grad`` when the flat buffers were built (trainable tensors first in every group): a
+        parameter frozen or unfrozen since would be stepped / skipped wrongly -- rebuild (``zero_grad()`` drops the layout) or
+        construct the optimiser after the change."""
+        for (p, o, k), was in zip(self._views, self._views_trainable):
+            if p.requires_grad != was:
+                raise RuntimeError(f"{self._name} (MI355X): a parameter's requires_grad changed after the flat buffers were built "
+                                   "(trainable tensors lie in front of the frozen ones of their group); build a new optimiser")
 
     def add_param_group(self, param_group):
         """torch calls this for every group at construction; once the flat buffers exist the layout is fixed."""

@@ -208,6 +208,15 @@ def _const_tensor(values, device):
     return t
 
 
+class _CondRequest:
+    """what ``_shared_step_gen`` yields where the sequential step computes its conditioning (``cond_fn(batch)`` on the batch as
+    trimmed for the iteration, or the yaml-instantiated text encoder + embedding manager): ``make()`` computes it -- with the
+    iteration flags of ITS micro-batch current -- on whatever stream the driver chooses."""
+
+    def __init__(self, make):
+        self.make = make
+
+
 class LatentDiffusion(ConditioningMixin, DDPM):
     """The recon-distillation iteration core of the reference ``LatentDiffusion`` (ddpm.py:710-3457)."""
 
@@ -1016,19 +1025,33 @@ class LatentDiffusion(ConditioningMixin, DDPM):
 
     # ---- one micro-batch of pure recon distillation ------------------------------------------------------------
     def shared_step(self, batch, **kwargs):
-        """One micro-batch's forward half -> (loss, grad, model_output, aux); arguments: ``_shared_step_gen``.  The plain recon
-        iteration's UNet pass is a REQUEST of that generator (``x_start, noise, t, cond`` -> ``guided_denoise``), served here at
-        once; ``training_window`` serves the requests of a window's micro-batches with ONE batched pass instead."""
+        """One micro-batch's forward half -> (loss, grad, model_output, aux); arguments: ``_shared_step_gen``.  That generator
+        REQUESTS what other micro-batches of an accumulation window may want to share or to keep off their stream: the
+        conditioning (``_CondRequest``: the hook / text encoder / embedding manager -- vendor kernels, which
+        ``training_window`` keeps on lane 0) and the plain recon iteration's UNet pass (``x_start, noise, t, cond`` ->
+        ``guided_denoise``; ``training_window(fuse=True)`` serves a window's requests with ONE batched pass).  Here both are
+        served at once, in place."""
         gen = self._shared_step_gen(batch, **kwargs)
+        req, res = self._resume(gen, None)
+        if req is None:                                # an iteration that runs its own passes (distillation, stage 2)
+            return res
+        req, res = self._resume(gen, self.guided_denoise(*req))
+        if req is not None:
+            raise RuntimeError("shared_step: a second denoising request")
+        return res
+
+    @staticmethod
+    def _resume(gen, value, serve_cond=None):
+        """advance a ``_shared_step_gen`` to its next DENOISING request, serving the conditioning requests on the way
+        (``serve_cond(request) -> cond``; default: in place, on the current stream).  -> (request, None), or (None, result)
+        when the generator has finished."""
         try:
-            req = next(gen)
-        except StopIteration as done:                  # an iteration that runs its own passes (distillation, stage 2)
-            return done.value
-        try:
-            gen.send(self.guided_denoise(*req))
+            req = gen.send(value)
+            while isinstance(req, _CondRequest):
+                req = gen.send(req.make() if serve_cond is None else serve_cond(req))
         except StopIteration as done:
-            return done.value
-        raise RuntimeError("shared_step: a second denoising request")
+            return None, done.value
+        return req, None
 
     def _shared_step_gen(self, batch, t=None, noise=None, post_noise=None, cond=None, x_start=None,
                          num_denoising_steps=1, use_arc2face_as_target=False, relative_ts=None, noises=None,
@@ -1076,9 +1099,13 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                 return loss.detach(), None, None, aux
             x_start, img_mask, fg_mask, captions = self.prepare_recon_iteration(batch, x_start, img_mask, fg_mask)
             fl = self.iter_flags
-            cond = self.assemble_conditioning(captions, x_start.shape[0])
-            cond[2]["capture_distill_attn"] = True                      # ddpm.py:2866 (recon: not do_teacher_filter)
-            self.attach_subject_indices(cond[2])
+
+            def recon_cond(captions=captions, bs=x_start.shape[0]):
+                c = self.assemble_conditioning(captions, bs)
+                c[2]["capture_distill_attn"] = True                     # ddpm.py:2866 (recon: not do_teacher_filter)
+                self.attach_subject_indices(c[2])
+                return c
+            cond = yield _CondRequest(recon_cond)
             instance_mask = fl["batch_have_fg_mask"]
             use_arc2face_as_target = bool(fl["use_arc2face_as_target"])
             num_denoising_steps = int(fl["num_denoising_steps"])
@@ -1103,7 +1130,7 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if noise is None:
             noise = torch.randn_like(x_start)
         if cond is None:
-            cond = self.cond_fn(batch)
+            cond = yield _CondRequest(lambda b=batch: self.cond_fn(b))       # (the batch as trimmed above)
         if anneal_t and teacher_out is None:
             # every normal-recon iteration -- Arc2Face distillation included -- shifts t up by a random factor in [1, 1.3]
             # with an annealed probability BEFORE the multi-step shift (ddpm.py:2851-2866: the zero-shot and the default
@@ -1464,6 +1491,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                                   "arc2face_distill_iter_prob": self.arc2face_distill_iter_prob,
                                   "mix_prompt_distill_weight": self.mix_prompt_distill_weight,
                                   "max_num_denoising_steps": self.max_num_denoising_steps}
+            if getattr(tr, "lanes", None) is not None and self.manual_accumulate_grad_batches > 1 and not step_kwargs:
+                return self._training_step_in_windows(batch, batch_idx, tr, auto_iteration)
         if auto_iteration is not None:
             self._iteration_preamble(auto_iteration, step_kwargs)
         loss, grad, model_output, aux = self.shared_step(batch, **step_kwargs)
@@ -1472,6 +1501,91 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         if optimizer is not None and self.batch_idx % self.manual_accumulate_grad_batches == 0:
             self._optimizer_step(optimizer, reducer, scheduler)
         return loss, aux
+
+    # ---- Lightning's per-batch call on micro-batch lanes ---------------------------------------------------------------------
+    def _training_step_in_windows(self, batch, batch_idx, tr, auto_iteration):
+        """``training_step(batch, batch_idx)`` as Lightning calls it (ddpm.py:515), once per micro-batch, with a trainer that
+        runs accumulation windows on lanes (``adaprompt_amd.trainer.Trainer(micro_batch_lanes=True)``): the micro-batches of a
+        window are BUFFERED and the window runs -- ``training_window`` on ``tr.lanes``, F0 F1 B0 B1, step -- when its last one
+        arrives.  The call that completes a window returns that micro-batch's ``(loss, aux)`` with ``aux['window']`` =
+        [(loss, aux), ...] of all of them; the others return ``(None, {'deferred': True})``: their loss is deferred, nothing
+        else changes (iteration flags and RNG are drawn per micro-batch, in order, when the window runs).
+        ``tr.prefetch_windows`` = L > 0 additionally keeps L windows of batches buffered AHEAD of the one that runs, and their
+        VAE encodes go to the prefetch stream behind the running window's backwards (``LatentPrefetcher``): the encodes then
+        fill the window's tail and the optimiser step, where one lane alone leaves the chip idle.  The latent's posterior
+        noise is then drawn at submission time, i.e. earlier in the device RNG sequence than the sequential loop draws it.
+        ``flush_window()`` runs what is still buffered (an epoch's end)."""
+        n = int(self.manual_accumulate_grad_batches)
+        look = max(0, int(getattr(tr, "prefetch_windows", 0) or 0))
+        st = self.__dict__.setdefault("_win_entry", {"buf": [], "submitted": 0, "pf": None})
+        if not st["buf"] and self.batch_idx % n != 0:
+            # (the open window was started outside this entry: finish it on one stream first)
+            return self.training_step(batch, optimizer=tr.optimizer, reducer=tr.reducer, scheduler=tr.scheduler,
+                                      auto_iteration=auto_iteration)
+        st["buf"].append(batch)
+        if len(st["buf"]) < n * (look + 1):
+            return None, {"deferred": True}
+        out = self._run_buffered_window(tr, auto_iteration, look)
+        loss, aux = out[-1]
+        aux = dict(aux or {})
+        aux["window"] = out
+        return loss, aux
+
+    def _run_buffered_window(self, tr, auto_iteration, look):
+        n = int(self.manual_accumulate_grad_batches)
+        st = self._win_entry
+        buf = st["buf"]
+        window = buf[:n]
+        kwargs, after_backward = None, None
+        if look > 0:
+            if st["pf"] is None:
+                st["pf"] = self.make_prefetcher()
+            pf = st["pf"]
+            while st["submitted"] < min(len(buf), n * look):           # (the first windows: nothing is in flight yet)
+                pf.submit(buf[st["submitted"]])
+                st["submitted"] += 1
+
+            def kwargs(k):
+                return {"x_start": pf.get()}
+
+            def after_backward(k):
+                j = n * look + k
+                if j < len(buf) and st["submitted"] <= j:
+                    pf.submit(buf[j])
+                    st["submitted"] = j + 1
+        out = self.training_window(window, tr.optimizer, tr.reducer, tr.scheduler, tr.lanes, auto_iteration=auto_iteration,
+                                   step_kwargs=kwargs, after_backward=after_backward)
+        del buf[:n]
+        st["submitted"] = max(0, st["submitted"] - n)
+        return out
+
+    def flush_window(self, run=True):
+        """what ``training_step(batch, batch_idx)`` still holds buffered: whole windows run as windows, a partial one through
+        the one-stream step (``run=False``: drop it, e.g. ``max_steps`` reached).  -> [(loss, aux), ...]"""
+        st = self.__dict__.get("_win_entry")
+        tr = getattr(self, "trainer", None)
+        out = []
+        if not st or not st["buf"]:
+            return out
+        n = int(self.manual_accumulate_grad_batches)
+        auto = {"max_steps": tr.max_steps, "composition_regs_iter_gap": self.composition_regs_iter_gap,
+                "arc2face_distill_iter_prob": self.arc2face_distill_iter_prob,
+                "mix_prompt_distill_weight": self.mix_prompt_distill_weight,
+                "max_num_denoising_steps": self.max_num_denoising_steps}
+        look = max(0, int(getattr(tr, "prefetch_windows", 0) or 0))
+        while run and len(st["buf"]) >= n and self.batch_idx % n == 0:
+            out += self._run_buffered_window(tr, auto, look)
+        pf = st["pf"]
+        for b in list(st["buf"]):
+            kw = {}
+            if st["submitted"] > 0:
+                kw["x_start"] = pf.get()                    # (drained either way: the queue must not leak into a later epoch)
+                st["submitted"] -= 1
+            if run:
+                out.append(self.training_step(b, optimizer=tr.optimizer, reducer=tr.reducer, scheduler=tr.scheduler,
+                                              auto_iteration=auto, **kw))
+        st["buf"].clear()
+        return out
 
     def _iteration_preamble(self, auto_iteration, step_kwargs):
         """the reference's ``training_step`` preamble (ddpm.py:516-572, 1839-1859): training_percent, the iteration type."""
@@ -1557,8 +1671,6 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             "training_window: one whole accumulation window, starting on a window border"
         if lanes is not None and any(p.requires_grad for p in self.model.parameters()):
             lanes = None               # the UNet's own gradients are written through raw pointers during the whole backward
-        if lanes is not None and self.cond_fn is None and not self._window_has_conds(step_kwargs, len(batches)):
-            lanes = None               # the conditioning side runs inside shared_step: it cannot be kept on lane 0 (see below)
         if fuse is None:
             env = os.environ.get("ADAP_WINDOW_FUSE")
             fuse = (lanes is None and torch.cuda.is_available()) if env is None else env != "0"
@@ -1597,13 +1709,6 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             if gn_owner_was is not None:
                 ops.set_gn_single_launch_stream(*gn_owner_was)
 
-    @staticmethod
-    def _window_has_conds(step_kwargs, n):
-        if callable(step_kwargs) or step_kwargs is None:
-            return False
-        kws = step_kwargs if isinstance(step_kwargs, (list, tuple)) else [step_kwargs] * n
-        return all(isinstance(kw, dict) and kw.get("cond") is not None for kw in kws)
-
     def _window_kwargs(self, k, step_kwargs, auto_iteration, cond=None):
         """micro-batch k's ``shared_step`` arguments: the caller's (a callable is evaluated NOW: RNG draws, a prefetched latent),
         then the iteration-type draw -- once per micro-batch, in order, as in the sequential loop."""
@@ -1622,6 +1727,9 @@ class LatentDiffusion(ConditioningMixin, DDPM):
 
     _FUSE_FLAGS = ("use_layerwise_context", "use_conv_attn_kernel_size", "iter_type", "is_training", "capture_distill_attn",
                    "capture_token_maps_only", "debug_attn")
+    _FUSE_MERGED = ("img_mask", "subj_indices", "bg_indices", "placeholder2indices")     # concatenated / shifted onto the merged batch
+    # read by the micro-batch's OWN losses after the pass (never by the UNet), or written by the pass and sliced back
+    _FUSE_PER_REQUEST = ("c_static_emb_4b", "prompt_emb_mask", "ca_layers_activations", "ca_tokmap_weights", "reg_tokmap_grads")
 
     def _denoise_fusable(self, reqs):
         """can these ``guided_denoise`` requests (x_start, noise, t, (c_emb, c_in, extra_info)) go through the UNet as one batch?"""
@@ -1635,6 +1743,18 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                 return False
             if any((ei.get(f) is None) != (e0.get(f) is None) for f in ("img_mask", "subj_indices", "bg_indices")):
                 return False
+            # whatever else the conditioning side put there must be the SAME for all requests (it is carried into the merged
+            # pass as is): a key that differs -- or that only some requests have -- would be dropped or applied to the wrong rows
+            for f in set(ei) | set(e0):
+                if f in self._FUSE_FLAGS or f in self._FUSE_MERGED or f in self._FUSE_PER_REQUEST:
+                    continue
+                a, b = ei.get(f), e0.get(f)
+                if a is b:
+                    continue
+                if torch.is_tensor(a) or torch.is_tensor(b) or isinstance(a, (dict, list, tuple)) or isinstance(b, (dict, list, tuple)):
+                    return False                   # (not the same object: a per-request payload this pass does not know how to merge)
+                if a != b:
+                    return False
         return True
 
     def _denoise_fused(self, reqs):
@@ -1645,8 +1765,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         sizes = [r[0].shape[0] for r in reqs]
         offs = [sum(sizes[:k]) for k in range(len(sizes))]
         eis = [r[3][2] for r in reqs]
-        ei = {f: eis[0][f] for f in self._FUSE_FLAGS if f in eis[0]}
-        ei["placeholder2indices"] = None
+        ei = {f: v for f, v in eis[0].items() if f not in self._FUSE_MERGED and f not in self._FUSE_PER_REQUEST}
+        ei["placeholder2indices"] = None           # (flags and the common remainder, equal for all requests: _denoise_fusable)
         if eis[0].get("img_mask") is not None:
             ei["img_mask"] = torch.cat([e["img_mask"] for e in eis])
         for f in ("subj_indices", "bg_indices"):
@@ -1695,10 +1815,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                 return {0: kw}
             if self._is_plain_recon(kw):
                 gens[k] = self._shared_step_gen(batch, **kw)
-                try:
-                    reqs[k] = next(gens[k])
-                except StopIteration as done:          # (the front decided on an iteration type that runs its own passes)
-                    results[k] = done.value
+                # (a front that decides on an iteration type that runs its own passes finishes here: no request)
+                reqs[k], results[k] = self._resume(gens[k], None)
             else:
                 # a distillation micro-batch behind recon ones: what is pending is served first, then this one runs by itself
                 self._serve_requests(gens, reqs, results)
@@ -1734,44 +1852,80 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         outs = self._denoise_fused(batch) if len(batch) > 1 and self._denoise_fusable(batch) else \
             [self.guided_denoise(*r) for r in batch]
         for k, o in zip(pending, outs):
-            try:
-                gens[k].send(o)
-            except StopIteration as done:
-                results[k] = done.value
-            else:
+            again, results[k] = self._resume(gens[k], o)
+            if again is not None:
                 raise RuntimeError("training_window: a second denoising request")
 
     def _training_window(self, batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward, contextlib,
                          after_backward=None, pre_kws=None):
-        # THIRD-PARTY KERNELS STAY ON LANE 0.  The conditioning side (the hook: SubjBasisGenerator / CLIP behind ``cond_fn``) runs
-        # vendor GEMMs; hipBLASLt's stream-K kernels wait inside the launch for partial tiles of their other workgroups, and two
-        # of them in flight on two streams (the two lanes' hook forwards start within a millisecond of each other) were seen to
-        # wait for ever (rocgdb: every wave at ``label_SK_Fixup``; profiles/r04_streams.md).  So every micro-batch's conditioning
-        # is computed on lane 0, one after the other, BEFORE the window's lanes start; its backward then also runs on lane 0
+        # The host order is the sequential loop's, micro-batch by micro-batch: preamble (iteration flags, host RNG), the front of
+        # ``shared_step`` (latent, trimming, t / noise draws), the conditioning, the timestep annealing -- and only the UNet
+        # passes of the plain recon micro-batches (the generator's denoising requests) are held back until every micro-batch's
+        # conditioning has been issued.
+        # THIRD-PARTY KERNELS STAY ON LANE 0.  The conditioning side (the hook: SubjBasisGenerator / CLIP behind ``cond_fn``, or
+        # the yaml-instantiated text encoder + embedding manager) runs vendor GEMMs; hipBLASLt's stream-K kernels wait inside
+        # the launch for partial tiles of their other workgroups, and two of them in flight on two streams (the two lanes' hook
+        # forwards start within a millisecond of each other) were seen to wait for ever (rocgdb: every wave at
+        # ``label_SK_Fixup``; profiles/r04_streams.md).  So every micro-batch's conditioning REQUEST (``_CondRequest``) is
+        # served on lane 0, one after the other, in front of lane 0's own UNet pass; its backward then also runs on lane 0
         # (autograd issues a node's backward on its forward's stream), in micro-batch order.  Beside lane 0's vendor kernels
-        # only this package's own non-waiting kernels run (lane k >= 1 never takes the single-launch GroupNorm).
-        conds = [None] * len(batches)
-        if lanes is not None and self.cond_fn is not None:
-            for k, batch in enumerate(batches):
-                conds[k] = self.cond_fn(batch)
-                if k > 0:
-                    lanes.hold(conds[k], k)
-            lanes.window_start()
-        fronts = []
+        # only this package's own non-waiting kernels run.  A compositional micro-batch (text encoder, CLIP scoring and
+        # decoder inside its own passes) runs on lane 0 as a whole.
+        n = len(batches)
+        gens, reqs, fronts, snaps, lane_of = [None] * n, [None] * n, [None] * n, [None] * n, list(range(n))
+
+        def on_lane(k, closing=False):
+            if lanes is None:
+                return contextlib.nullcontext()
+            return lanes.micro_batch(k, closing=closing, lane=lane_of[k])
+
+        def cond_server(k):
+            if lanes is None or lane_of[k] % len(lanes.streams) == 0:
+                return None                                   # in place: this micro-batch runs on lane 0 anyway
+            lane = lanes.streams[lane_of[k] % len(lanes.streams)]
+
+            def serve(req):
+                ev = torch.cuda.Event()
+                ev.record(lane)                               # (what the front made on lane k and the request may read)
+                lanes.main.wait_event(ev)
+                with torch.cuda.stream(lanes.main):
+                    cond = req.make()
+                    ev = torch.cuda.Event()
+                    ev.record(lanes.main)
+                lanes.hold(cond, lane_of[k])
+                lane.wait_event(ev)
+                return cond
+            return serve
+
         for k, batch in enumerate(batches):
-            with (lanes.micro_batch(k) if lanes is not None else contextlib.nullcontext()):
+            with on_lane(k):
                 if pre_kws is not None and k in pre_kws:          # (already evaluated by the fused attempt: not twice)
                     kw = pre_kws[k]
-                    if conds[k] is not None and kw.get("cond") is None:
-                        kw["cond"] = conds[k]
                 else:
-                    kw = self._window_kwargs(k, step_kwargs, auto_iteration, conds[k])
-                fronts.append(self.shared_step(batch, **kw))
-                if after_forward is not None:
+                    kw = self._window_kwargs(k, step_kwargs, auto_iteration)
+            if lanes is not None and k > 0 and auto_iteration is not None and self.iter_flags.get("is_compos_iter"):
+                lanes.main.wait_stream(lanes.streams[k % len(lanes.streams)])     # (what evaluating the kwargs queued there)
+                lane_of[k] = 0
+            with on_lane(k):
+                snaps[k] = (self.iter_flags, getattr(self, "training_percent", 0.0))
+                gens[k] = self._shared_step_gen(batch, **kw)
+                reqs[k], fronts[k] = self._resume(gens[k], None, cond_server(k))
+                if reqs[k] is None and after_forward is not None:          # (an iteration that ran its own passes: issued)
                     after_forward(k)
             self.batch_idx += 1
+        for k in range(n):
+            if reqs[k] is None:
+                continue
+            with on_lane(k):
+                self.iter_flags, self.training_percent = snaps[k]
+                again, fronts[k] = self._resume(gens[k], self.guided_denoise(*reqs[k]), cond_server(k))
+                if again is not None:
+                    raise RuntimeError("training_window: a second denoising request")
+                if after_forward is not None:
+                    after_forward(k)
+        self.iter_flags, self.training_percent = snaps[-1]
         for k, (loss, grad, model_output, aux) in enumerate(fronts):
-            with (lanes.micro_batch(k, closing=True) if lanes is not None else contextlib.nullcontext()):
+            with on_lane(k, closing=True):
                 self._micro_batch_backward(model_output, grad, aux, reducer, lanes)
                 if after_backward is not None:
                     after_backward(k)
@@ -1808,6 +1962,7 @@ class MicroBatchLanes:
             self.streams = [self.main] + [lane_stream(k) for k in range(1, n)]
         self.reducer = reducer
         self._prev_done = None
+        self._gated, self._gate_ev = set(), None
         # Every stream this process will use takes its hardware queue NOW, in a fixed order -- the lanes, then each lane's block
         # side lane (functional.side_lane; suspended while the lanes run, used by every other leg of a process).  Which streams
         # end up sharing a queue depends on the order of their first use, and the order "lanes first, side lanes whenever a later
@@ -1829,30 +1984,49 @@ class MicroBatchLanes:
             [p.register_hook(self._gate) for p in params if p.requires_grad]
         # autograd accumulates a leaf's gradient on the stream its AccumulateGrad node was created on (lane 0's, typically),
         # synchronised with the producing lane: intended here, and ordered by the gate
-        warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-        if warn_off is not None:
-            warn_off(False)
+        self._warn_set = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if self._warn_set is not None:
+            self._warn_set(False)
 
     def _gate(self, g):
-        ev = self._prev_done
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+        """in front of every accumulation into a trainable ``.grad``: the accumulating stream -- WHICHEVER it is; a gradient
+        produced from conditioning made on another stream arrives on that stream -- waits for the previous micro-batch's
+        backward and, under data parallelism, for its all-reduce.  The first gate of a backward consumes the exchange
+        (``GradReducer.wait`` is one-shot: it also applies gloo's 1/world scale) and records ONE event behind it; every
+        other stream that reaches a gate in the same backward waits for that event."""
+        prev = self._prev_done
+        if prev is None:
+            return g
+        s = torch.cuda.current_stream()
+        key = s.cuda_stream
+        if key in self._gated:
+            return g
+        if self._gate_ev is None:
+            s.wait_event(prev)
             if self.reducer is not None:
                 self.reducer.wait()
+            self._gate_ev = torch.cuda.Event()
+            self._gate_ev.record(s)
+        else:
+            s.wait_event(self._gate_ev)
+        self._gated.add(key)
         return g
 
-    def micro_batch(self, k, closing=False):
-        """context: the stream of the window's k-th micro-batch.  ``closing``: this context issues the micro-batch's backward;
-        on exit its end is the event the next micro-batch's accumulation waits for."""
+    def micro_batch(self, k, closing=False, lane=None):
+        """context: the stream of the window's k-th micro-batch (``lane``: run it on that lane instead of lane k).
+        ``closing``: this context issues the micro-batch's backward; on exit its end is the event the next micro-batch's
+        accumulation waits for."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
-            s = self.streams[k % len(self.streams)]
+            s = self.streams[(k if lane is None else lane) % len(self.streams)]
             if s is not self.main and not closing:
                 s.wait_event(self._window)
-            if closing and k == 0:
-                self._prev_done = None                 # (the optimiser step on lane 0 ordered everything before this window)
+            if closing:
+                self._gated, self._gate_ev = set(), None
+                if k == 0:
+                    self._prev_done = None             # (the optimiser step on lane 0 ordered everything before this window)
             with torch.cuda.stream(s):
                 yield s
                 if closing:
@@ -1886,9 +2060,13 @@ class MicroBatchLanes:
         self._window.record(self.main)
 
     def remove(self):
+        """take the gates off the parameters and give autograd its stream-mismatch warning back (process-wide setting)."""
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._warn_set is not None:
+            self._warn_set(True)
+            self._warn_set = None
 
 
 _PREFETCH_STREAMS = {}

@@ -116,13 +116,16 @@ class Prodigy(FlatParams, torch.optim.Optimizer):
                                    "values of 0")
         st, ws, s = self._state.data_ptr(), self._ws.data_ptr(), _stream()
         self._clip(clip_norm)
-        active = [i for i, g in enumerate(self.param_groups) if g["lr"] > 0.0 and self._ranges[i][1] > 0]
+        # frozen (requires_grad=False) tensors of a group lie behind its stepped span (flatopt ``_train_ranges``): the reference
+        # skips parameters without a gradient (prodigy.py:160 ``if p.grad is None: continue``) -- no decay, no moments
+        self._check_layout()
+        active = [i for i, g in enumerate(self.param_groups) if g["lr"] > 0.0 and self._train_ranges[i][1] > 0]
         if not active:                               # every d_denom term is absent: prodigy.py:200-201
             return loss
         ubc = int(bool(g0["use_bias_correction"]))
         for slot, gi in enumerate(active):
             g = self.param_groups[gi]
-            o, k = self._ranges[gi]
+            o, k = self._train_ranges[gi]
             coupled = float(g["weight_decay"]) if (g["weight_decay"] != 0 and not g0["decouple"]) else 0.0
             _lib.call("adap_prodigy_moments", self._flat[o:].data_ptr(), self._p0[o:].data_ptr(),
                       self._grad[o:].data_ptr(), self._m[o:].data_ptr(), self._v[o:].data_ptr(),
@@ -131,7 +134,7 @@ class Prodigy(FlatParams, torch.optim.Optimizer):
         _lib.call("adap_prodigy_finish", st, ws, len(active), float(lr), float(beta1), float(beta2), float(beta3),
                   float(self.d0), float(g0["d_coef"]), float(g0["growth_rate"]), ubc, s)
         for gi, g in enumerate(self.param_groups):   # second loop of the reference runs over ALL groups
-            o, k = self._ranges[gi]
+            o, k = self._train_ranges[gi]
             if k == 0:
                 continue
             dec = float(g["weight_decay"]) if (g["weight_decay"] != 0 and g0["decouple"]) else 0.0

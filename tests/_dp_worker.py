@@ -51,11 +51,65 @@ def micro_batch(rank, mb, dev):
     return batch, dict(t=t.to(dev), noise=noise.to(dev), x_start=x0.to(dev))
 
 
+def lanes_main(rank, world, dev):
+    """ADAP_DP_MODE=lanes: the SHIPPED mode under data parallelism -- two accumulation windows through
+    ``training_window`` on two micro-batch lanes with the exchange inside the lanes' gate (``MicroBatchLanes(reducer=...)``) --
+    against the hand-averaged sequential loop: per window, the gradients of BOTH ranks' micro-batches at the window's weights,
+    mean over ranks, summed over the window, clip + Prodigy step (main.py:829; ddpm.py:591-633)."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import MicroBatchLanes
+    from adaprompt_amd.parallel import GradReducer
+    ld, hook, params, opt = build(dev, seed=3)
+    red = GradReducer(params, flat=opt.grad_buffer)
+    assert red.world == world
+    lanes = MicroBatchLanes(params, n=2, reducer=red)
+    losses = []
+    for w in range(2):
+        mbs = [micro_batch(rank, 2 * w + k, dev) for k in range(2)]
+        out = ld.training_window([b for b, _ in mbs], opt, red, None, lanes, step_kwargs=[kw for _, kw in mbs])
+        losses += [float(o[0]) for o in out]
+    red.wait()
+    torch.cuda.synchronize()
+    lanes.remove()
+    dp = torch.cat([p.detach().flatten() for p in params]).clone()
+    d_dp = opt.device_state()["d"]
+    ld2, hook2, params2, opt2 = build(dev, seed=3)
+    ref_losses = []
+    for w in range(2):
+        acc = torch.zeros_like(opt2.grad_buffer)
+        for k in range(2):
+            for r in range(world):
+                batch, kw = micro_batch(r, 2 * w + k, dev)
+                opt2.grad_buffer.zero_()
+                loss, grad, out, aux = ld2.shared_step(batch, **kw)
+                ld2.manual_backward(out, grad, aux)
+                acc += opt2.grad_buffer / world
+                if r == rank:
+                    ref_losses.append(float(loss))
+        opt2.grad_buffer.copy_(acc)
+        opt2.step(clip_norm=ld2.grad_clip)
+        opt2.grad_buffer.zero_()
+    torch.cuda.synchronize()
+    ref = torch.cat([p.detach().flatten() for p in params2])
+    init = torch.cat([p.detach().flatten() for p in build(dev, seed=3)[2]])
+    both = [torch.zeros_like(dp) for _ in range(world)]
+    dist.all_gather(both, dp)
+    print("DPRESULT " + json.dumps({
+        "rank": rank, "backend": dist.get_backend(), "device": str(dev), "mode": "lanes", "moved": float((ref - init).norm()),
+        "rel_err_vs_hand_averaged": float((dp - ref).norm() / (ref - init).norm()),
+        "replicas_identical": bool(torch.equal(both[0], both[1])),
+        "grad_buffer_zeroed": float(opt.grad_buffer.abs().max()) == 0.0,
+        "losses": losses, "ref_losses": ref_losses, "d": d_dp, "ref_d": opt2.device_state()["d"],
+        "optimizer_steps": opt.device_state()["k"], "bytes_per_reduce": red.bytes_per_reduce}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     from adaprompt_amd.parallel import GradReducer, init_distributed
     rank, world, local = init_distributed()
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    if os.environ.get("ADAP_DP_MODE") == "lanes":
+        return lanes_main(rank, world, dev)
     # ---- data parallel: each rank its own micro-batches, exchange after every backward
     ld, hook, params, opt = build(dev, seed=3)
     red = GradReducer(params, flat=opt.grad_buffer)

@@ -471,3 +471,113 @@ def test_hostinfo_cpu_share_reads_the_cgroup_quota(tmp_path):
         assert hostinfo.limit_torch_threads(cap=1) == 1 and torch.get_num_threads() == 1
     finally:
         torch.set_num_threads(before)
+
+
+def test_trainer_fit_window_loop_host_logic():
+    """``Trainer.fit`` = Lightning's loop over ``training_step(batch, batch_idx)``; on lanes that entry buffers a window's
+    micro-batches (``_training_step_in_windows``), optionally with windows of latents prefetched ahead, and ``flush_window``
+    finishes an epoch.  Host logic only (the window itself is a stub): partial windows, ``max_steps``, checkpoint cadence,
+    every batch encoded / consumed / logged exactly once and in order, the lanes' gates removed at the end."""
+    from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaprompt_amd.trainer import Trainer
+
+    class FakePrefetcher:
+        def __init__(self, log):
+            self.q, self.log = [], log
+
+        def submit(self, batch, post_noise=None):
+            self.log.append(("submit", batch["i"]))
+            self.q.append(batch["i"])
+
+        def get(self):
+            self.log.append(("get", self.q[0]))
+            return self.q.pop(0)
+
+    class Lanes:
+        removed = False
+
+        def remove(self):
+            self.removed = True
+
+    class Stub:
+        manual_accumulate_grad_batches = 2
+        composition_regs_iter_gap = arc2face_distill_iter_prob = mix_prompt_distill_weight = 0
+        max_num_denoising_steps = 1
+        training_step = LatentDiffusion.training_step
+        _training_step_in_windows = LatentDiffusion._training_step_in_windows
+        _run_buffered_window = LatentDiffusion._run_buffered_window
+        flush_window = LatentDiffusion.flush_window
+
+        def __init__(self):
+            self.batch_idx, self.log, self.saves, self.steps = 0, [], [], 0
+
+        @property
+        def global_step(self):
+            return self.batch_idx // self.manual_accumulate_grad_batches
+
+        def make_prefetcher(self):
+            return FakePrefetcher(self.log)
+
+        def training_window(self, batches, optimizer, reducer, scheduler, lanes, auto_iteration=None, step_kwargs=None,
+                            after_backward=None):
+            assert self.batch_idx % 2 == 0 and len(batches) == 2 and lanes is not None and auto_iteration["max_steps"] > 0
+            got = [step_kwargs(k)["x_start"] if step_kwargs is not None else None for k in range(2)]
+            self.log.append(("window", [b["i"] for b in batches], got))
+            self.batch_idx += 2
+            self.steps += 1
+            if after_backward is not None:
+                for k in range(2):
+                    after_backward(k)
+            return [(float(b["i"]), {}) for b in batches]
+
+        def _iteration_preamble(self, auto, kw):
+            pass
+
+        def shared_step(self, batch, **kw):
+            self.log.append(("single", batch["i"], kw.get("x_start")))
+            return float(batch["i"]), None, None, {}
+
+        def _micro_batch_backward(self, *a, **k):
+            pass
+
+        def _optimizer_step(self, *a):
+            self.steps += 1
+
+        def on_save_checkpoint(self, ckpt):
+            self.saves.append(self.global_step)
+
+    def fit(n_batches, max_steps, look, every=2):
+        m, lanes = Stub(), Lanes()
+        tr = Trainer(max_steps=max_steps, every_n_train_steps=every, micro_batch_lanes=True, prefetch_windows=look)
+        tr.optimizer = type("O", (), {"param_groups": []})()
+        tr.lanes = lanes
+        object.__setattr__(m, "trainer", tr)
+        import adaprompt_amd.ops as ops_mod
+        was, ops_mod.gn_sync_poisoned = ops_mod.gn_sync_poisoned, lambda: False          # (save_checkpoint's device read)
+        try:
+            logged = tr.fit(m, ({"i": i} for i in range(n_batches)))
+        finally:
+            ops_mod.gn_sync_poisoned = was
+        assert lanes.removed and tr.lanes is None
+        return m, logged
+
+    # no prefetch: windows as their last micro-batch arrives, the odd tail on one stream, window left open
+    m, logged = fit(7, 10, 0)
+    assert logged == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0] and m.batch_idx == 7 and m.steps == 3
+    assert [e for e in m.log if e[0] != "single"] == [("window", [0, 1], [None, None]), ("window", [2, 3], [None, None]),
+                                                        ("window", [4, 5], [None, None])]
+    assert m.log[-1] == ("single", 6, None) and m.saves == [2]
+    # one window of latents ahead: every batch submitted once, in order, each window consumes ITS latents
+    m, logged = fit(7, 10, 1)
+    assert logged == [float(i) for i in range(7)] and m.batch_idx == 7
+    assert [e[1] for e in m.log if e[0] == "submit"] == list(range(7))
+    wins = [e for e in m.log if e[0] == "window"]
+    assert wins == [("window", [0, 1], [0, 1]), ("window", [2, 3], [2, 3]), ("window", [4, 5], [4, 5])]
+    assert m.log[-1] == ("single", 6, 6)                   # (the tail's latent was prefetched behind the last window too)
+    # the encodes of window w+1 are submitted behind window w's backwards, not before it
+    i_w0 = m.log.index(wins[0])
+    assert ("submit", 2) in m.log[i_w0:] and ("submit", 2) not in m.log[:i_w0]
+    # max_steps reached with batches still buffered: they are dropped, the prefetch queue is drained
+    m, logged = fit(9, 2, 1, every=1)
+    assert m.global_step == 2 and logged == [0.0, 1.0, 2.0, 3.0] and m.saves == [1, 2]
+    assert not m._win_entry["buf"] and not m._win_entry["pf"].q and m._win_entry["submitted"] == 0

@@ -22,9 +22,7 @@ def _reducer_backends():
     return ["torch", "c_abi"] if torch.cuda.device_count() >= 2 else ["torch"]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("reducer_backend", _reducer_backends())
-def test_training_step_two_ranks_matches_hand_averaged_step(reducer_backend):
+def _run_two_ranks(reducer_backend, mode=None):
     ndev = torch.cuda.device_count()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -39,6 +37,11 @@ def test_training_step_two_ranks_matches_hand_averaged_step(reducer_backend):
             env["ADAP_GN_TWO_PASS"] = "1"
         if reducer_backend == "c_abi":
             env["ADAP_REDUCER_BACKEND"] = "c_abi"
+        if mode is not None:
+            env["ADAP_DP_MODE"] = mode
+            # the comparison is about ORDER (streams, gate, exchange), so the kernels are held to the forms that do not depend
+            # on the lane: two-pass GroupNorm everywhere, the lone-stream split-K plans under lanes
+            env.update(ADAP_GN_TWO_PASS="1", ADAP_LANES_KSPLIT_SCALE="100")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
@@ -48,9 +51,32 @@ def test_training_step_two_ranks_matches_hand_averaged_step(reducer_backend):
     assert len(res) == 2
     for r in res:
         assert r["backend"] == ("nccl" if ndev >= 2 else "gloo")
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reducer_backend", _reducer_backends())
+def test_training_step_two_ranks_matches_hand_averaged_step(reducer_backend):
+    for r in _run_two_ranks(reducer_backend):
         assert r["replicas_identical"] and r["grad_buffer_zeroed"] and r["moved"] > 0
         # same gradients, summed in a different order (ranks in parallel vs one after the other): f32 round-off only
         assert r["rel_err_vs_hand_averaged"] < 1e-4, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reducer_backend", _reducer_backends())
+def test_training_window_on_lanes_two_ranks_matches_hand_averaged_windows(reducer_backend):
+    """the mode that produces the headline -- ``training_window`` on ``MicroBatchLanes(params, n=2,
+    reducer=...)``: F0 F1 B0 B1 on two streams, micro-batch 0's all-reduce in flight while micro-batch 1's backward runs, the
+    wait inside the lanes' gate in front of the accumulation -- on two ranks (one card over gloo; RCCL through torch and through
+    the library's own communicator when the box has two devices), two windows, against the hand-averaged sequential loop."""
+    for r in _run_two_ranks(reducer_backend, mode="lanes"):
+        assert r["mode"] == "lanes" and r["optimizer_steps"] == 2
+        assert r["replicas_identical"] and r["grad_buffer_zeroed"] and r["moved"] > 0
+        assert r["rel_err_vs_hand_averaged"] < 1e-4, r
+        assert abs(r["d"] - r["ref_d"]) <= 1e-5 * abs(r["ref_d"]), r
+        for a, b in zip(r["losses"], r["ref_losses"]):
+            assert abs(a - b) <= 1e-5 * abs(b), r
 
 
 @pytest.mark.gpu
