@@ -72,7 +72,8 @@ struct AttnParams {
                                 // of the matrix core in the exp2 domain and, with the reference point / -lse as the accumulator's
                                 // initial value, go into v_exp_f32 as they are -- one VALU instruction per score less
     int qsplit;                 // dK/dV kernel: the query range is cut into qsplit slices (blockIdx.z), f32 partials
-    int xcd;                    // 1: the workgroups of one (batch, head) -- and of neighbouring heads -- share an XCD (attn_wg_coords)
+    int xcd;                    // bit 0 / 1 / 2 (forward / dQ / dK,dV kernel): the workgroups of one (batch, head) -- and of
+                                // neighbouring heads -- share an XCD (attn_wg_coords)
     float* part;                // [qsplit][2][B*M][H*d] when qsplit > 1
     // gradient of the cross-attention token maps folded into this backward (adap_attention_bwd_tok): dq += scale * dT . kw,
     // dk += scale * w . gq, with kw = w^T K and gq = dT^T Q from adap_attention_tokmap_prep
@@ -100,9 +101,9 @@ __device__ __forceinline__ int attn_key_count(const AttnParams& p, int b) {
 // row's workgroups share are fetched into one L2, and rows that run side by side on an XCD are neighbouring heads of one sample
 // -- their 80-byte head slices of a token's row share 128-byte lines (a head alone touches 1.5 lines per 80 bytes).
 // Placement only changes speed; B*H not a multiple of 8 keeps the plain map.
-__device__ __forceinline__ void attn_wg_coords(const AttnParams& p, int& bx, int& bh, int& bz) {
+__device__ __forceinline__ void attn_wg_coords(const AttnParams& p, int which, int& bx, int& bh, int& bz) {
     const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-    if (!p.xcd || (gy & 7u)) { bx = blockIdx.x; bh = blockIdx.y; bz = blockIdx.z; return; }
+    if (!(p.xcd & which) || (gy & 7u)) { bx = blockIdx.x; bh = blockIdx.y; bz = blockIdx.z; return; }
     const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const unsigned grp = L & 7u, slot = L >> 3, per = gx * gz;
     const unsigned row = slot / per, r = slot - row * per;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     int bx, bh, bz_;
-    attn_wg_coords(p, bx, bh, bz_);
+    attn_wg_coords(p, 1, bx, bh, bz_);
     const int b = bh / p.H, head = bh - b * p.H;
     const int q0 = bx * (128 * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pp_kernel(AttnParams p) {
     const int grp = wave >> 2;                          // 0: waves 0-3, 1: waves 4-7 (the SIMD partners), half a tile behind
     const int c = lane & 31, h = lane >> 5;
     int bx, bh, bz_;
-    attn_wg_coords(p, bx, bh, bz_);
+    attn_wg_coords(p, 1, bx, bh, bz_);
     const int b = bh / p.H, head = bh - b * p.H;
     const int q0 = bx * 512 + wave * 64 + c;    // query of block qb: q0 + 32 * qb
     const int d = p.d;
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(64 * NW, (QB == 1 && NW == 4) ? 2 : 1) void attn_fw
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     int bx, bh, bz_;
-    attn_wg_coords(p, bx, bh, bz_);
+    attn_wg_coords(p, 1, bx, bh, bz_);
     const int b = bh / p.H, head = bh - b * p.H;
     const int q0 = bx * (32 * NW * QB) + wave * (32 * QB) + c;      // query of block qb: q0 + 32 * qb
     const int d = p.d;
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     int bx, bh, bz_;
-    attn_wg_coords(p, bx, bh, bz_);
+    attn_wg_coords(p, 2, bx, bh, bz_);
     const int b = bh / p.H, head = bh - b * p.H;
     const int q = bx * 128 + wave * 32 + c;
     const int d = p.d;
@@ -1257,7 +1258,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     int bx, bh, bz;
-    attn_wg_coords(p, bx, bh, bz);
+    attn_wg_coords(p, 4, bx, bh, bz);
     const int b = bh / p.H, head = bh - b * p.H;
     // Which 128 keys: rotated by the (batch, head) row.  With a key count the workgroups of the LAST key blocks have nothing to
     // do; workgroups are placed round-robin over the CUs in launch order, and with 32 key blocks per row an unrotated map puts
@@ -1504,7 +1505,7 @@ struct AttnDebug {
     int pp_prio;      // ping-pong kernel: phase at raised priority, 1 = matrix (default), 2 = vector, 0 = neither
     int qb1;          // 1 = one query block per wave even at the 64 x 64 level
     int dkv_qsplit;   // 0 = heuristic, else the dK/dV kernel's query-split factor
-    int xcd;          // AttnParams::xcd (ADAP_ATTN_XCD=0: the plain blockIdx map, for A/B runs)
+    int xcd;          // AttnParams::xcd bits (ADAP_ATTN_XCD=0: the plain blockIdx map everywhere, for A/B runs)
 };
 static AttnDebug& attn_debug() {
     static AttnDebug d = [] {
@@ -1518,7 +1519,7 @@ static AttnDebug& attn_debug() {
         e = getenv("ADAP_ATTN_DKV_QSPLIT");
         v.dkv_qsplit = e ? atoi(e) : 0;
         e = getenv("ADAP_ATTN_XCD");
-        v.xcd = e ? atoi(e) : 1;
+        v.xcd = e ? atoi(e) : 7;
         return v;
     }();
     return d;

@@ -174,18 +174,21 @@ extern "C" int adap_stblock_fwd(const int* cfg, const void* const* w, void* cons
     float *lse1 = lse, *lse2 = lse + (size_t)B * heads * N;
     uint16_t *xn = scr, *nn = scr + rc_, *gg = scr + 2 * rc_, *t3 = scr + 6 * rc_;
     int rc;
-    // side lane: the cross-attention K/V projection of the context tokens (k | v halves of one [B, M, 2C] tensor)
-    if (lane) ST_TRY(hand_over(stream, lane));
-    if (same_ctx) {
-        ST_TRY(lin(ctx_k, 0, Cctx, w[ADAP_STW_KV2], nullptr, nullptr, nullptr, kv2, 2 * C, crows, Cctx, 2 * C, sk_side, side));
-    } else {
-        ST_TRY(lin(ctx_k, 0, Cctx, w[ADAP_STW_KV2], nullptr, nullptr, nullptr, kv2, 2 * C, crows, Cctx, C, sk_side, side));
-        ST_TRY(lin(ctx_v, 0, Cctx, w[ADAP_STW_V2], nullptr, nullptr, nullptr, kv2 + C, 2 * C, crows, Cctx, C, sk_side, side));
-    }
+    // side lane: the cross-attention K/V projection of the context tokens (k | v halves of one [B, M, 2C] tensor) -- unless the
+    // caller made it already (ADAP_STB_KV_GIVEN: the layers' projections hoisted in front of the UNet as batched launches)
     hipEvent_t kv_ready = nullptr;
-    if (lane) {
-        kv_ready = next_event();
-        ADAP_REQUIRE(kv_ready && hipEventRecord(kv_ready, (hipStream_t)lane) == hipSuccess, ADAP_ERR_HIP, "stblock_fwd: event");
+    if (!(flags & ADAP_STB_KV_GIVEN)) {
+        if (lane) ST_TRY(hand_over(stream, lane));
+        if (same_ctx) {
+            ST_TRY(lin(ctx_k, 0, Cctx, w[ADAP_STW_KV2], nullptr, nullptr, nullptr, kv2, 2 * C, crows, Cctx, 2 * C, sk_side, side));
+        } else {
+            ST_TRY(lin(ctx_k, 0, Cctx, w[ADAP_STW_KV2], nullptr, nullptr, nullptr, kv2, 2 * C, crows, Cctx, C, sk_side, side));
+            ST_TRY(lin(ctx_v, 0, Cctx, w[ADAP_STW_V2], nullptr, nullptr, nullptr, kv2 + C, 2 * C, crows, Cctx, C, sk_side, side));
+        }
+        if (lane) {
+            kv_ready = next_event();
+            ADAP_REQUIRE(kv_ready && hipEventRecord(kv_ready, (hipStream_t)lane) == hipSuccess, ADAP_ERR_HIP, "stblock_fwd: event");
+        }
     }
     // main chain
     ST_TRY(adap_groupnorm_fwd(x, 0, C, (const float*)w[ADAP_STW_GN_G], (const float*)w[ADAP_STW_GN_B], nullptr, 0, xn, C, gn_stats,

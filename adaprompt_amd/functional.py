@@ -483,8 +483,8 @@ STBLOCK_C = os.environ.get("ADAP_STBLOCK_C", "1") != "0"
 STB_CALLS = [0, 0, 0]                  # forward / backward calls that took the C path, backward calls that skipped the input gradient
 _STB_WS = {}
 # include/adaprompt_hip.h: ADAP_STB_* flags
-_STB_SAME_CTX, _STB_COMPACT, _STB_CAPTURE, _STB_Q1_PRESCALED, _STB_TOKGRAD, _STB_WANT_GK, _STB_WANT_GV, _STB_G_BF16, _STB_NO_GX = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256
+_STB_SAME_CTX, _STB_COMPACT, _STB_CAPTURE, _STB_Q1_PRESCALED, _STB_TOKGRAD, _STB_WANT_GK, _STB_WANT_GV, _STB_G_BF16, _STB_NO_GX, \
+    _STB_KV_GIVEN = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 STB_PRUNE_GX = os.environ.get("ADAP_STB_PRUNE_GX", "1") != "0"     # A/B switch: skip the input-gradient half where it is not needed
 
 
@@ -524,9 +524,75 @@ def _stb_weights(P, same_ctx):
     return hit
 
 
+HOIST_KV = os.environ.get("ADAP_HOIST_KV", "1") != "0"      # A/B switch: the 16 layers' context K | V projections as grouped launches
+
+
+class HoistedKV:
+    """a layer's cross-attention context together with its K | V projection, made in front of the UNet by ``ContextKVFn``:
+    ``kv`` bf16 [B, M, 2C] (the block's ``kv2``), ``dkv`` the slot of the same shape its backward writes the gradient into."""
+    __slots__ = ("ctx", "kv", "dkv")
+
+    def __init__(self, ctx, kv, dkv):
+        self.ctx, self.kv, self.dkv = ctx, kv, dkv
+
+
+class ContextKVFn(torch.autograd.Function):
+    """The cross-attention K | V projections of ALL conditioned layers (attention.py:195-213 ``to_k`` / ``to_v`` of ``attn2``, 16
+    of them in SD-1.5, each on its own layer's 77 context tokens) hoisted in front of the UNet: a layer's projection is a
+    308-row GEMM (B = 4) that costs a whole dependent launch (25-29 us) at the head of its block's chain; layers that are
+    neighbours in the layerwise context and have the same width (SD-1.5: layers 0-1, 2-3, 4-9, 10-12, 13-15) go out as ONE
+    batched launch (``adap_conv2d_nhwc`` nbatch: per-layer weights, per-layer rows), 5 launches instead of 16, and the context
+    gradients -- dK Wk + dV Wv per layer -- as 5 behind the UNet's backward instead of 16 inside it.  Frozen weights only.
+
+    forward(ctx_l f32 [L, B, M, Cctx] layer-major, runs) -> L tensors bf16 [B, M, 2C_l];  ``runs``: [(first layer, layers, C,
+    stacked forward packs [n][2C][Cctx], stacked data-gradient packs [n][Cctx][2C])].  The blocks write their dK | dV straight
+    into the run's gradient buffer (``slots``, handed out with the outputs through ``LAST_SLOTS``), so the backward here is
+    the batched contraction alone."""
+    LAST_SLOTS = None
+
+    @staticmethod
+    def forward(ctx, ctx_l, runs):
+        L, B, M, Cctx = ctx_l.shape
+        assert ctx_l.dtype == torch.float32 and ctx_l.is_contiguous()
+        c16 = ops.pad_cast_bf16(ctx_l)
+        rows = B * M
+        outs, slots, dbufs = [], [], []
+        for l0, n, C, wf, _wb in runs:
+            kv = torch.empty(n, B, M, 2 * C, device=ctx_l.device, dtype=BF16)
+            ops._lib.call("adap_conv2d_nhwc", c16[l0].data_ptr(), 1, Cctx, wf.data_ptr(), 0, 0, 0, 0, 0, 0, 0, kv.data_ptr(), 2 * C,
+                          1, rows, 1, Cctx, rows, 1, 2 * C, 1, 1, 1, 0, 0, 1.0, 1, 0, n, rows * Cctx, 2 * C * Cctx, 0, rows * 2 * C,
+                          ops._stream())
+            dkv = torch.empty(n, B, M, 2 * C, device=ctx_l.device, dtype=BF16)
+            outs += list(kv.unbind(0))
+            slots += list(dkv.unbind(0))
+            dbufs.append(dkv)
+        ctx.runs, ctx.dbufs, ctx.slots, ctx.shape = runs, dbufs, slots, (L, B, M, Cctx)
+        ctx.set_materialize_grads(False)
+        ContextKVFn.LAST_SLOTS = slots
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        L, B, M, Cctx = ctx.shape
+        rows = B * M
+        for g, slot in zip(gs, ctx.slots):
+            if g is None:
+                slot.zero_()                       # (a layer whose K | V nothing downstream used)
+            elif g.data_ptr() != slot.data_ptr():
+                slot.copy_(g)                      # (a gradient that did not come from the block's own write into the slot)
+        g_ctx = torch.empty(L, B, M, Cctx, device=ctx.dbufs[0].device, dtype=torch.float32)
+        for (l0, n, C, _wf, wb), dkv in zip(ctx.runs, ctx.dbufs):
+            ops._lib.call("adap_conv2d_nhwc", dkv.data_ptr(), 1, 2 * C, wb.data_ptr(), 0, 0, 0, 0, 0, g_ctx[l0].data_ptr(), Cctx, 0, 0,
+                          1, rows, 1, 2 * C, rows, 1, Cctx, 1, 1, 1, 0, 0, 1.0, 1, 0, n, rows * 2 * C, Cctx * 2 * C, rows * Cctx, 0,
+                          ops._stream())
+        return g_ctx, None
+
+
 class SpatialTransformerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None, tokmap_only=False):
+    def forward(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w=None, tokmap_only=False, kv=None, dkv_slot=None):
+        """``kv`` / ``dkv_slot``: the cross-attention K | V projection of this layer's context already made (``ContextKVFn``:
+        bf16 [B, M, 2C]) and where the backward is to leave dK | dV; ``ctx_k`` / ``ctx_v`` are then only shapes."""
         _note_forward(ctx, P.get("train"))
         B, H, W, C = x.shape
         N = H * W
@@ -539,7 +605,8 @@ class SpatialTransformerFn(torch.autograd.Function):
                 and (key_mask is None or isinstance(key_mask, KeyCompaction) or torch.is_tensor(key_mask))):
             fw, _bw, ok, Cctx = _stb_weights(P, same_ctx)
             if ok and ctx_k.shape[-1] == Cctx:
-                return SpatialTransformerFn._forward_c(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w, same_ctx, fw, Cctx)
+                return SpatialTransformerFn._forward_c(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w, same_ctx, fw, Cctx,
+                                                       kv, dkv_slot)
         # the cross-attention K/V projection reads only the 77 context tokens: on the side lane, under the block's first half
         lane = side_lane(x)
         M = ctx_k.shape[1]
@@ -554,7 +621,10 @@ class SpatialTransformerFn(torch.autograd.Function):
             kv[..., C:].copy_(vv)
             return kv
         kv2_ready = None
-        if lane is not None:
+        ctx.dkv_slot = dkv_slot if kv is not None else None
+        if kv is not None:
+            kv2 = kv
+        elif lane is not None:
             lane.fork()
             with lane:
                 kv2 = project_kv()
@@ -646,7 +716,7 @@ class SpatialTransformerFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def _forward_c(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w, same_ctx, fw, Cctx):
+    def _forward_c(ctx, x, ctx_k, ctx_v, P, heads, key_mask, capture, tok_w, same_ctx, fw, Cctx, kv=None, dkv_slot=None):
         import ctypes
         B, H, W, C = x.shape
         N, M = H * W, ctx_k.shape[1]
@@ -664,7 +734,13 @@ class SpatialTransformerFn(torch.autograd.Function):
             assert key_mask.dtype == torch.uint8 and key_mask.shape == (B, N) and key_mask.is_contiguous()
             mask_ptr = key_mask.data_ptr()
         e = torch.empty
-        kv2 = e(B, M, 2 * C, device=dev, dtype=BF16)
+        if kv is not None:
+            assert kv.dtype == BF16 and kv.is_contiguous() and tuple(kv.shape) == (B, M, 2 * C)
+            kv2 = kv
+            flags |= _STB_KV_GIVEN
+        else:
+            kv2 = e(B, M, 2 * C, device=dev, dtype=BF16)
+        ctx.dkv_slot = dkv_slot if kv is not None else None
         gn_stats = e(2, B, 32, device=dev, dtype=torch.float32)
         tres = e(3, B, N, C, device=dev, dtype=torch.float32)
         ln_stats = e(6, rows, device=dev, dtype=torch.float32)
@@ -740,7 +816,9 @@ class SpatialTransformerFn(torch.autograd.Function):
         e = torch.empty
         gx = None if no_gx else e(B, H, W, C, device=dev, dtype=torch.float32)
         gx16 = None if no_gx else e(B, H, W, C, device=dev, dtype=BF16)
-        dkv2 = e(B, M, 2 * C, device=dev, dtype=BF16)
+        slot = ctx.dkv_slot
+        given = ctx.needs_input_grad[9] if len(ctx.needs_input_grad) > 9 else False
+        dkv2 = slot if (given and slot is not None) else e(B, M, 2 * C, device=dev, dtype=BF16)
         g_ck = e(B, M, Cctx, device=dev, dtype=torch.float32) if want_gk else None
         g_cv = e(B, M, Cctx, device=dev, dtype=torch.float32) if want_gv else None
         s32 = e(2 * rows * C + at_n + prep_n + gn_n + 2 * sk_n, device=dev, dtype=torch.float32)
@@ -766,10 +844,11 @@ class SpatialTransformerFn(torch.autograd.Function):
         cfg = (ctypes.c_int * 11)(B, H, W, C, heads, M, Cctx, flags, G, ldg, ldg32)
         ops._lib.call("adap_stblock_bwd", cfg, bw, tens, 0 if lane is None else lane.side.cuda_stream, ops._stream())
         STB_CALLS[1] += 1
+        g_kv = dkv2 if given else None
         if no_gx:
             STB_CALLS[2] += 1
-            return None, g_ck, g_cv, None, None, None, None, None, None
-        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None
+            return None, g_ck, g_cv, None, None, None, None, None, None, g_kv, None
+        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None, g_kv, None
 
     @staticmethod
     def backward(ctx, g, g_score=None, _g_prob=None, g_qs=None, g_tokmap=None):
@@ -830,7 +909,8 @@ class SpatialTransformerFn(torch.autograd.Function):
         _, go2 = _lin_bwd(gt2h, P["to_out2"], out_f32=False, out_bf16=True)
         M = kv2.shape[1]
         dq2 = torch.empty(B, N, C, device=x.device, dtype=BF16)
-        dkv2 = torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
+        given = ctx.needs_input_grad[9] if len(ctx.needs_input_grad) > 9 else False
+        dkv2 = ctx.dkv_slot if (given and ctx.dkv_slot is not None) else torch.empty(B, M, 2 * C, device=x.device, dtype=BF16)
         if tok_ready is not None:
             torch.cuda.current_stream().wait_event(tok_ready)
         ops.attention_bwd(q2, kv2[..., :C], kv2[..., C:], o2, go2, lse2, heads, None, dq=dq2, dk=dkv2[..., :C],
@@ -915,7 +995,7 @@ class SpatialTransformerFn(torch.autograd.Function):
                                      add_from=g if g.dim() == 4 else g.view(B, H, W, C))   # dx + g, no clone of g
         if ctx_grad_ready is not None:
             torch.cuda.current_stream().wait_event(ctx_grad_ready)
-        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None
+        return _stash16(gx, gx16), g_ck, g_cv, None, None, None, None, None, None, (dkv2 if given else None), None
 
 
 # ---------------------------------------------------------------------------------------------

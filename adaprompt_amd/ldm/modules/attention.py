@@ -175,6 +175,9 @@ class SpatialTransformer(nn.Module):
             context, _placeholder2indices = context()
         if context is None:
             raise NotImplementedError("SpatialTransformer without a text context is not on the SD-1.5 path")
+        kv = dkv_slot = None
+        if isinstance(context, HF.HoistedKV):           # K | V of this layer's context already projected (HF.ContextKVFn)
+            kv, dkv_slot, context = context.kv, context.dkv, context.ctx
         if isinstance(context, (list, tuple)):
             v_ctx, k_ctx = context
         else:
@@ -198,7 +201,7 @@ class SpatialTransformer(nn.Module):
         if tok_w is not None and (tok_w.shape[0] != B or tok_w.shape[1] != k_ctx.shape[1]):
             tok_w = None
         res = HF.SpatialTransformerFn.apply(x.contiguous(), k_ctx, v_ctx, self._packs(same), self.n_heads, key_mask, capture,
-                                            tok_w, bool(getattr(blk.attn2, "tokmap_only", False)))
+                                            tok_w, bool(getattr(blk.attn2, "tokmap_only", False)), kv, dkv_slot)
         if capture:
             out, score, prob, qs = res[:4]
             blk.attn2.cached_activations = {"q": qs, "attn": prob, "attnscore": score}

@@ -290,6 +290,46 @@ class UNetModel(nn.Module):
 
         return apply(ca_flag_dict, ca_layer_indices, True), apply(trans_flag_dict, trans_layer_indices, False)
 
+    def _kv_runs(self, Cctx):
+        """the plan of ``HF.ContextKVFn``: the conditioned layers in LAYER2CA order cut into runs of neighbours of equal width,
+        each with its layers' ``attn2.to_k | to_v`` packs stacked (forward [n][2C][Cctx], data gradient [n][Cctx][2C]); cached
+        per model state.  None when any of those weights trains (their gradients are made inside the blocks) or a layer's
+        context width differs."""
+        key = (HF.MODEL_STAMP, torch.is_grad_enabled(), Cctx)
+        hit = self.__dict__.get("_kv_runs_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        stms = self.__dict__.get("_ca_stms")
+        if stms is None:
+            by_layer, li = {}, 0
+            for seq in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
+                for m_ in seq:
+                    if isinstance(m_, SpatialTransformer):
+                        by_layer[li] = m_
+                li += 1
+            stms = self.__dict__["_ca_stms"] = [by_layer.get(l) for l in ALL_CA_LAYERS]
+        runs = None
+        if all(m_ is not None for m_ in stms):
+            a2s = [m_.transformer_blocks[0].attn2 for m_ in stms]
+            trains = torch.is_grad_enabled() and any(w.requires_grad for a in a2s for w in (a.to_k.weight, a.to_v.weight))
+            if not trains and all(a.to_k.weight.shape[1] == Cctx and a.to_k.weight.shape == a.to_v.weight.shape for a in a2s):
+                runs, i = [], 0
+                with torch.no_grad():
+                    while i < len(a2s):
+                        C, j = a2s[i].to_k.weight.shape[0], i + 1
+                        while j < len(a2s) and a2s[j].to_k.weight.shape[0] == C:
+                            j += 1
+                        pks = [stms[k]._wc.get("kv2", [a2s[k].to_k.weight, a2s[k].to_v.weight]) for k in range(i, j)]
+                        if not all(pk.O4 == pk.O and pk.I8 == pk.I for pk in pks):
+                            runs = None
+                            break
+                        wf = torch.stack([pk.fwd.view(2 * C, Cctx) for pk in pks]).contiguous()
+                        wb = torch.stack([pk.bwd.view(Cctx, 2 * C) for pk in pks]).contiguous()
+                        runs.append((i, j - i, C, wf, wb))
+                        i = j
+        self.__dict__["_kv_runs_cache"] = (key, runs)
+        return runs
+
     def _attn2_modules(self):
         """the cross-attention modules of every SpatialTransformer, listed once (walking ``self.modules()`` -- ~1500 modules -- on
         every forward cost 1 ms of host time per training step)."""
@@ -359,6 +399,13 @@ class UNetModel(nn.Module):
         # unbind, not 16 x select: its backward is ONE stack of the 16 layers' gradients (a select's backward materialises
         # a zero [16,B,M,C] tensor per layer and autograd then adds the 16 of them)
         ctx_layers = ctx_l.unbind(0)
+        # the 16 layers' cross-attention K | V projections as a few batched launches in front of the UNet (HF.ContextKVFn)
+        hoisted = None
+        if HF.HOIST_KV and iter_type != "mix_hijk" and context.shape[0] == 16 * B:
+            runs = self._kv_runs(Cctx)
+            if runs is not None:
+                kvs = HF.ContextKVFn.apply(ctx_l, runs)
+                hoisted = (kvs, HF.ContextKVFn.LAST_SLOTS)
         if img_mask is not None:
             from ..attention import KeyMasks
             img_mask = KeyMasks(img_mask)
@@ -370,6 +417,9 @@ class UNetModel(nn.Module):
             if iter_type == "mix_hijk":
                 v, k = c.chunk(2, dim=1)
                 return (v.contiguous(), k.contiguous()), placeholder2indices
+            if hoisted is not None:
+                ca = LAYER2CA[layer_idx]
+                return HF.HoistedKV(c.detach(), hoisted[0][ca], hoisted[1][ca]), placeholder2indices
             return (c, c), placeholder2indices
 
         if not isinstance(use_conv_attn_kernel_size, (int, np.integer)):

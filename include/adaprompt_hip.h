@@ -164,6 +164,7 @@ int adap_resblock_bwd(const void* g, int g_dtype, const float* g32, const float*
 #define ADAP_STB_WANT_GV 64
 #define ADAP_STB_G_BF16 128
 #define ADAP_STB_NO_GX 256          /* bwd: the block's input needs no gradient -- stop after the cross attention (GX / GX16 may be NULL) */
+#define ADAP_STB_KV_GIVEN 512       /* fwd: KV2 already holds the context's K | V projection (hoisted, batched over layers): not recomputed */
 enum { ADAP_STW_GN_G, ADAP_STW_GN_B, ADAP_STW_PIN_W, ADAP_STW_PIN_B, ADAP_STW_LN1_G, ADAP_STW_LN1_B, ADAP_STW_QKV, ADAP_STW_OUT1_W,
        ADAP_STW_OUT1_B, ADAP_STW_LN2_G, ADAP_STW_LN2_B, ADAP_STW_Q2, ADAP_STW_KV2, ADAP_STW_V2, ADAP_STW_OUT2_W, ADAP_STW_OUT2_B,
        ADAP_STW_LN3_G, ADAP_STW_LN3_B, ADAP_STW_FF1G_W, ADAP_STW_FF1G_B, ADAP_STW_FF2_W, ADAP_STW_FF2_B, ADAP_STW_POUT_W,

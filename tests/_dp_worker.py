@@ -45,7 +45,7 @@ def micro_batch(rank, mb, dev):
     x0 = synth.synthetic_input(tag + ".x0", (B, 4, 64, 64))
     noise = synth.synthetic_input(tag + ".noise", (B, 4, 64, 64))
     ids = synth.synthetic_input(tag + ".ids", (B, 32))
-    t = torch.tensor([100 + 300 * mb + 50 * rank, 850 - 200 * mb - 30 * rank])
+    t = torch.tensor([(100 + 300 * mb + 50 * rank) % 1000, (850 - 200 * mb - 30 * rank) % 1000])       # (timesteps 0 .. 999)
     m = torch.ones(B, 64, 64)
     batch = {"zs_id_embs": ids.to(dev), "fg_mask": m.to(dev), "aug_mask": m.to(dev)}
     return batch, dict(t=t.to(dev), noise=noise.to(dev), x_start=x0.to(dev))

@@ -98,6 +98,70 @@ def test_unet_narrow_mask():
     run_unet_case(NARROW, "narrow_mask", load_golden("unet_narrow_mask"), False)
 
 
+@pytest.mark.parametrize("c_call", [True, False])
+def test_context_kv_hoist_equals_the_per_layer_projections(c_call):
+    """``functional.ContextKVFn``: the 16 layers' cross-attention K | V projections (attention.py:195-213) as 5 batched launches
+    in front of the UNet -- and their context gradients as 5 behind its backward -- against the same projections made inside
+    the blocks, one launch per layer each way (``HF.HOIST_KV`` off).  Same operands, same bf16 rounding of the context; the
+    batched launch goes to another contraction kernel (bf16 operand ring kernel instead of the f32-gather kernel), so the f32
+    accumulation order differs: K | V agree to a bf16 ulp, eps / the token maps / the context gradient to round-off."""
+    from adaprompt_amd import functional as HF
+    B, M = 2, 77
+    unet = build_unet(NARROW)
+    x = synth.synthetic_input("kvh.x", (B, 4, 64, 64)).to(dev())
+    t = torch.tensor([420, 640]).to(dev())
+    ctx0 = synth.synthetic_input("kvh.ctx", (16 * B, M, NARROW["context_dim"])).to(dev())
+    w = synth.synthetic_input("kvh.gw", (B, 4, 64, 64)).to(dev())
+    subj = (torch.arange(B, device=dev()).repeat_interleave(16), torch.arange(4, 20, device=dev()).repeat(B))
+
+    def run(hoist):
+        was, was_c = HF.HOIST_KV, HF.STBLOCK_C
+        HF.HOIST_KV, HF.STBLOCK_C = hoist, c_call
+        try:
+            ctx = ctx0.clone().requires_grad_(True)
+            extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon", "is_training": True,
+                     "capture_distill_attn": True, "placeholder2indices": None, "img_mask": border_mask(B, 64, 64, 6).to(dev()),
+                     "subj_indices": subj, "capture_token_maps_only": True}
+            eps = unet(x, t, context=ctx, context_in=None, extra_info=extra)
+            tms = extra["ca_layers_activations"]["attnscore_tokmap"]
+            roots = [eps] + [tms[li] for li in sorted(tms)]
+            grads = [w] + [torch.full_like(tms[li], 1e-3) for li in sorted(tms)]
+            torch.autograd.backward(roots, grads)
+            torch.cuda.synchronize()
+            return eps.detach().clone(), ctx.grad.detach().clone(), {li: v.detach().clone() for li, v in tms.items()}
+        finally:
+            HF.HOIST_KV, HF.STBLOCK_C = was, was_c
+
+    n0 = list(HF.STB_CALLS)
+    e1, g1, tm1 = run(True)
+    if c_call:
+        assert HF.STB_CALLS[0] == n0[0] + 16 and HF.STB_CALLS[1] == n0[1] + 16, "the C path was not taken"
+    e0, g0, tm0 = run(False)
+    e1b, g1b, _ = run(True)
+    assert torch.equal(e1, e1b) and torch.equal(g1, g1b)                 # reproducible
+    assert rel_err(e1, e0) < 2e-3, rel_err(e1, e0)
+    assert rel_err(g1, g0) < 5e-3, rel_err(g1, g0)
+    for li in tm0:
+        assert rel_err(tm1[li], tm0[li]) < 2e-3, (li, rel_err(tm1[li], tm0[li]))
+    # the projections themselves: batched launch against one ops.linear per layer
+    runs = unet._kv_runs(NARROW["context_dim"]) if HF.MODEL_STAMP is not None else None
+    HF.MODEL_STAMP = (id(unet),) + HF.model_stamp(list(unet.parameters()))
+    try:
+        runs = unet._kv_runs(NARROW["context_dim"])
+        assert [(l0, n) for l0, n, *_ in runs] == [(0, 2), (2, 2), (4, 6), (10, 3), (13, 3)]
+        ctx_l = ctx0.reshape(B, 16, M, -1).permute(1, 0, 2, 3).contiguous()
+        kvs = HF.ContextKVFn.apply(ctx_l, runs)
+        for ca, stm in enumerate(unet._ca_stms):
+            a2 = stm.transformer_blocks[0].attn2
+            pk = stm._wc.get("kv2", [a2.to_k.weight, a2.to_v.weight])
+            _, ref = ops.linear(ctx_l[ca], pk.fwd, pk.O, out_f32=False, out_bf16=True)
+            d = (kvs[ca].float() - ref.float()).abs()
+            assert float(d.max()) <= float(ref.float().abs().max()) * 2 ** -7, (ca, float(d.max()))
+            assert float((d > 0).float().mean()) < 0.02, (ca, float((d > 0).float().mean()))
+    finally:
+        HF.MODEL_STAMP = None
+
+
 def test_unet_narrow_mixhijk():
     run_unet_case(NARROW, "narrow_mixhijk", load_golden("unet_narrow_mixhijk"), False)
 

@@ -49,6 +49,7 @@ def _run_two_ranks(reducer_backend, mode=None):
         assert p.returncode == 0, se[-3000:]
     res = [json.loads(l.split("DPRESULT ", 1)[1]) for so, _ in outs for l in so.splitlines() if l.startswith("DPRESULT ")]
     assert len(res) == 2
+    print("two-rank results:", json.dumps(res))
     for r in res:
         assert r["backend"] == ("nccl" if ndev >= 2 else "gloo")
     return res
@@ -71,8 +72,8 @@ def test_training_window_on_lanes_two_ranks_matches_hand_averaged_windows(reduce
     wait inside the lanes' gate in front of the accumulation -- on two ranks (one card over gloo; RCCL through torch and through
     the library's own communicator when the box has two devices), two windows, against the hand-averaged sequential loop."""
     for r in _run_two_ranks(reducer_backend, mode="lanes"):
-        assert r["mode"] == "lanes" and r["optimizer_steps"] == 2
-        assert r["replicas_identical"] and r["grad_buffer_zeroed"] and r["moved"] > 0
+        assert r["mode"] == "lanes" and r["optimizer_steps"] == 2, r
+        assert r["replicas_identical"] and r["grad_buffer_zeroed"] and r["moved"] > 0, r
         assert r["rel_err_vs_hand_averaged"] < 1e-4, r
         assert abs(r["d"] - r["ref_d"]) <= 1e-5 * abs(r["ref_d"]), r
         for a, b in zip(r["losses"], r["ref_losses"]):

@@ -43,6 +43,9 @@ def build(B, teacher=False, seed=3, max_steps=8):
     ld.load_state_dict(synth.synthetic_unet_state_dict(ucfg), strict=False)
     ld = ld.to(dev())
     ld.freeze_unet()
+    # stage 1 as this model can run it: the compositional iteration (every 3rd global step in the yaml) needs the reference's
+    # conditioning side and is refused by the preamble without it
+    ld.composition_regs_iter_gap = 0
     if teacher:
         TP = "arc2face.unet."
         tsd = synth.synthetic_unet_state_dict(ucfg, prefix=TP)
