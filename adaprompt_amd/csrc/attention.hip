@@ -22,6 +22,7 @@
 // Backward = two kernels without atomics (bit-reproducible): dQ is query-stationary (same loop
 // as the forward), dK/dV are key-stationary (a wave owns 32 keys and sweeps the queries); P is
 // recomputed from the saved LSE.
+#include <algorithm>
 #include "common.h"
 #include <float.h>
 
@@ -1635,7 +1636,14 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
 }
 
 template <int KS, int VT>
-static int launch_bwd(const AttnParams& p, hipStream_t s) {
+static int launch_bwd(const AttnParams& p_in, hipStream_t s) {
+    // The XCD-aware workgroup map (attn_wg_coords) for the two backward kernels only where a (batch, head) row has few blocks:
+    // at N = 4096 (32 blocks per row) the kernels are bound by vector / matrix issue, the Infinity Cache absorbs the re-fetches
+    // of the plain map (FETCH 221 -> 66 MB per dK/dV launch with the map, time 511 -> 519 us), and a row's 32 workgroups walking
+    // the same K / V (Q / dO) lines in step on one XCD cost more than the traffic saved; at 32 x 32 and below (<= 8 blocks per
+    // row) the map takes 8-14 % off (profiles/r05_attn_xcd.md).  ADAP_ATTN_XCD bit 3 forces the map for every shape.
+    AttnParams p = p_in;
+    if (!(attn_debug().xcd & 8) && (p.N + 127) / 128 > 16) p.xcd &= ~6;
     size_t lds1 = 2 * 64 * TileGeom<KS>::RSTRIDE + 68 * 4;
     dim3 g1((p.N + 127) / 128, p.B * p.H);
     if (p.pre) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT, true>), g1, dim3(256), lds1, s, p);
@@ -1926,17 +1934,30 @@ static void tokmap_allow_lds(K kernel, size_t bytes) {          // beyond the 64
     if (bytes > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-__global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __restrict__ q, long ldq,
-                                                              const uint16_t* __restrict__ k, long ldk,
-                                                              const float* __restrict__ tok_w, float* __restrict__ tokmap,
-                                                              int G, int H, int N, int M, int d, float scale) {
-    __shared__ float sKW[TOK_MAXP];                 // [G <= 4][d <= 160]
-    __shared__ float sPart[512];                    // the key slices' partial sums (G d <= 256: tokmap_kw_phase)
-    extern __shared__ __attribute__((aligned(16))) char tok_stage[];
+// The token maps of SEVERAL layers in one launch (adap_attention_tokmap_fwd_batched / _prep_batched): the 12 distillation layers'
+// maps are only read by the losses after the UNet's forward, and their gradient prologue (kw, gq) only depends on what the forward
+// saved and on the losses' gradients -- all known when the backward starts -- so neither has to sit on a block's dependency
+// chain: one launch (grid.z = layer) behind the forward, three in front of the backward, instead of one / three per layer.
+#define TOK_MAXL 16
+struct TokLayer {
+    const uint16_t* q; long ldq;
+    const uint16_t* k; long ldk;
+    const float* tok_w;         // [B][M][G]
+    float* tokmap;              // forward: out [B][H][N][G]
+    const float* dt;            // prep: d tokmap [B][H][N][G]
+    float* ws;                  // prep: kw | gq | chunk partials (adap_attention_tokmap_prep_workspace_floats)
+    int B, H, N, M, d, G;
+    float scale;
+};
+struct TokBatch { TokLayer L[TOK_MAXL]; };
+
+__device__ __forceinline__ void tokmap_fwd_body(const uint16_t* __restrict__ q, long ldq, const uint16_t* __restrict__ k, long ldk,
+                                                const float* __restrict__ tok_w, float* __restrict__ tokmap, int G, int H, int N,
+                                                int M, int d, float scale, int bx, int bh, float* sKW, float* sPart, char* tok_stage) {
     const int tid = threadIdx.x;
-    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    const int b = bh / H, head = bh - b * H;
     tokmap_kw_phase(sPart, sKW, tok_stage, tok_w, k, ldk, b, head, M, d, G, scale);
-    const int n = blockIdx.x * TOKF_ROWS + tid;
+    const int n = bx * TOKF_ROWS + tid;
     if (n >= N) return;
     const uint16_t* qr = q + ((size_t)b * N + n) * ldq + head * d;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1965,6 +1986,26 @@ __global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         if (g < G) out[g] = acc[g];
+}
+
+__global__ __launch_bounds__(256) void attn_tokmap_fwd_kernel(const uint16_t* __restrict__ q, long ldq,
+                                                              const uint16_t* __restrict__ k, long ldk,
+                                                              const float* __restrict__ tok_w, float* __restrict__ tokmap,
+                                                              int G, int H, int N, int M, int d, float scale) {
+    __shared__ float sKW[TOK_MAXP];                 // [G <= 4][d <= 160]
+    __shared__ float sPart[512];                    // the key slices' partial sums (G d <= 256: tokmap_kw_phase)
+    extern __shared__ __attribute__((aligned(16))) char tok_stage[];
+    tokmap_fwd_body(q, ldq, k, ldk, tok_w, tokmap, G, H, N, M, d, scale, blockIdx.x, blockIdx.y, sKW, sPart, tok_stage);
+}
+
+__global__ __launch_bounds__(256) void attn_tokmap_fwd_batched_kernel(TokBatch bt) {
+    __shared__ float sKW[TOK_MAXP];
+    __shared__ float sPart[512];
+    extern __shared__ __attribute__((aligned(16))) char tok_stage[];
+    const TokLayer& L = bt.L[blockIdx.z];
+    if ((int)blockIdx.x * TOKF_ROWS >= L.N || (int)blockIdx.y >= L.B * L.H) return;          // (whole workgroups: before any barrier)
+    tokmap_fwd_body(L.q, L.ldq, L.k, L.ldk, L.tok_w, L.tokmap, L.G, L.H, L.N, L.M, L.d, L.scale, blockIdx.x, blockIdx.y, sKW, sPart,
+                    tok_stage);
 }
 
 extern "C" int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, float* attnscore, float* attn,
@@ -2135,14 +2176,29 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_dk_finish_kernel(const f
 // gq is a reduction over the queries: 128-row chunks, two stages, fixed order.
 // =============================================================================================
 // kw[bh][g][c] = sum_m w[b][m][g] * k[b][m][head*d + c]  -- G*d numbers per (batch, head), one small workgroup each
+__device__ __forceinline__ void tokmap_kw_body(const float* __restrict__ tok_w, const uint16_t* __restrict__ k, long ldk,
+                                               float* __restrict__ kw, int H, int M, int d, int G, int bh, float* sKW, float* sPart,
+                                               char* tok_stage) {
+    const int b = bh / H, head = bh - b * H;
+    tokmap_kw_phase(sPart, sKW, tok_stage, tok_w, k, ldk, b, head, M, d, G, 1.f);
+    for (int p = threadIdx.x; p < G * d; p += 256) kw[(size_t)bh * G * d + p] = sKW[p];
+}
+
 __global__ __launch_bounds__(256) void attn_tokmap_kw_kernel(const float* __restrict__ tok_w, const uint16_t* __restrict__ k,
                                                              long ldk, float* __restrict__ kw, int H, int M, int d, int G) {
     __shared__ float sKW[TOK_MAXP];
     __shared__ float sPart[512];
     extern __shared__ __attribute__((aligned(16))) char tok_stage[];
-    const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
-    tokmap_kw_phase(sPart, sKW, tok_stage, tok_w, k, ldk, b, head, M, d, G, 1.f);
-    for (int p = threadIdx.x; p < G * d; p += 256) kw[(size_t)bh * G * d + p] = sKW[p];
+    tokmap_kw_body(tok_w, k, ldk, kw, H, M, d, G, blockIdx.x, sKW, sPart, tok_stage);
+}
+
+__global__ __launch_bounds__(256) void attn_tokmap_kw_batched_kernel(TokBatch bt) {
+    __shared__ float sKW[TOK_MAXP];
+    __shared__ float sPart[512];
+    extern __shared__ __attribute__((aligned(16))) char tok_stage[];
+    const TokLayer& L = bt.L[blockIdx.y];
+    if ((int)blockIdx.x >= L.B * L.H) return;
+    tokmap_kw_body(L.tok_w, L.k, L.ldk, L.ws, L.H, L.M, L.d, L.G, blockIdx.x, sKW, sPart, tok_stage);
 }
 
 // dq[b][n][head*d + c] += scale * sum_g dT[b][head][n][g] * kw[bh][g][c]: element-wise, 8 channels per thread
@@ -2181,15 +2237,14 @@ __global__ __launch_bounds__(256) void attn_tokmap_bwd_dq_kernel(const float* __
 // load each, RL = 256 / (d / 8) rows in flight per pass, then a fixed-order LDS reduction over the row lanes (one bf16 per lane
 // with 40 of 64 lanes busy at d = 40 ran at 0.2 TB/s: 11.7 -> 6.2 us at 64 x 64, 14.7 -> 6.4 us at 16 x 16,
 // tools/microbench/tokmap_family.hip).  Dynamic LDS: RL * G * d floats.
-__global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __restrict__ dt, const uint16_t* __restrict__ q,
-                                                                 long ldq, float* __restrict__ part, int B, int H, int N, int d,
-                                                                 int G) {
-    extern __shared__ float tok_red[];             // [RL][G * d]
+__device__ __forceinline__ void tokmap_gq_body(const float* __restrict__ dt, const uint16_t* __restrict__ q, long ldq,
+                                               float* __restrict__ part, int H, int N, int d, int G, int bx, int nchunks, int bh,
+                                               float* tok_red) {
     const int tid = threadIdx.x;
     const int octs = d >> 3, RL = 256 / octs;
     const int o = tid % octs, rl = tid / octs;
-    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
-    const int n0 = blockIdx.x * CAPB_ROWS;
+    const int b = bh / H, head = bh - b * H;
+    const int n0 = bx * CAPB_ROWS;
     const int rows = min(CAPB_ROWS, N - n0);
     const int P = G * d;
     float acc[TOK_MAXG][8];
@@ -2236,8 +2291,24 @@ __global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __
     for (int p = tid; p < P; p += 256) {
         float v = 0.f;
         for (int i = 0; i < RL; ++i) v += tok_red[(size_t)i * P + p];
-        part[((size_t)bh * gridDim.x + blockIdx.x) * P + p] = v;
+        part[((size_t)bh * nchunks + bx) * P + p] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void attn_tokmap_bwd_gq_kernel(const float* __restrict__ dt, const uint16_t* __restrict__ q,
+                                                                 long ldq, float* __restrict__ part, int B, int H, int N, int d,
+                                                                 int G) {
+    extern __shared__ float tok_red[];             // [RL][G * d]
+    tokmap_gq_body(dt, q, ldq, part, H, N, d, G, blockIdx.x, gridDim.x, blockIdx.y, tok_red);
+}
+
+__global__ __launch_bounds__(256) void attn_tokmap_gq_batched_kernel(TokBatch bt) {
+    extern __shared__ float tok_red[];
+    const TokLayer& L = bt.L[blockIdx.z];
+    const int nchunks = (L.N + CAPB_ROWS - 1) / CAPB_ROWS;
+    if ((int)blockIdx.x >= nchunks || (int)blockIdx.y >= L.B * L.H) return;
+    const long bhgd = (long)L.B * L.H * L.G * L.d;
+    tokmap_gq_body(L.dt, L.q, L.ldq, L.ws + 2 * bhgd, L.H, L.N, L.d, L.G, blockIdx.x, nchunks, blockIdx.y, tok_red);
 }
 static size_t tokmap_gq_lds(int d, int G) { return (size_t)(256 / (d >> 3)) * G * d * sizeof(float); }
 
@@ -2283,6 +2354,21 @@ __global__ __launch_bounds__(256) void attn_tokmap_gq_reduce_kernel(const float*
     gq[i] = a;
 }
 
+__global__ __launch_bounds__(256) void attn_tokmap_gq_reduce_batched_kernel(TokBatch bt) {
+    const TokLayer& L = bt.L[blockIdx.y];
+    const int Gd = L.G * L.d, nchunks = (L.N + CAPB_ROWS - 1) / CAPB_ROWS;
+    const long total = (long)L.B * L.H * Gd;
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const float* part = L.ws + 2 * total;
+    const long bh = i / Gd;
+    const int e = (int)(i - bh * Gd);
+    float a = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < nchunks; ++k) a += part[(bh * nchunks + k) * Gd + e];
+    L.ws[total + i] = a;
+}
+
 // workspace floats of adap_attention_tokmap_prep: kw | gq | the gq chunk partials
 extern "C" long adap_attention_tokmap_prep_workspace_floats(int B, int H, int N, int d, int G) {
     return (long)B * H * (((N + CAPB_ROWS - 1) / CAPB_ROWS) + 2) * G * d;
@@ -2313,6 +2399,73 @@ extern "C" int adap_attention_tokmap_prep(const float* d_tokmap, const float* to
     hipLaunchKernelGGL(attn_tokmap_gq_reduce_kernel, dim3((unsigned)((bhgd + 255) / 256)), dim3(256), 0, s, part, gq, nchunks, G * d,
                        bhgd);
     return adap_check_launch("attention_tokmap_prep");
+}
+
+// n <= 16 layers described by flat host arrays: ptrs [n][6] = {q, k, tok_w, tokmap (fwd) or NULL, d_tokmap (prep) or NULL,
+// workspace (prep) or NULL}; lds [n][2] = {ldq, ldk}; dims [n][6] = {B, H, N, M, d, G}; scales [n] (forward only).
+static int tok_batch_fill(TokBatch& bt, int n, const void* const* ptrs, const long* lds, const int* dims, const float* scales,
+                          bool fwd, const char* who) {
+    ADAP_REQUIRE(n >= 1 && n <= TOK_MAXL && ptrs && lds && dims, ADAP_ERR_SHAPE, "%s: 1 <= layers <= %d", who, TOK_MAXL);
+    for (int i = 0; i < n; ++i) {
+        TokLayer& L = bt.L[i];
+        L.q = (const uint16_t*)ptrs[6 * i]; L.k = (const uint16_t*)ptrs[6 * i + 1]; L.tok_w = (const float*)ptrs[6 * i + 2];
+        L.tokmap = (float*)ptrs[6 * i + 3]; L.dt = (const float*)ptrs[6 * i + 4]; L.ws = (float*)ptrs[6 * i + 5];
+        L.ldq = lds[2 * i]; L.ldk = lds[2 * i + 1];
+        L.B = dims[6 * i]; L.H = dims[6 * i + 1]; L.N = dims[6 * i + 2]; L.M = dims[6 * i + 3]; L.d = dims[6 * i + 4]; L.G = dims[6 * i + 5];
+        L.scale = scales ? scales[i] : 1.f;
+        ADAP_REQUIRE(L.q && L.k && L.tok_w && (fwd ? (L.tokmap != nullptr) : (L.dt && L.ws)), ADAP_ERR_SHAPE, "%s: null pointer (layer %d)", who, i);
+        ADAP_REQUIRE(L.B > 0 && L.H > 0 && L.N > 0 && (long)L.B * L.H <= 65535, ADAP_ERR_SHAPE, "%s: dims (layer %d)", who, i);
+        ADAP_REQUIRE(L.G >= 1 && L.G <= TOK_MAXG && L.M >= 1 && L.M <= 192 && L.d >= 8 && L.d <= 160 && L.d % 8 == 0, ADAP_ERR_UNSUPPORTED,
+                     "%s: G=%d M=%d d=%d (layer %d)", who, L.G, L.M, L.d, i);
+        ADAP_REQUIRE(L.ldq % 8 == 0 && ((uintptr_t)L.q % 16) == 0 && L.ldk % 4 == 0 && ((uintptr_t)L.k & 7) == 0, ADAP_ERR_ALIGN,
+                     "%s: q / k alignment (layer %d)", who, i);
+        ADAP_REQUIRE(tokmap_kw_lds(L.M, L.d, L.G) <= 150 * 1024, ADAP_ERR_UNSUPPORTED, "%s: M=%d keys x d=%d do not fit the LDS stage", who, L.M, L.d);
+    }
+    return ADAP_OK;
+}
+
+// adap_attention_capture's token maps (no dense side outputs) for n layers in ONE launch: the same arithmetic per layer.
+extern "C" int adap_attention_tokmap_fwd_batched(int n, const void* const* ptrs, const long* lds, const int* dims, const float* scales,
+                                                 void* stream) {
+    TokBatch bt = {};
+    int rc = tok_batch_fill(bt, n, ptrs, lds, dims, scales, true, "attention_tokmap_fwd_batched");
+    if (rc) return rc;
+    unsigned gx = 0, gy = 0;
+    size_t lds_b = 0;
+    for (int i = 0; i < n; ++i) {
+        const TokLayer& L = bt.L[i];
+        gx = std::max(gx, (unsigned)((L.N + TOKF_ROWS - 1) / TOKF_ROWS));
+        gy = std::max(gy, (unsigned)(L.B * L.H));
+        lds_b = std::max(lds_b, tokmap_kw_lds(L.M, L.d, L.G));
+    }
+    tokmap_allow_lds(attn_tokmap_fwd_batched_kernel, lds_b);
+    hipLaunchKernelGGL(attn_tokmap_fwd_batched_kernel, dim3(gx, gy, n), dim3(256), lds_b, (hipStream_t)stream, bt);
+    return adap_check_launch("attention_tokmap_fwd_batched");
+}
+
+// adap_attention_tokmap_prep for n layers in THREE launches (kw, gq partials, gq): the same arithmetic per layer.
+extern "C" int adap_attention_tokmap_prep_batched(int n, const void* const* ptrs, const long* lds, const int* dims, void* stream) {
+    TokBatch bt = {};
+    int rc = tok_batch_fill(bt, n, ptrs, lds, dims, nullptr, false, "attention_tokmap_prep_batched");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned bh_max = 0, ch_max = 0;
+    size_t lds_kw = 0, lds_gq = 0;
+    long tot_max = 0;
+    for (int i = 0; i < n; ++i) {
+        const TokLayer& L = bt.L[i];
+        bh_max = std::max(bh_max, (unsigned)(L.B * L.H));
+        ch_max = std::max(ch_max, (unsigned)((L.N + CAPB_ROWS - 1) / CAPB_ROWS));
+        lds_kw = std::max(lds_kw, tokmap_kw_lds(L.M, L.d, L.G));
+        lds_gq = std::max(lds_gq, tokmap_gq_lds(L.d, L.G));
+        tot_max = std::max(tot_max, (long)L.B * L.H * L.G * L.d);
+    }
+    tokmap_allow_lds(attn_tokmap_kw_batched_kernel, lds_kw);
+    hipLaunchKernelGGL(attn_tokmap_kw_batched_kernel, dim3(bh_max, n), dim3(256), lds_kw, s, bt);
+    tokmap_allow_lds(attn_tokmap_gq_batched_kernel, lds_gq);
+    hipLaunchKernelGGL(attn_tokmap_gq_batched_kernel, dim3(ch_max, bh_max, n), dim3(256), lds_gq, s, bt);
+    hipLaunchKernelGGL(attn_tokmap_gq_reduce_batched_kernel, dim3((unsigned)((tot_max + 255) / 256), n), dim3(256), 0, s, bt);
+    return adap_check_launch("attention_tokmap_prep_batched");
 }
 
 extern "C" long adap_attention_tokmap_bwd_workspace_floats(int B, int H, int N, int d, int G) {

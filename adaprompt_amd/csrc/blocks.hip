@@ -212,7 +212,7 @@ extern "C" int adap_stblock_fwd(const int* cfg, const void* const* w, void* cons
     if (kv_ready)
         ADAP_REQUIRE(hipStreamWaitEvent((hipStream_t)stream, kv_ready, 0) == hipSuccess, ADAP_ERR_HIP, "stblock_fwd: wait");
     ST_TRY(adap_attention_fwd(q2, C, kv2, 2 * C, kv2 + C, 2 * C, nullptr, nullptr, o2, C, lse2, B, heads, N, M, d, scale2, stream));
-    if (capture) {
+    if (capture && !(flags & ADAP_STB_CAPTURE_DEFERRED)) {
         // the side outputs are read by the losses after the UNet's forward: beside the rest of the block, joined by the caller
         if (lane) ST_TRY(hand_over(stream, lane));
         ST_TRY(adap_attention_capture(q2, C, kv2, 2 * C, nullptr, nullptr, nullptr, (const float*)t[ADAP_STF_TOK_W],
@@ -287,7 +287,7 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
              *dkvc = s16 + 15 * rc_;
     int rc;
     hipEvent_t tok_ready = nullptr;
-    if (tok) {
+    if (tok && !(flags & ADAP_STB_TOKPREP_GIVEN)) {
         // the token maps' gradient, its dq / dk-independent half (kw = w^T K, gq = dT^T Q): beside the feed-forward's backward
         if (lane) ST_TRY(hand_over(stream, lane));
         ST_TRY(adap_attention_tokmap_prep((const float*)t[ADAP_STG_D_TOKMAP], (const float*)t[ADAP_STG_TOK_W], q2, C, kv2, 2 * C,

@@ -485,6 +485,7 @@ _STB_WS = {}
 # include/adaprompt_hip.h: ADAP_STB_* flags
 _STB_SAME_CTX, _STB_COMPACT, _STB_CAPTURE, _STB_Q1_PRESCALED, _STB_TOKGRAD, _STB_WANT_GK, _STB_WANT_GV, _STB_G_BF16, _STB_NO_GX, \
     _STB_KV_GIVEN = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+_STB_CAPTURE_DEFERRED, _STB_TOKPREP_GIVEN = 1024, 2048
 STB_PRUNE_GX = os.environ.get("ADAP_STB_PRUNE_GX", "1") != "0"     # A/B switch: skip the input-gradient half where it is not needed
 
 
@@ -522,6 +523,79 @@ def _stb_weights(P, same_ctx):
           and pout.bias is not None and all(pk.O4 == pk.O and pk.I8 == pk.I for pk in (pin, qkv, o1, q2, o2, ff1g, ff2, pout, kv)))
     hit = P["_stb"] = ((ctypes.c_void_p * len(fw))(*fw), (ctypes.c_void_p * len(bw))(*bw), ok, kv.I)
     return hit
+
+
+# ---------------------------------------------------------------------------------------------
+# The distillation layers' token maps off the blocks' chains (csrc/attention.hip TokBatch): a block's capture launch, and the
+# three launches of its gradient prologue (kw = w^T K, gq = dT^T Q), are dependent links of the block's chain -- ~20 us of a lane's
+# time each -- although nothing in the block reads the maps, and the prologue only needs what the forward saved plus the losses'
+# gradients.  With BATCH_TOKMAPS the blocks of one UNet forward DEFER their captures (``DEFERRED_CAPTURES``, flushed by
+# UNetModel.forward as ONE launch over all layers) and ``prepare_tokmap_backward`` makes all layers' prologues in THREE launches
+# in front of ``autograd.backward``: 12 + 36 launches per micro-batch become 1 + 3.
+# ---------------------------------------------------------------------------------------------
+BATCH_TOKMAPS = os.environ.get("ADAP_BATCH_TOKMAPS", "1") != "0"
+DEFERRED_CAPTURES = None          # a list while a UNetModel.forward collects its blocks' token-map captures
+
+
+def _tok_batched(entry, items, fwd):
+    """items: [(q [B,N,C] bf16, kv [B,M,2C] bf16, tok_w, tokmap | None, d_tokmap | None, workspace | None, heads, scale)]"""
+    import ctypes
+    for i0 in range(0, len(items), 16):
+        part = items[i0:i0 + 16]
+        n = len(part)
+        ptrs, lds, dims, scales = (ctypes.c_void_p * (6 * n))(), (ctypes.c_long * (2 * n))(), (ctypes.c_int * (6 * n))(), \
+            (ctypes.c_float * n)()
+        for i, (q, kv, tok_w, tokmap, dt, ws, heads, scale) in enumerate(part):
+            B, N, C = q.shape
+            M = kv.shape[1]
+            for j, t_ in enumerate((q, kv, tok_w, tokmap, dt, ws)):
+                ptrs[6 * i + j] = None if t_ is None else t_.data_ptr()
+            lds[2 * i], lds[2 * i + 1] = ops._rows_ld(q)[1], ops._rows_ld(kv)[1]
+            for j, v in enumerate((B, heads, N, M, C // heads, tok_w.shape[2])):
+                dims[6 * i + j] = v
+            scales[i] = scale
+        if fwd:
+            ops._lib.call(entry, n, ptrs, lds, dims, scales, ops._stream())
+        else:
+            ops._lib.call(entry, n, ptrs, lds, dims, ops._stream())
+
+
+def flush_deferred_captures():
+    """the token maps the blocks of the current UNet forward deferred, as one launch (UNetModel.forward, after its last block)."""
+    global DEFERRED_CAPTURES
+    items, DEFERRED_CAPTURES = DEFERRED_CAPTURES, None
+    if items:
+        _tok_batched("adap_attention_tokmap_fwd_batched", items, True)
+
+
+def prepare_tokmap_backward(roots, grads):
+    """call in front of ``torch.autograd.backward(roots, grads)``: for every root that is a transformer block's token-map output
+    (the fused regularisers' gradients enter there), the block's gradient prologue is made NOW, all layers in three launches; the
+    block's backward finds it on its ctx (``tok_prep``) and skips its own three."""
+    if not BATCH_TOKMAPS:
+        return
+    items, owners = [], []
+    for r, g in zip(roots, grads):
+        fn = getattr(r, "grad_fn", None)
+        if fn is None or type(fn).__name__ != "SpatialTransformerFnBackward" or not getattr(fn, "fast", False):
+            continue
+        tok_w = getattr(fn, "tok_w", None)
+        if tok_w is None or getattr(r, "output_nr", -1) != 4 or g is None or g.dtype != torch.float32 or not g.is_contiguous():
+            continue
+        if getattr(fn, "tok_prep", None) is not None:
+            continue
+        x, _gn, _tres, _ln, _qkv1, obuf, _lse, _hh, _kv1c, kv2, ctx_k, _cv = fn.saved_tensors
+        B, H, W, C = x.shape
+        heads, G = fn.heads, tok_w.shape[2]
+        if tuple(g.shape) != (B, heads, H * W, G):
+            continue
+        ws = torch.empty(_stb_sizes(B, H * W, C, ctx_k.shape[-1], kv2.shape[1], heads, G)[3], device=x.device, dtype=torch.float32)
+        items.append((obuf[1], kv2, tok_w, None, g, ws, heads, 1.0))
+        owners.append((fn, ws, g))
+    if items:
+        _tok_batched("adap_attention_tokmap_prep_batched", items, False)
+        for fn, ws, g in owners:
+            fn.tok_prep = (ws, g.data_ptr(), g._version)
 
 
 HOIST_KV = os.environ.get("ADAP_HOIST_KV", "1") != "0"      # A/B switch: the 16 layers' context K | V projections as grouped launches
@@ -763,12 +837,18 @@ class SpatialTransformerFn(torch.autograd.Function):
                                       ln_stats.data_ptr(), qkv1.data_ptr(), obuf.data_ptr(), lse.data_ptr(), hh.data_ptr(), dp(kv1c),
                                       dp(tokmap), out.data_ptr(), scr.data_ptr(), wp, (wp + 4 * gn_n) if sk_n else 0,
                                       (wp + 4 * (gn_n + sk_n)) if sk_n else 0, ops.gn_sync_buffer(dev))
+        deferred = capture and DEFERRED_CAPTURES is not None
+        if deferred:
+            flags |= _STB_CAPTURE_DEFERRED
         cfg = (ctypes.c_int * 11)(B, H, W, C, heads, M, Cctx, flags, G, 0, 0)
         ops._lib.call("adap_stblock_fwd", cfg, fw, tens, 0 if lane is None else lane.side.cuda_stream, ops._stream())
         STB_CALLS[0] += 1
-        if capture and lane is not None:
+        if deferred:         # (the same arithmetic, one launch for all layers behind the UNet's forward: flush_deferred_captures)
+            DEFERRED_CAPTURES.append((obuf[1], kv2, tok_w, tokmap, None, None, heads, float(C // heads) ** -0.5))
+        if capture and lane is not None and not deferred:
             lane.pending = lane.mark_now()              # the capture's join is deferred to UNetModel.forward (join_side_lane)
         ctx.fast = True
+        ctx.tok_prep = None
         ctx.P, ctx.heads, ctx.same_ctx = P, heads, same_ctx
         ctx.key_mask, ctx.key_compaction = key_mask, kc
         ctx.tok_w = tok_w if capture else None
@@ -831,6 +911,11 @@ class SpatialTransformerFn(torch.autograd.Function):
         if tok:
             g_tokmap = g_tokmap.contiguous()
             assert g_tokmap.dtype == torch.float32 and tuple(g_tokmap.shape) == (B, heads, N, G)
+            given = ctx.tok_prep
+            # (made by prepare_tokmap_backward from exactly this gradient tensor: otherwise the block makes its own)
+            if given is not None and given[1] == g_tokmap.data_ptr() and given[2] == g_tokmap._version:
+                prep_p = given[0].data_ptr()
+                flags |= _STB_TOKPREP_GIVEN
         dp = lambda t: 0 if t is None else t.data_ptr()          # noqa: E731
         _fw, bw, _ok, _ = _stb_weights(P, same_ctx)
         km = ctx.key_mask

@@ -1318,6 +1318,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         ONE pass over the tape, so the UNet's backward runs once and receives the attnscore gradients on the way."""
         roots, grads = LatentDiffusion._backward_roots(model_output, grad, aux)
         if roots:
+            from .... import functional as HF
+            HF.prepare_tokmap_backward(roots, grads)       # all layers' token-map gradient prologues, three launches
             torch.autograd.backward(roots, grads)
 
     @staticmethod
@@ -1835,6 +1837,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             roots += r
             grads += g
         if roots:
+            from .... import functional as HF
+            HF.prepare_tokmap_backward(roots, grads)
             torch.autograd.backward(roots, grads)
         if reducer is not None:
             reducer.reduce()

@@ -482,6 +482,21 @@ class UNetModel(nn.Module):
         h = x.float().permute(0, 2, 3, 1).contiguous()                   # NCHW latent -> pixel-major
         hs = []
         layer_idx = 0
+        # the distillation layers' token maps: nothing inside the UNet reads them -- the blocks defer the capture and ONE launch
+        # behind the last block makes all of them (HF.flush_deferred_captures)
+        defer = HF.BATCH_TOKMAPS and tm_only and bool(distill) and HF.DEFERRED_CAPTURES is None
+        if defer:
+            HF.DEFERRED_CAPTURES = []
+        try:
+            h = self._run_blocks(h, hs, run, grab, layer_idx)
+            if defer:
+                HF.flush_deferred_captures()
+        finally:
+            if defer:
+                HF.DEFERRED_CAPTURES = None
+        return self._finish_forward(h, acts, tok_w, extra_info, stack)
+
+    def _run_blocks(self, h, hs, run, grab, layer_idx):
         for module in self.input_blocks:
             h = run(module, h, layer_idx)
             if torch.is_grad_enabled() and h.requires_grad:
@@ -501,6 +516,9 @@ class UNetModel(nn.Module):
             if len(module) > 1 and isinstance(module[1], SpatialTransformer):
                 grab(layer_idx, module[1], h)
             layer_idx += 1
+        return h
+
+    def _finish_forward(self, h, acts, tok_w, extra_info, stack):
         HF.join_side_lane(h.device)          # the captures of the distillation layers ran beside their blocks
         if extra_info is not None:
             extra_info["ca_layers_activations"] = {

@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--entry", choices=["window", "lightning"], default="window",
                     help="how the timed loop drives the model: 'window' = training_window per accumulation window (the default); "
                          "'lightning' = training_step(batch, batch_idx) once per micro-batch, as Lightning calls it (ddpm.py:515), "
-                         "with adaprompt_amd.trainer.Trainer attached (lanes + one window of latents prefetched ahead).  The default "
+                         "with adaprompt_amd.trainer.Trainer attached (lanes + two windows of latents prefetched ahead).  The default "
                          "run times the other entry as an extra leg (`entry_lightning`)")
     ap.add_argument("--no-entry-leg", action="store_true", help="skip the extra leg that times the other entry")
     ap.add_argument("--no-rehearse-exchange", action="store_true",
@@ -450,7 +450,7 @@ def main():
     def lightning_runner():
         from adaprompt_amd.trainer import Trainer
         tr = Trainer(max_steps=60000, every_n_train_steps=0, micro_batch_lanes=True,
-                     prefetch_windows=int(os.environ.get("ADAP_ENTRY_PREFETCH_WINDOWS", "1")))
+                     prefetch_windows=int(os.environ.get("ADAP_ENTRY_PREFETCH_WINDOWS", "2")))
         tr.optimizer, tr.scheduler, tr.reducer = opt, sched, reducer
         tr.lanes = lanes                                   # (the lanes this process already has: streams are few and shared)
         object.__setattr__(ld, "trainer", tr)
@@ -478,7 +478,7 @@ def main():
         if lanes is None:
             raise SystemExit("--entry lightning needs the lanes (no --no-lanes / --graph / --no-prefetch)")
         _run_l, _close_l = lightning_runner()
-        _run_l(4)          # untimed: the entry keeps a window of batches buffered ahead, so its first calls run nothing
+        _run_l(6)          # untimed: the entry keeps two windows of batches buffered ahead, so its first calls run nothing
 
         def run_steps(first, n):                            # noqa: F811 -- the timed loop through the per-batch entry
             return _run_l(n)
@@ -598,11 +598,11 @@ def main():
 
     if rank == 0 and world == 1 and lanes is not None and not args.no_entry_leg and ld.batch_idx % 2 == 0 and args.entry == "window":
         run_l, close_l = lightning_runner()
-        run_l(6)                                            # fills the look-ahead buffer, warms the global generator's path
+        run_l(8)                                            # fills the look-ahead buffer, warms the global generator's path
         d_l = timed_leg(run_l, n_leg)
         close_l()
         d_w = timed_leg(lambda n: window_run_steps(0, n), n_leg)
-        entry_leg = {"entry": "training_step(batch, batch_idx) per micro-batch, Trainer attached (lanes, 1 window of latents ahead)",
+        entry_leg = {"entry": "training_step(batch, batch_idx) per micro-batch, Trainer attached (lanes, 2 windows of latents ahead)",
                      "ms_per_step": round(1e3 * d_l / n_leg, 3), "images_per_sec": round(B * n_leg / d_l, 2),
                      "window_entry_ms_per_step_back_to_back": round(1e3 * d_w / n_leg, 3),
                      "ratio_to_window_entry": round(d_l / d_w, 4)}

@@ -165,6 +165,10 @@ int adap_resblock_bwd(const void* g, int g_dtype, const float* g32, const float*
 #define ADAP_STB_G_BF16 128
 #define ADAP_STB_NO_GX 256          /* bwd: the block's input needs no gradient -- stop after the cross attention (GX / GX16 may be NULL) */
 #define ADAP_STB_KV_GIVEN 512       /* fwd: KV2 already holds the context's K | V projection (hoisted, batched over layers): not recomputed */
+#define ADAP_STB_CAPTURE_DEFERRED 1024   /* fwd (with ADAP_STB_CAPTURE): the token maps are NOT made here -- the caller fills TOKMAP with
+                                            adap_attention_tokmap_fwd_batched behind the UNet's forward */
+#define ADAP_STB_TOKPREP_GIVEN 2048      /* bwd (with ADAP_STB_TOKGRAD): TOK_PREP already holds adap_attention_tokmap_prep's result
+                                            (adap_attention_tokmap_prep_batched in front of the backward) */
 enum { ADAP_STW_GN_G, ADAP_STW_GN_B, ADAP_STW_PIN_W, ADAP_STW_PIN_B, ADAP_STW_LN1_G, ADAP_STW_LN1_B, ADAP_STW_QKV, ADAP_STW_OUT1_W,
        ADAP_STW_OUT1_B, ADAP_STW_LN2_G, ADAP_STW_LN2_B, ADAP_STW_Q2, ADAP_STW_KV2, ADAP_STW_V2, ADAP_STW_OUT2_W, ADAP_STW_OUT2_B,
        ADAP_STW_LN3_G, ADAP_STW_LN3_B, ADAP_STW_FF1G_W, ADAP_STW_FF1G_B, ADAP_STW_FF2_W, ADAP_STW_FF2_B, ADAP_STW_POUT_W,
@@ -305,6 +309,15 @@ int adap_attention_capture(const void* q, long ldq, const void* k, long ldk, flo
  * stream as soon as d_tokmap is known), adap_attention_bwd_tok = adap_attention_bwd + scale * d_tokmap . kw into dq and
  * scale * w . gq into dk inside its epilogues. */
 long adap_attention_tokmap_prep_workspace_floats(int B, int H, int N, int d, int G);
+/* The token maps of n <= 16 layers in ONE launch, and their gradient prologue (adap_attention_tokmap_prep) for n layers in THREE:
+ * the distillation layers' maps are read by the losses only after the UNet's forward, and the prologue depends only on what the
+ * forward saved and on the losses' gradients, so neither has to sit on a transformer block's dependency chain
+ * (ldm/modules/diffusionmodules/openaimodel.py capture of the 12 distillation layers, ddpm.py:3246-3270).  Flat HOST arrays:
+ * ptrs [n][6] = {q, k, tok_w, tokmap (fwd) | NULL, d_tokmap (prep) | NULL, workspace (prep) | NULL} (device pointers),
+ * lds [n][2] = {ldq, ldk}, dims [n][6] = {B, H, N, M, d, G}, scales [n].  Per layer the arithmetic of the single-layer calls. */
+int adap_attention_tokmap_fwd_batched(int n, const void* const* ptrs, const long* lds, const int* dims, const float* scales,
+                                      void* stream);
+int adap_attention_tokmap_prep_batched(int n, const void* const* ptrs, const long* lds, const int* dims, void* stream);
 int adap_attention_tokmap_prep(const float* d_tokmap, const float* tok_w, const void* q, long ldq, const void* k, long ldk,
                                float* workspace, int B, int H, int N, int M, int d, int G, void* stream);
 int adap_attention_bwd_tok(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,

@@ -770,6 +770,51 @@ def test_fused_window_with_unfrozen_unet_equals_sequential_steps():
     assert den > 0 and num <= 8e-2 * den, (num, den)
 
 
+def test_batched_token_maps_equal_the_per_layer_launches():
+    """``functional.BATCH_TOKMAPS``: the 12 distillation layers' token-map captures as ONE launch behind the UNet's forward
+    (``adap_attention_tokmap_fwd_batched``) and their gradient prologues as THREE in front of the backward
+    (``prepare_tokmap_backward`` -> ``adap_attention_tokmap_prep_batched``) against one capture launch and three prologue launches
+    inside every block: the same arithmetic per layer, so eps, the token maps and the context gradient are equal bit for bit."""
+    from adaprompt_amd import functional as HF
+    B, M = 2, 77
+    unet = build_unet(NARROW)
+    x = synth.synthetic_input("btm.x", (B, 4, 64, 64)).to(dev())
+    t = torch.tensor([300, 760]).to(dev())
+    ctx0 = synth.synthetic_input("btm.ctx", (16 * B, M, NARROW["context_dim"])).to(dev())
+    w = synth.synthetic_input("btm.gw", (B, 4, 64, 64)).to(dev())
+    subj = (torch.arange(B, device=dev()).repeat_interleave(16), torch.arange(4, 20, device=dev()).repeat(B))
+    bgi = (torch.arange(B, device=dev()).repeat_interleave(4), torch.arange(24, 28, device=dev()).repeat(B))
+
+    def run(batched):
+        was = HF.BATCH_TOKMAPS
+        HF.BATCH_TOKMAPS = batched
+        try:
+            ctx = ctx0.clone().requires_grad_(True)
+            extra = {"use_layerwise_context": True, "use_conv_attn_kernel_size": -1, "iter_type": "normal_recon", "is_training": True,
+                     "capture_distill_attn": True, "placeholder2indices": None, "img_mask": border_mask(B, 64, 64, 6).to(dev()),
+                     "subj_indices": subj, "bg_indices": bgi, "capture_token_maps_only": True}
+            eps = unet(x, t, context=ctx, context_in=None, extra_info=extra)
+            tms = extra["ca_layers_activations"]["attnscore_tokmap"]
+            assert len(tms) == 12
+            roots = [eps] + [tms[li] for li in sorted(tms)]
+            grads = [w] + [synth.synthetic_input(f"btm.dt{li}", tuple(tms[li].shape)).to(dev()) * 1e-3 for li in sorted(tms)]
+            HF.prepare_tokmap_backward(roots, grads)
+            given = sum(getattr(r.grad_fn, "tok_prep", None) is not None for r in roots[1:])
+            torch.autograd.backward(roots, grads)
+            torch.cuda.synchronize()
+            return eps.detach().clone(), ctx.grad.detach().clone(), {li: v.detach().clone() for li, v in tms.items()}, given
+        finally:
+            HF.BATCH_TOKMAPS = was
+
+    e1, g1, tm1, n1 = run(True)
+    e0, g0, tm0, n0 = run(False)
+    assert n1 == 12 and n0 == 0, (n1, n0)
+    assert torch.equal(e1, e0) and torch.equal(g1, g0)
+    for li in tm0:
+        assert torch.equal(tm1[li], tm0[li]), li
+    assert float(g1.abs().max()) > 0 and torch.isfinite(g1).all()
+
+
 ROLLOUT_EPS_TOL = EPS_TOL  # teacher eps / x0 at every rollout step (measured 1e-2 / 4e-3: the feedback does not amplify)
 DISTILL_LOSS_TOL = LOSS_TOL  # sum over steps of masked MSE(student eps, teacher eps): the north-star bar (measured 2.6e-4)
 
