@@ -301,8 +301,12 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
     ST_TRY(lin(gop, g_bf16 ? 1 : 0, ldg, wb[ADAP_STWB_POUT], nullptr, nullptr, gt, gth, C, rows, C, C, sk_ws, stream));
     // feed-forward
     ST_TRY(adap_linear_geglu_bwd(gth, C, wb[ADAP_STWB_FF2], hh, 8 * C, ghh, 8 * C, rows, C, 4 * C, stream));
+    // (a long-K data gradient: where it goes out split, its reduce pass does the LayerNorm backward on the rows it sums --
+    // adap_conv2d_next_ln_bwd: the same numbers, one launch less on the chain)
+    ST_TRY(adap_conv2d_next_ln_bwd(t2, C, (const float*)wb[ADAP_STWB_LN3_G], l3m, l3r, gt, C, 1, gth, C));
     ST_TRY(lin(ghh, 1, 8 * C, wb[ADAP_STWB_FF1G], nullptr, nullptr, gn, nullptr, 0, rows, 8 * C, C, sk_ws, stream));
-    ST_TRY(adap_layernorm_bwd(gn, C, t2, C, (const float*)wb[ADAP_STWB_LN3_G], l3m, l3r, gt, C, 1, gth, C, rows, C, stream));
+    if (!adap_conv2d_last_ln_bwd())
+        ST_TRY(adap_layernorm_bwd(gn, C, t2, C, (const float*)wb[ADAP_STWB_LN3_G], l3m, l3r, gt, C, 1, gth, C, rows, C, stream));
     // cross attention
     ST_TRY(lin(gth, 1, C, wb[ADAP_STWB_OUT2], nullptr, nullptr, nullptr, go, C, rows, C, C, sk_ws, stream));
     if (tok_ready)
@@ -351,8 +355,10 @@ extern "C" int adap_stblock_bwd(const int* cfg, const void* const* wb, void* con
                                   lse1, at_ws, nullptr, dqkv1, 3 * C, nullptr, dqkv1 + C, 3 * C, nullptr, dqkv1 + 2 * C, 3 * C, B, heads, N, N, d,
                                   scale1, stream));
     }
+    ST_TRY(adap_conv2d_next_ln_bwd(t0, C, (const float*)wb[ADAP_STWB_LN1_G], l1m, l1r, gt, C, 1, gth, C));
     ST_TRY(lin(dqkv1, 1, 3 * C, wb[ADAP_STWB_QKV], nullptr, nullptr, gn, nullptr, 0, rows, 3 * C, C, sk_ws, stream));
-    ST_TRY(adap_layernorm_bwd(gn, C, t0, C, (const float*)wb[ADAP_STWB_LN1_G], l1m, l1r, gt, C, 1, gth, C, rows, C, stream));
+    if (!adap_conv2d_last_ln_bwd())
+        ST_TRY(adap_layernorm_bwd(gn, C, t0, C, (const float*)wb[ADAP_STWB_LN1_G], l1m, l1r, gt, C, 1, gth, C, rows, C, stream));
     // proj_in, GroupNorm (dx + g: the block's residual path, no clone of g)
     ST_TRY(lin(gth, 1, C, wb[ADAP_STWB_PIN], nullptr, nullptr, nullptr, gxn, C, rows, C, C, sk_ws, stream));
     ST_TRY(adap_groupnorm_bwd(gxn, 1, C, x, 0, C, (const float*)wb[ADAP_STWB_GN_G], (const float*)wb[ADAP_STWB_GN_B], gn_stats,

@@ -675,6 +675,85 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvParams p, int M,
 }
 
 
+// split-K second pass with the LayerNorm BACKWARD that consumes its result folded in (adap_conv2d_next_ln_bwd): the data-gradient
+// contraction in front of a LayerNorm's backward (attention.py:267-269 norm1 / norm3 behind to_q|k|v / ff.net.0.proj) is a long-K
+// GEMM that goes out split whenever the level has few pixel tiles -- its reduce pass already is a launch of its own that walks
+// whole rows, so it can hand each row straight to the LayerNorm arithmetic instead of through memory and a further launch.  One
+// wave per row, as ln_bwd_kernel (norms.hip); the slab sum, alpha / bias / residual and the LayerNorm arithmetic are those of
+// splitk_reduce_kernel followed by ln_bwd_kernel in the same order: bit-identical to the two launches.  The contraction's own
+// output (dy) is not stored.
+struct LnBwdExt {
+    const float* x; long ldx;          // the LayerNorm's input (saved by the forward)
+    const float* gamma; const float* mean; const float* rstd;
+    float* dx; long lddx; int accumulate;
+    uint16_t* dx16; long lddx16;
+};
+#define SK_LN_MAXV 5    // float4 per lane: Cout <= 1280 (norms.hip LN_MAXV)
+
+__global__ __launch_bounds__(256) void splitk_reduce_ln_bwd_kernel(ConvParams p, LnBwdExt e, int M) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int D = p.Cout, Q = D >> 2;
+    const float mu = e.mean[row], rs = e.rstd[row];
+    float dyh[SK_LN_MAXV][4], xh[SK_LN_MAXV][4];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < SK_LN_MAXV; ++k) {
+        const int q = lane + 64 * k;
+        if (q < Q) {
+            const int c0 = 4 * q;
+            float4 a = *(const float4*)(p.ws + (size_t)row * D + c0);
+            for (int z = 1; z < p.ksplit; ++z) {
+                const float4 t = *(const float4*)(p.ws + ((size_t)z * M + row) * D + c0);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            float ds[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+            if (p.bias) {
+                const float4 t = *(const float4*)(p.bias + c0);
+                ds[0] += t.x; ds[1] += t.y; ds[2] += t.z; ds[3] += t.w;
+            }
+            if (p.residual) {
+                const float4 t = *(const float4*)(p.residual + (size_t)row * p.ldr + c0);
+                ds[0] += t.x; ds[1] += t.y; ds[2] += t.z; ds[3] += t.w;
+            }
+            const float4 xv = *(const float4*)(e.x + row * e.ldx + c0);
+            const float4 g = *(const float4*)(e.gamma + c0);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xh[k][c] = (xs[c] - mu) * rs;
+                dyh[k][c] = ds[c] * gs[c];
+                sa += dyh[k][c];
+                sb += dyh[k][c] * xh[k][c];
+            }
+        }
+    }
+    sa = wave_sum(sa) / D;
+    sb = wave_sum(sb) / D;
+#pragma unroll
+    for (int k = 0; k < SK_LN_MAXV; ++k) {
+        const int q = lane + 64 * k;
+        if (q < Q) {
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = rs * (dyh[k][c] - sa - xh[k][c] * sb);
+            float* dst = e.dx + row * e.lddx + 4 * q;
+            if (e.accumulate) {
+                const float4 t = *(const float4*)dst;
+                o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+            }
+            *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+            if (e.dx16) {
+                uint2 w;
+                w.x = pack_bf16x2(o[0], o[1]);
+                w.y = pack_bf16x2(o[2], o[3]);
+                *(uint2*)(e.dx16 + row * e.lddx16 + 4 * q) = w;
+            }
+        }
+    }
+}
+
 // =============================================================================================
 // Large-problem variant: 256 pixels x BN channels per workgroup, 8 waves (4 pixel quarters x 2 channel halves),
 // bf16 activations only, THREE LDS stages filled by LDS-DMA with the prefetch two K steps ahead: the wait
@@ -973,8 +1052,31 @@ static int num_cus() {
     return n;
 }
 
+// the LayerNorm backward folded into the CURRENT adap_conv2d_nhwc call's split-K reduce (adap_conv2d_next_ln_bwd), or inactive
+static thread_local LnBwdExt g_ln_bwd_cur = {};
+static thread_local bool g_ln_bwd_cur_on = false;
+static thread_local int g_ln_bwd_last = 0;
+
+static thread_local LnBwdExt g_ln_bwd_next = {};
+static thread_local bool g_ln_bwd_next_on = false;
+extern "C" int adap_conv2d_next_ln_bwd(const float* x, long ldx, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                       long lddx, int accumulate, void* dx16, long lddx16) {
+    ADAP_REQUIRE(x && gamma && mean && rstd && dx, ADAP_ERR_SHAPE, "conv2d_next_ln_bwd: null pointer");
+    ADAP_REQUIRE(ldx % 4 == 0 && lddx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                 (!dx16 || (lddx16 % 4 == 0 && ((uintptr_t)dx16 % 8) == 0)), ADAP_ERR_ALIGN, "conv2d_next_ln_bwd: alignment");
+    g_ln_bwd_next = LnBwdExt{x, ldx, gamma, mean, rstd, dx, lddx, accumulate, (uint16_t*)dx16, lddx16};
+    g_ln_bwd_next_on = true;
+    return ADAP_OK;
+}
+extern "C" int adap_conv2d_last_ln_bwd(void) { return g_ln_bwd_last; }
+
 static void launch_reduce(const ConvParams& p, hipStream_t stream) {
     const int M = p.B * p.Hout * p.Wout;
+    if (g_ln_bwd_cur_on && !p.chan_add && p.epi == 0 && p.Cout % 4 == 0 && p.Cout <= 256 * SK_LN_MAXV) {
+        hipLaunchKernelGGL(splitk_reduce_ln_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, p, g_ln_bwd_cur, M);
+        g_ln_bwd_last = 1;
+        return;
+    }
     long total = (long)M * (p.Cout >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -1713,6 +1815,16 @@ extern "C" int adap_conv2d_nhwc(
     const int gn_next_cpg = g_gn_next_cpg;
     g_gn_next = nullptr;
     g_gn_last_chunks = 0;
+    // ... and so is the one-shot LayerNorm-backward request (adap_conv2d_next_ln_bwd): live for this call only, on every exit
+    struct LnBwdScope {
+        LnBwdScope() {
+            g_ln_bwd_cur = g_ln_bwd_next;
+            g_ln_bwd_cur_on = g_ln_bwd_next_on;
+            g_ln_bwd_next_on = false;
+            g_ln_bwd_last = 0;
+        }
+        ~LnBwdScope() { g_ln_bwd_cur_on = false; }
+    } ln_scope;
     ADAP_REQUIRE(x && w_packed && (y32 || y16), ADAP_ERR_SHAPE, "conv2d: null pointer");
     ADAP_REQUIRE(x_dtype == 0 || x_dtype == 1, ADAP_ERR_UNSUPPORTED, "conv2d: x_dtype %d", x_dtype);
     ADAP_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cin > 0 && Cout > 0,

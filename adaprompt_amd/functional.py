@@ -911,10 +911,10 @@ class SpatialTransformerFn(torch.autograd.Function):
         if tok:
             g_tokmap = g_tokmap.contiguous()
             assert g_tokmap.dtype == torch.float32 and tuple(g_tokmap.shape) == (B, heads, N, G)
-            given = ctx.tok_prep
+            prep = ctx.tok_prep
             # (made by prepare_tokmap_backward from exactly this gradient tensor: otherwise the block makes its own)
-            if given is not None and given[1] == g_tokmap.data_ptr() and given[2] == g_tokmap._version:
-                prep_p = given[0].data_ptr()
+            if prep is not None and prep[1] == g_tokmap.data_ptr() and prep[2] == g_tokmap._version:
+                prep_p = prep[0].data_ptr()
                 flags |= _STB_TOKPREP_GIVEN
         dp = lambda t: 0 if t is None else t.data_ptr()          # noqa: E731
         _fw, bw, _ok, _ = _stb_weights(P, same_ctx)

@@ -102,6 +102,17 @@ int adap_conv2d_debug_force(int kind, int bn);
 int adap_conv2d_next_gn_partial(float* partial, int channels_per_group);
 int adap_conv2d_last_gn_chunks(void);
 
+/* The LayerNorm BACKWARD that consumes a contraction's output (attention.py:267-269: norm1 / norm3 behind the data gradients of
+ * to_q|k|v and ff.net.0.proj), folded into that contraction's split-K reduce pass.  adap_conv2d_next_ln_bwd arms the calling
+ * thread's NEXT adap_conv2d_nhwc call (one shot; arguments as adap_layernorm_bwd, with the call's output as dy and Cout as D).  If
+ * that call goes out split (and Cout <= 1280, no chan_add), its reduce launch does the LayerNorm arithmetic on every row it has
+ * just summed -- bit-identical to the reduce followed by adap_layernorm_bwd -- and the call's y32 / y16 are NOT written;
+ * adap_conv2d_last_ln_bwd() is then 1.  Otherwise it is 0, the outputs are written as usual and the caller runs
+ * adap_layernorm_bwd itself. */
+int adap_conv2d_next_ln_bwd(const float* x, long ldx, const float* gamma, const float* mean, const float* rstd, float* dx,
+                            long lddx, int accumulate, void* dx16, long lddx16);
+int adap_conv2d_last_ln_bwd(void);
+
 /* conv3x3 (stride 1, pad 1) on an RGB image -- the VAE encoder's conv_in (model.py:426, 468) -- with the whole 3 x 3 x 3 patch of a
  * pixel as ONE K step of the matrix core (k = 3 * tap + channel) instead of nine steps of a channel dimension padded 3 -> 64.
  * x_hwc f32 [B][H][W][ldx >= 3]; w_packed = adap_pack_conv_weight's forward pack [9][Cout][8] of the [Cout][3][3][3] weight;
