@@ -149,7 +149,7 @@ class KeyCompaction:
 
 # self-attention with a key mask at N >= this many tokens gathers the kept keys to the front and runs on them alone (two row
 # gathers per layer against ~1/4 of the key tiles at the training masks' border widths); ADAP_COMPACT_KEYS=0 switches it off
-COMPACT_KEYS_MIN_N = 1024 if os.environ.get("ADAP_COMPACT_KEYS", "1") != "0" else 1 << 30
+COMPACT_KEYS_MIN_N = int(os.environ.get("ADAP_COMPACT_KEYS_MIN_N", "1024")) if os.environ.get("ADAP_COMPACT_KEYS", "1") != "0" else 1 << 30
 
 
 # Set by UNetModel.forward for the duration of a pass: a stamp of ALL the model's parameters (sum of their version counters --

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""VAE encoder (bs=4, 512x512) alone, for rocprofv3 --stats: which kernels make up the first stage's ~10 ms."""
+"""The first stage alone: ``get_input`` (VAE encode of a bs-4 512 x 512 batch + posterior sample) ITERS times on one stream, timed
+with events; under ``rocprofv3 --kernel-trace --stats`` the per-kernel table of the encoder by itself (which of the step's
+chip-filling work is the encoder's, and where inside it)."""
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,14 +11,17 @@ import torch
 import bench
 
 dev = torch.device("cuda:0")
-torch.cuda.set_device(dev)
+ITERS = int(os.environ.get("ITERS", "20"))
 ld, hook = bench.build_model(dev)
-batch = bench.synthetic_batch(4, dev, 1)
-for _ in range(2):
-    ld.get_input(batch)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
+batch = bench.synthetic_batch(int(os.environ.get("BATCH", "4")), dev, 1234)
+pn = torch.randn(batch["image"].shape[0], 4, 64, 64, device=dev)
 for _ in range(5):
-    ld.get_input(batch)
+    ld.get_input(batch, pn)
 torch.cuda.synchronize()
-print(f"VAE encode bs=4: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(ITERS):
+    ld.get_input(batch, pn)
+e1.record()
+torch.cuda.synchronize()
+print(f"VAE encode + sample, bs {batch['image'].shape[0]}: {e0.elapsed_time(e1) / ITERS:.3f} ms per call", flush=True)
