@@ -533,7 +533,6 @@ def _stb_weights(P, same_ctx):
 # UNetModel.forward as ONE launch over all layers) and ``prepare_tokmap_backward`` makes all layers' prologues in THREE launches
 # in front of ``autograd.backward``: 12 + 36 launches per micro-batch become 1 + 3.
 # ---------------------------------------------------------------------------------------------
-FORWARD_MARK = None                # callable(layer_idx) called behind every block of a UNetModel forward, or None
 BATCH_TOKMAPS = os.environ.get("ADAP_BATCH_TOKMAPS", "1") != "0"
 DEFERRED_CAPTURES = None          # a list while a UNetModel.forward collects its blocks' token-map captures
 

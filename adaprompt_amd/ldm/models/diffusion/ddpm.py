@@ -1917,37 +1917,12 @@ class LatentDiffusion(ConditioningMixin, DDPM):
                 if reqs[k] is None and after_forward is not None:          # (an iteration that ran its own passes: issued)
                     after_forward(k)
             self.batch_idx += 1
-        # LANE SKEW (ADAP_LANES_SKEW_LAYER = a UNet layer index, default off): the next lane's UNet pass starts only when the
-        # previous lane's has passed that block.  Two passes that start together are in the same phase all the way -- both in the
-        # 64 x 64 level's chip-filling kernels, then both in the deep levels' short launches -- skewed, one lane's large grids
-        # run beside the other's small ones.
-        skew_layer = int(os.environ.get("ADAP_LANES_SKEW_LAYER", "-1")) if lanes is not None else -1
-        skew_ev = None
-        from .... import functional as HF
         for k in range(n):
             if reqs[k] is None:
                 continue
             with on_lane(k):
                 self.iter_flags, self.training_percent = snaps[k]
-                if skew_ev is not None:
-                    torch.cuda.current_stream().wait_event(skew_ev)
-                    skew_ev = None
-                if skew_layer >= 0 and k + 1 < n and reqs[k + 1] is not None:
-                    ev_box = []
-
-                    def mark(layer_idx, ev_box=ev_box):
-                        if layer_idx == skew_layer and not ev_box:
-                            ev = torch.cuda.Event()
-                            ev.record()
-                            ev_box.append(ev)
-                    HF.FORWARD_MARK = mark
-                try:
-                    denoised = self.guided_denoise(*reqs[k])
-                finally:
-                    if HF.FORWARD_MARK is not None:
-                        HF.FORWARD_MARK = None
-                        skew_ev = ev_box[0] if ev_box else None
-                again, fronts[k] = self._resume(gens[k], denoised, cond_server(k))
+                again, fronts[k] = self._resume(gens[k], self.guided_denoise(*reqs[k]), cond_server(k))
                 if again is not None:
                     raise RuntimeError("training_window: a second denoising request")
                 if after_forward is not None:

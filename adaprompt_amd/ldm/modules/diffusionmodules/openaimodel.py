@@ -497,11 +497,8 @@ class UNetModel(nn.Module):
         return self._finish_forward(h, acts, tok_w, extra_info, stack)
 
     def _run_blocks(self, h, hs, run, grab, layer_idx):
-        mark = HF.FORWARD_MARK          # (training_window's lane skew: an event recorded behind a chosen block of lane 0's pass)
         for module in self.input_blocks:
             h = run(module, h, layer_idx)
-            if mark is not None:
-                mark(layer_idx)
             if torch.is_grad_enabled() and h.requires_grad:
                 h, h_skip = HF.SkipFn.apply(h)      # two consumers: their gradients meet in one fused add
             else:
@@ -511,15 +508,11 @@ class UNetModel(nn.Module):
                 grab(layer_idx, module[1], h)
             layer_idx += 1
         h = run(self.middle_block, h, layer_idx)
-        if mark is not None:
-            mark(layer_idx)
         grab(layer_idx, self.middle_block[1], h)
         layer_idx += 1
         for module in self.output_blocks:
             h = HF.ConcatFn.apply(h, hs.pop())
             h = run(module, h, layer_idx)
-            if mark is not None:
-                mark(layer_idx)
             if len(module) > 1 and isinstance(module[1], SpatialTransformer):
                 grab(layer_idx, module[1], h)
             layer_idx += 1
