@@ -99,8 +99,9 @@ ResW res_w(Cursor& cur, int cin, int cout) {
 
 // ResnetBlock.forward (model.py:108-142): x f32 [B,H,W,cin] -> y f32 [B,H,W,cout]; a16 / h16 bf16 scratch, skip f32 scratch
 // *xc: statistics records per image that the producer of x left in c.partB (0: none); on return, those of y
+// y16 (instead of y): the block's output goes to a Downsample's contraction alone -- written as its bf16 operand only
 int resblock(const Ctx& c, const ResW& w, const float* x, int H, int W, int cin, int cout, void* a16, void* h16, float* skip,
-             float* y, int* xc) {
+             float* y, int* xc, void* y16 = nullptr) {
     int rc, hc = 0;
     if (*xc > 0) rc = gn_stats(c, x, 0, H * W, cin, w.n1, 1, a16, c.partB, *xc);
     else rc = gn(c, x, 0, H * W, cin, w.n1, 1, a16);
@@ -114,7 +115,16 @@ int resblock(const Ctx& c, const ResW& w, const float* x, int H, int W, int cin,
         if ((rc = conv(c, x, 0, H, W, cin, w.nin, cout, 1, 1, 0, H, W, nullptr, skip, nullptr))) return rc;
         sk = skip;
     }
+    if (y16) {
+        *xc = 0;
+        return conv(c, a16, 1, H, W, cout, w.c2, cout, 3, 1, 1, H, W, sk, nullptr, y16);
+    }
     return conv_stats(c, a16, H, W, cout, w.c2, cout, sk, y, nullptr, c.partB, xc);
+}
+
+bool downsample_bf16() {
+    static const bool on = [] { const char* e = getenv("ADAP_VAE_DOWNSAMPLE_BF16"); return !(e && atoi(e) == 0); }();   // A/B switch
+    return on;
 }
 
 struct Plan {                       // what the configuration implies
@@ -230,15 +240,20 @@ int run(const Plan& p, Cursor cur, Arena& ar, const float* x_hwc, const uint8_t*
     int hh = H, ww = W, cin = p.ch;
     for (int l = 0; l < p.levels; ++l) {
         int cout = p.ch * p.mult[l];
+        // a level's last block feeds the Downsample alone: handed over as that contraction's bf16 operand (the same rounding the
+        // contraction applies to an f32 input in registers; half the bytes written there and read here), in the f32 buffer's memory
+        const bool to_down = l != p.levels - 1 && downsample_bf16();
         for (int r = 0; r < p.nres; ++r) {
             ResW w = res_w(cur, cin, cout);
-            if ((rc = resblock(c, w, h, hh, ww, cin, cout, a16, h16, hS, other, &xc))) return rc;
+            const bool hand16 = to_down && r == p.nres - 1;
+            if ((rc = resblock(c, w, h, hh, ww, cin, cout, a16, h16, hS, other, &xc, hand16 ? (void*)other : nullptr))) return rc;
             float* t = h; h = other; other = t;
             cin = cout;
         }
         if (l != p.levels - 1) {       // Downsample: F.pad(0,1,0,1) + conv3x3 stride 2 pad 0 (model.py:151-178)
             ConvW dw = conv_w(cur);
-            if ((rc = conv_stats_any(c, h, 0, hh, ww, cin, dw, cin, 2, 0, hh / 2, ww / 2, nullptr, other, nullptr, c.partB, &xc)))
+            if ((rc = conv_stats_any(c, h, to_down ? 1 : 0, hh, ww, cin, dw, cin, 2, 0, hh / 2, ww / 2, nullptr, other, nullptr, c.partB,
+                                     &xc)))
                 return rc;
             float* t = h; h = other; other = t;
             hh /= 2; ww /= 2;

@@ -33,6 +33,9 @@ class Downsample(nn.Module):
         self._wc = HF.WeightCache()
 
     def forward(self, x):
+        """x f32 or -- from the level's last ResnetBlock (``out_bf16_only``) -- bf16: the contraction's operand is bf16 either way
+        (an f32 input is converted in registers with the same rounding), so the bf16 hand-over is the same arithmetic with half
+        the bytes written by the producer and read here (537 MB -> 268 MB each way at 512 x 512, bs 4)."""
         B, H, W, C = x.shape
         pk = self._wc.get("conv", self.conv.weight, self.conv.bias)
         # (its output is the next level's first GroupNorm input: statistics from the epilogue when it is large, as in ResnetBlock)
@@ -41,6 +44,7 @@ class Downsample(nn.Module):
         return y
 
 
+DOWNSAMPLE_BF16 = __import__("os").environ.get("ADAP_VAE_DOWNSAMPLE_BF16", "1") != "0"       # A/B switch (csrc/vae.hip reads the same)
 _GN_EPI_MIN_LOG2 = int(__import__("os").environ.get("ADAP_GN_EPILOGUE_MIN_LOG2", "23"))      # (tuning; csrc/vae.hip reads the same)
 
 
@@ -68,7 +72,9 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
         self._wc = HF.WeightCache()
 
-    def forward(self, x, temb=None):
+    def forward(self, x, temb=None, out_bf16_only=False):
+        """``out_bf16_only``: the block's output is read by a Downsample's contraction alone (the encoder's last block of a
+        level): it is written as the bf16 operand that contraction would make of it anyway, and not as f32."""
         assert temb is None
         wc = self._wc
         c1 = wc.get("conv1", self.conv1.weight, self.conv1.bias)
@@ -84,6 +90,9 @@ class ResnetBlock(nn.Module):
             skip, _ = ops.conv2d(x, sk.fwd, sk.O4, 1, bias=sk.bias)
         else:
             skip = x
+        if out_bf16_only:
+            _, y = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip, out_f32=False, out_bf16=True)
+            return y
         y, _ = ops.conv2d(a2, c2.fwd, c2.O4, 3, 1, 1, bias=c2.bias, residual=skip, gn_stats=big)
         return y
 
@@ -188,9 +197,12 @@ class Encoder(nn.Module):
             x16 = ops.pad_cast_bf16(xf, cin.I8)
             h, _ = ops.conv2d(x16, cin.fwd, cin.O4, 3, 1, 1, bias=cin.bias, gn_stats=gn_stats_from_epilogue(*x16.shape[:3], cin.O4))
         for i_level in range(self.num_resolutions):
-            for blk in self.down[i_level].block:
-                h = blk(h)
-            if i_level != self.num_resolutions - 1:
+            last = i_level == self.num_resolutions - 1
+            blocks = list(self.down[i_level].block)
+            for j, blk in enumerate(blocks):
+                # (a level's last block feeds the Downsample alone: handed over as that contraction's bf16 operand)
+                h = blk(h, out_bf16_only=DOWNSAMPLE_BF16 and not last and j == len(blocks) - 1)
+            if not last:
                 h = self.down[i_level].downsample(h)
         h = self.mid.block_1(h)
         h = self.mid.attn_1(h, mask)

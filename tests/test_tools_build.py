@@ -19,3 +19,13 @@ def test_microbenchmark_compiles_for_gfx950(src, tmp_path):
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert os.path.getsize(tmp_path / "a.out") > 0
+
+
+PY_TOOLS = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")))
+
+
+@pytest.mark.parametrize("src", PY_TOOLS, ids=[os.path.basename(s) for s in PY_TOOLS])
+def test_tool_script_compiles(src):
+    """the measurement / probe scripts under tools/ (run by hand on the GPU box) must at least stay valid Python."""
+    import py_compile
+    py_compile.compile(src, doraise=True)
