@@ -105,30 +105,68 @@ __device__ __forceinline__ void unpack_bf16x4(uint2 v, float* f) {
     f[2] = __builtin_bit_cast(float, v.y << 16); f[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
 }
 
+// Widened bf16 epilogue stores.  A lane's quad of an accumulator tile is 4 channels of one pixel = 8 bytes as bf16, and the four
+// lanes that hold a pixel's 16 channels of the tile (lanes l, l + 16, l + 32, l + 48) write 32 contiguous bytes: a wave's store
+// instruction covers 16 rows x 32 bytes, and the epilogues of the bf16-output contractions were bound by the NUMBER of such
+// instructions, not by bytes (tools/ff_probe.py: FF1's main loop 33 us of an 81 us launch; guide T21).  Two channel-adjacent
+// tiles A (tile i) and B (tile i + 1) are regrouped with v_permlane16_swap (odd 16-lane rows of A <-> even rows of B): afterwards
+// lane rows 0 / 2 hold quads (0,1) / (2,3) of tile i and rows 1 / 3 those of tile i + 1 -- 16 contiguous bytes per lane, ONE
+// dwordx4 store where there were two dwordx2, 16 rows x 64 bytes per instruction.  Same values, same addresses.
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// the regrouped pair as this lane's 16 bytes; ``c_off``: its channel offset from tile i's first channel (elements)
+__device__ __forceinline__ uint4 pair16(uint2 a, uint2 b, int fchunk, int& c_off) {
+    swap16(a.x, b.x);
+    swap16(a.y, b.y);
+    c_off = (fchunk & 1) * 16 + (fchunk >> 1) * 8;
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+// the inverse for loads: 16 bytes at ``c_off`` -> this lane's quad of tile i (a) and of tile i + 1 (b)
+__device__ __forceinline__ void unpair16(uint4 v, uint2& a, uint2& b) {
+    uint2 lo = make_uint2(v.x, v.y), hi = make_uint2(v.z, v.w);
+    swap16(lo.x, hi.x);
+    swap16(lo.y, hi.y);
+    a = lo;
+    b = hi;
+}
+
 // epi 1: accumulator tiles (i, i + 1) of a wave are a block of 16 value channels and the block of their gates
 template <int MT, int PT, class Geo>
 __device__ __forceinline__ void conv_epilogue_geglu_fwd(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo) {
     if constexpr (MT % 2 == 0) {
+        // (value block | gate block) of a pair are 64 contiguous bytes of h, the outputs of two pairs 64 contiguous bytes of z:
+        // regrouped into 16-byte stores (pair16) when the rows are 16-byte aligned
+        const bool wide = (p.ldy16 & 7) == 0 && ((uintptr_t)p.y16 & 15) == 0 && (p.ldz16 & 7) == 0 && ((uintptr_t)p.z16 & 15) == 0 &&
+                          (geo.cbase & 31) == 0 && !(p.dbg & 8);
 #pragma unroll
-        for (int i = 0; i < MT; i += 2) {
-            const unsigned ca = (unsigned)geo.chan(i), cg = (unsigned)geo.chan(i + 1);
-            if ((int)cg >= p.Cout) continue;
-            float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-            if (p.bias) {
-                ba = *(const float4*)(p.bias + ca);
-                bg = *(const float4*)(p.bias + cg);
-            }
-            const unsigned cz = (ca >> 5) * 16u + (ca & 15u);              // the value channels' position in the 4C output
+        for (int j = 0; j < PT; ++j) {
+            int m, b;
+            const bool mok = geo.pixel(j, m, b);
+            uint2 zz[MT / 2 + 1];
 #pragma unroll
-            for (int j = 0; j < PT; ++j) {
-                int m, b;
-                if (!geo.pixel(j, m, b)) continue;
+            for (int i = 0; i < MT; i += 2) {
+                const unsigned ca = (unsigned)geo.chan(i), cg = (unsigned)geo.chan(i + 1);
+                const bool cok = (int)cg < p.Cout;                                  // (the same for all lanes of the wave: Cout % 32 == 0)
+                float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+                if (p.bias && cok) {
+                    ba = *(const float4*)(p.bias + ca);
+                    bg = *(const float4*)(p.bias + cg);
+                }
                 const uint2 ha = make_uint2(pack_bf16x2(acc[i][j][0] * p.alpha + ba.x, acc[i][j][1] * p.alpha + ba.y),
                                             pack_bf16x2(acc[i][j][2] * p.alpha + ba.z, acc[i][j][3] * p.alpha + ba.w));
                 const uint2 hg = make_uint2(pack_bf16x2(acc[i + 1][j][0] * p.alpha + bg.x, acc[i + 1][j][1] * p.alpha + bg.y),
                                             pack_bf16x2(acc[i + 1][j][2] * p.alpha + bg.z, acc[i + 1][j][3] * p.alpha + bg.w));
-                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ca) = ha;
-                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + cg) = hg;
+                if (wide && cok) {
+                    int c_off;
+                    const uint4 w = pair16(ha, hg, geo.fchunk, c_off);
+                    if (mok) *(uint4*)(p.y16 + (size_t)m * p.ldy16 + (unsigned)(geo.cbase + i * 16 + c_off)) = w;
+                } else if (mok && cok) {
+                    *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ca) = ha;
+                    *(uint2*)(p.y16 + (size_t)m * p.ldy16 + cg) = hg;
+                }
                 float a[4], g[4], o[4];
                 unpack_bf16x4(ha, a);                  // (from the rounded values: what the backward will read)
                 unpack_bf16x4(hg, g);
@@ -138,7 +176,25 @@ __device__ __forceinline__ void conv_epilogue_geglu_fwd(const ConvParams& p, con
                     conv_gelu_cdf_pdf(g[e], cdf, pdf);
                     o[e] = a[e] * (g[e] * cdf);
                 }
-                *(uint2*)(p.z16 + (size_t)m * p.ldz16 + cz) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                zz[i / 2] = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            }
+            // z: pair q = (tiles 2q, 2q + 1) writes 16 channels at (cbase / 2 + 16 q); two pairs regroup like two tiles
+#pragma unroll
+            for (int q = 0; q < MT / 2; q += 2) {
+                const unsigned cz0 = (unsigned)(geo.cbase >> 1) + 16u * q;           // first z channel of pair q (this wave)
+                if (q + 1 < MT / 2 && wide && geo.cbase + (2 * q + 4) * 16 <= p.Cout) {
+                    int c_off;
+                    const uint4 w = pair16(zz[q], zz[q + 1], geo.fchunk, c_off);
+                    if (mok) *(uint4*)(p.z16 + (size_t)m * p.ldz16 + cz0 + (unsigned)c_off) = w;
+                } else {
+                    const unsigned ca0 = (unsigned)geo.chan(2 * q), ca1 = (unsigned)geo.chan(2 * q + 2);
+                    if (mok && (int)ca0 + 16 < p.Cout)
+                        *(uint2*)(p.z16 + (size_t)m * p.ldz16 + (ca0 >> 5) * 16u + (ca0 & 15u)) = zz[q];
+                    if (q + 1 < MT / 2) {
+                        if (mok && (int)ca1 + 16 < p.Cout)
+                            *(uint2*)(p.z16 + (size_t)m * p.ldz16 + (ca1 >> 5) * 16u + (ca1 & 15u)) = zz[q + 1];
+                    }
+                }
             }
         }
     }
@@ -147,18 +203,33 @@ __device__ __forceinline__ void conv_epilogue_geglu_fwd(const ConvParams& p, con
 // epi 2: acc = d out of the 4C activations; dh = [d out * gelu(gate) | d out * a * gelu'(gate)] in the permuted 8C layout
 template <int MT, int PT, class Geo>
 __device__ __forceinline__ void conv_epilogue_geglu_bwd(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo) {
+    // a tile's (value | gate) blocks are 64 contiguous bytes of h and of dh: 16-byte loads / stores regrouped over the four lanes
+    // of a pixel (unpair16 / pair16) when the rows are 16-byte aligned
+    const bool wide = (p.ldh16 & 7) == 0 && ((uintptr_t)p.h16 & 15) == 0 && (p.ldy16 & 7) == 0 && ((uintptr_t)p.y16 & 15) == 0 &&
+                      (geo.cbase & 15) == 0 && !(p.dbg & 8);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const unsigned c = (unsigned)geo.chan(i);
-        if ((int)c >= p.Cout) continue;
+        const bool cok = (int)c < p.Cout;                                  // (tiles of 16 inside Cout % 16 == 0: wave-uniform)
         const unsigned ch = (c >> 4) * 32u + (c & 15u);                    // the value quad's position in h; its gates: + 16
+        const unsigned cht = (unsigned)((geo.cbase + i * 16) >> 4) * 32u;  // ... and the tile's (value | gate) block
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             int m, b;
-            if (!geo.pixel(j, m, b)) continue;
+            const bool mok = geo.pixel(j, m, b);
+            uint2 ua = make_uint2(0u, 0u), ug = ua;
+            if (wide && cok) {
+                const int c_off = (geo.fchunk & 1) * 16 + (geo.fchunk >> 1) * 8;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (mok) v = *(const uint4*)(p.h16 + (size_t)m * p.ldh16 + cht + (unsigned)c_off);
+                unpair16(v, ua, ug);
+            } else if (mok && cok) {
+                ua = *(const uint2*)(p.h16 + (size_t)m * p.ldh16 + ch);
+                ug = *(const uint2*)(p.h16 + (size_t)m * p.ldh16 + ch + 16);
+            }
             float a[4], g[4], da[4], dg[4];
-            unpack_bf16x4(*(const uint2*)(p.h16 + (size_t)m * p.ldh16 + ch), a);
-            unpack_bf16x4(*(const uint2*)(p.h16 + (size_t)m * p.ldh16 + ch + 16), g);
+            unpack_bf16x4(ua, a);
+            unpack_bf16x4(ug, g);
             // (the separate kernel read d out as bf16: round it the same way)
             float d[4];
             unpack_bf16x4(make_uint2(pack_bf16x2(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha),
@@ -170,8 +241,16 @@ __device__ __forceinline__ void conv_epilogue_geglu_bwd(const ConvParams& p, con
                 da[e] = d[e] * g[e] * cdf;
                 dg[e] = d[e] * a[e] * (cdf + g[e] * pdf);
             }
-            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ch) = make_uint2(pack_bf16x2(da[0], da[1]), pack_bf16x2(da[2], da[3]));
-            *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ch + 16) = make_uint2(pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3]));
+            const uint2 oa = make_uint2(pack_bf16x2(da[0], da[1]), pack_bf16x2(da[2], da[3]));
+            const uint2 og = make_uint2(pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3]));
+            if (wide && cok) {
+                int c_off;
+                const uint4 w = pair16(oa, og, geo.fchunk, c_off);
+                if (mok) *(uint4*)(p.y16 + (size_t)m * p.ldy16 + cht + (unsigned)c_off) = w;
+            } else if (mok && cok) {
+                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ch) = oa;
+                *(uint2*)(p.y16 + (size_t)m * p.ldy16 + ch + 16) = og;
+            }
         }
     }
 }
@@ -195,6 +274,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (
     }
     const bool has_res = p.residual != nullptr, has_ca = p.chan_add != nullptr;
     const unsigned ldr = (unsigned)p.ldr, ldca = (unsigned)p.ld_ca, ld32 = (unsigned)p.ldy32, ld16 = (unsigned)p.ldy16;
+    const bool wide16 = y16 && (p.ldy16 & 7) == 0 && ((uintptr_t)y16 & 15) == 0 && (geo.cbase & 7) == 0 && !(p.dbg & 8);   // (wave-uniform)
 #pragma unroll
     for (int j0 = 0; j0 < PT; j0 += JB) {
         unsigned mm[JB], bb[JB];
@@ -229,9 +309,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (
                     }
         }
 #pragma unroll
-        for (int j = 0; j < JB; ++j)
+        for (int j = 0; j < JB; ++j) {
+            uint2 o16[MT + 1];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
+                o16[i] = make_uint2(0u, 0u);
                 if (!(mok[j] && cok[i])) continue;
                 const f32x4 a = acc[i][j0 + j];
                 const float v0 = a[0] * p.alpha + bq[i].x + rq[i][j].x, v1 = a[1] * p.alpha + bq[i].y + rq[i][j].y;
@@ -247,12 +329,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const f32x4 (
                 }
                 if (y32) *(float4*)((char*)y32 + (mm[j] * ld32 + cc[i]) * 4u) = make_float4(v0, v1, v2, v3);
                 if (y16) {
-                    uint2 o;
-                    o.x = pack_bf16x2(v0, v1);
-                    o.y = pack_bf16x2(v2, v3);
-                    *(uint2*)((char*)y16 + (mm[j] * ld16 + cc[i]) * 2u) = o;
+                    o16[i].x = pack_bf16x2(v0, v1);
+                    o16[i].y = pack_bf16x2(v2, v3);
                 }
             }
+            if (y16) {
+                // pairs of channel-adjacent tiles that lie wholly inside Cout go out as one 16-byte store per lane (pair16);
+                // (all lanes take part in the regrouping: the predicate is on the store)
+#pragma unroll
+                for (int i = 0; i < MT; i += 2) {
+                    if (i + 1 < MT && wide16 && geo.cbase + (i + 2) * 16 <= p.Cout) {
+                        int c_off;
+                        const uint4 w = pair16(o16[i], o16[i + 1], geo.fchunk, c_off);
+                        if (mok[j]) *(uint4*)((char*)y16 + (mm[j] * ld16 + (unsigned)(geo.cbase + i * 16 + c_off)) * 2u) = w;
+                    } else {
+                        if (mok[j] && cok[i]) *(uint2*)((char*)y16 + (mm[j] * ld16 + cc[i]) * 2u) = o16[i];
+                        if (i + 1 < MT) {
+                            if (mok[j] && cok[i + 1]) *(uint2*)((char*)y16 + (mm[j] * ld16 + cc[i + 1]) * 2u) = o16[i + 1];
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
