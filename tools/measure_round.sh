@@ -14,7 +14,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-distill-mix --no-ddim --no-unfrozen --no-compos --no-zs-frontend"   # the profiled legs: the main step only
+COMMON="--no-cpu-baseline --no-distill-mix --no-ddim --no-unfrozen --no-compos --no-zs-frontend --no-rehearse-exchange --no-entry-leg"   # the profiled legs: the main step only
 echo "[measure] stats pass"; date
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_stats" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-clock-probe --no-aggregates $COMMON > "$OUT/${TAG}_stats.log" 2>&1
 echo "[measure] stats pass, one stream (--no-lanes: the kernels without the other lane's contention, as bench.py's HIP-event roofline times them)"; date
