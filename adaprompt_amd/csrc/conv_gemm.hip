@@ -205,8 +205,10 @@ template <int MT, int PT, class Geo>
 __device__ __forceinline__ void conv_epilogue_geglu_bwd(const ConvParams& p, const f32x4 (&acc)[MT][PT], const Geo& geo) {
     // a tile's (value | gate) blocks are 64 contiguous bytes of h and of dh: 16-byte loads / stores regrouped over the four lanes
     // of a pixel (unpair16 / pair16) when the rows are 16-byte aligned
-    const bool wide = (p.ldh16 & 7) == 0 && ((uintptr_t)p.h16 & 15) == 0 && (p.ldy16 & 7) == 0 && ((uintptr_t)p.y16 & 15) == 0 &&
-                      (geo.cbase & 15) == 0 && !(p.dbg & 8);
+    // (opt-in, ADAP_CONV_DEBUG bit 4: here the regrouped form measured 3-4 % SLOWER -- 58.1 vs 55.7 us at 64 x 64 -- the loads'
+    // regrouping sits between the load and the GELU' arithmetic that hides its latency in the narrow form)
+    const bool wide = (p.dbg & 16) && (p.ldh16 & 7) == 0 && ((uintptr_t)p.h16 & 15) == 0 && (p.ldy16 & 7) == 0 &&
+                      ((uintptr_t)p.y16 & 15) == 0 && (geo.cbase & 15) == 0;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const unsigned c = (unsigned)geo.chan(i);
