@@ -819,15 +819,19 @@ ROLLOUT_EPS_TOL = EPS_TOL  # teacher eps / x0 at every rollout step (measured 1e
 DISTILL_LOSS_TOL = LOSS_TOL  # sum over steps of masked MSE(student eps, teacher eps): the north-star bar (measured 2.6e-4)
 
 
-def test_arc2face_distill_step_vs_oracle():
-    """a9/a17: three-step teacher rollout (narrow SD-topology UNet with its own weights, [B,21,ctx] context repeated
+@pytest.mark.parametrize("size", ["narrow", "sd15"])
+def test_arc2face_distill_step_vs_oracle(size):
+    """a9/a17: three-step teacher rollout (SD-topology UNet with its own weights, [B,21,ctx] context repeated
     over the layers) + student passes on the teacher's predictions + loss / sqrt(3) + gradient into the student's
     context, against oracle/distill_oracle.py with the fp32 UNet restatement in both roles; rand / randn draws
-    supplied.  The timesteps the rollout visits are integer work and must be identical."""
+    supplied.  The timesteps the rollout visits are integer work and must be identical.  ``narrow``: HALF_BS = 2, the batched and
+    the one-by-one student; ``sd15`` (round 5: config 2's iteration at FULL size, 859.5 M-parameter student and teacher): HALF_BS = 1
+    of a batch of 2, the batched student (three passes as one)."""
     from adaprompt_amd.ldm.models.diffusion.ddpm import LatentDiffusion, Arc2FaceWrapper
     from oracle import ldm_oracle as O
     from oracle import distill_oracle as D
-    ucfg = dict(NARROW)
+    full = size == "sd15"
+    ucfg = dict(synth.SD15_UNET) if full else dict(NARROW)
     vdd = dict(synth.SD15_VAE_DD, ch=32, resolution=64)
     ld = LatentDiffusion.hot_path({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": vdd, "embed_dim": 4}},
                          {"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel", "params": ucfg})
@@ -843,11 +847,11 @@ def test_arc2face_distill_step_vs_oracle():
     ld.set_arc2face_teacher(teacher.to(dev()).eval())
     assert not any(k.startswith("arc2face") for k in ld.state_dict())
 
-    B, nd = 2, 3
+    B, nd = (1 if full else 2), 3
     x0 = synth.synthetic_input("distill.x0", (B, 4, 64, 64))
     noises = [synth.synthetic_input(f"distill.noise{i}", (B, 4, 64, 64)) for i in range(nd)]
     rel = [synth.synthetic_input(f"distill.rel{i}", (B,)).sigmoid() for i in range(nd - 1)]     # in (0, 1)
-    t = torch.tensor([420, 640])
+    t = torch.tensor([420, 640])[:B]
     tctx = synth.synthetic_input("distill.tctx", (B, 21, ucfg["context_dim"]))
     ctx = synth.synthetic_input("distill.ctx", (16 * B, 77, ucfg["context_dim"]))
     fg64, im64 = ellipse_mask(B, 64, 64), border_mask(B, 64, 64, 5)
@@ -885,16 +889,18 @@ def test_arc2face_distill_step_vs_oracle():
     # for bit: the contraction kernels pick tile sizes and split-K plans from M = batch x pixels, so the summation
     # order of the bf16-product accumulations differs between a batch of 6 and three batches of 2 (measured: loss
     # 3.7e-5 apart).  Each is separately held to the oracle below; against each other they get a fraction of that bar.
-    ctx_seq = ctx.to(dev()).clone().requires_grad_(True)
-    loss_s, grads_s, outs_s, aux_s = ld.shared_step(batch, cond=(ctx_seq, None, extra), batched_student=False, **kw)
-    assert len(outs_s) == nd
-    torch.autograd.backward(outs_s, grads_s)
-    assert abs(float(loss) - float(loss_s)) / float(loss_s) < LOSS_TOL / 5
-    assert rel_err(ctx_hip.grad, ctx_seq.grad) < 5e-3
-    for a, b in zip(aux["model_outputs_per_step"], outs_s):
-        assert rel_err(a.detach(), b.detach()) < 8e-3                 # (measured 4.6e-3 ... 5.1e-3: the batch of 6 and the batches of
-        #                                                                 2 get different tile / split-K plans and attention kernels)
-    lr_seq = float(loss_s)
+    lr_seq = None
+    if not full:
+        ctx_seq = ctx.to(dev()).clone().requires_grad_(True)
+        loss_s, grads_s, outs_s, aux_s = ld.shared_step(batch, cond=(ctx_seq, None, extra), batched_student=False, **kw)
+        assert len(outs_s) == nd
+        torch.autograd.backward(outs_s, grads_s)
+        assert abs(float(loss) - float(loss_s)) / float(loss_s) < LOSS_TOL / 5
+        assert rel_err(ctx_hip.grad, ctx_seq.grad) < 5e-3
+        for a, b in zip(aux["model_outputs_per_step"], outs_s):
+            assert rel_err(a.detach(), b.detach()) < 8e-3             # (measured 4.6e-3 ... 5.1e-3: the batch of 6 and the batches of
+            #                                                             2 get different tile / split-K plans and attention kernels)
+        lr_seq = float(loss_s)
     outs = aux["model_outputs_per_step"]
     npred, px0, nz, ts = aux["teacher"]
     assert aux["loss_start_step"] == start == 0 and len(outs) == nd
@@ -909,12 +915,13 @@ def test_arc2face_distill_step_vs_oracle():
     for a, b in zip(outs, outs_ref):
         assert rel_err(a.detach().cpu(), b.detach()) < ROLLOUT_EPS_TOL
     lr_ = float(loss_ref)
-    print(f"[distill] teacher (eps, x0) rel err per step {[(round(a, 4), round(b, 4)) for a, b in errs]}  "
+    print(f"[distill {size}] teacher (eps, x0) rel err per step {[(round(a, 4), round(b, 4)) for a, b in errs]}  "
           f"loss hip {float(loss):.6f} ref {lr_:.6f} rel {abs(float(loss) - lr_) / lr_:.2e}  "
           f"grad rel {rel_err(ctx_hip.grad.cpu(), g_ref):.3e}")
     assert abs(float(loss) - lr_) / lr_ < DISTILL_LOSS_TOL
-    assert abs(lr_seq - lr_) / lr_ < DISTILL_LOSS_TOL              # the one-by-one path against the oracle too
-    assert rel_err(ctx_hip.grad.cpu(), g_ref) < 1.5e-2                    # measured 6.2e-3
+    if lr_seq is not None:
+        assert abs(lr_seq - lr_) / lr_ < DISTILL_LOSS_TOL          # the one-by-one path against the oracle too
+    assert rel_err(ctx_hip.grad.cpu(), g_ref) < (GRAD_CTX_TOL if full else 1.5e-2)      # measured 6.2e-3 narrow
 
 
 def test_guided_denoise_cfg_pixel_recon_vs_oracle():
