@@ -61,9 +61,10 @@ def _op16(t):
 # ADAP_PRESCALE_Q=1: the self-attention query projection's weight pack carries d^-1/2 * log2(e) (folded in before the pack's one
 # bf16 rounding), so the attention kernels get their scores in the exp2 domain straight from the matrix core
 # (adap_attention_fwd / _bwd with scale = 0): one VALU instruction per score less.  Parity-green (tests/test_kernels_gpu.py,
-# the model tests) and OFF by default: three interleaved A/B pairs of the training step measured 124.27 vs 124.40 img/s -- the
-# softmax phase is bound by its dependency chain (MFMA -> exp -> convert -> MFMA with two waves per SIMD), not by issue slots.
-PRESCALE_Q = os.environ.get("ADAP_PRESCALE_Q", "0") == "1"
+# the model tests: the same error figures as the unscaled form).  Round 3 measured nothing for it on one stream (124.27 vs
+# 124.40 img/s); round 5, on two lanes with the attention workgroups' XCD map: 24.09 vs 24.27 ms per micro-batch in both of two
+# interleaved pairs (profiles/r05_ab_misc.log) -- ON by default since; ADAP_PRESCALE_Q=0 switches it off.
+PRESCALE_Q = os.environ.get("ADAP_PRESCALE_Q", "1") == "1"
 LOG2E = 1.4426950408889634
 
 
