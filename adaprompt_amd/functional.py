@@ -637,10 +637,13 @@ class ContextKVFn(torch.autograd.Function):
             ops._lib.call("adap_conv2d_nhwc", c16[l0].data_ptr(), 1, Cctx, wf.data_ptr(), 0, 0, 0, 0, 0, 0, 0, kv.data_ptr(), 2 * C,
                           1, rows, 1, Cctx, rows, 1, 2 * C, 1, 1, 1, 0, 0, 1.0, 1, 0, n, rows * Cctx, 2 * C * Cctx, 0, rows * 2 * C,
                           ops._stream())
-            dkv = torch.empty(n, B, M, 2 * C, device=ctx_l.device, dtype=BF16)
             outs += list(kv.unbind(0))
-            slots += list(dkv.unbind(0))
-            dbufs.append(dkv)
+            if ctx.needs_input_grad[0]:            # (a no-grad pass -- the teacher's, a sampler's -- has no gradient slots)
+                dkv = torch.empty(n, B, M, 2 * C, device=ctx_l.device, dtype=BF16)
+                slots += list(dkv.unbind(0))
+                dbufs.append(dkv)
+            else:
+                slots += [None] * n
         ctx.runs, ctx.dbufs, ctx.slots, ctx.shape = runs, dbufs, slots, (L, B, M, Cctx)
         ctx.set_materialize_grads(False)
         ContextKVFn.LAST_SLOTS = slots
