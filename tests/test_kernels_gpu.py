@@ -1146,3 +1146,40 @@ def test_feed_forward_with_the_geglu_inside_its_contractions(rows, C):
     a, gate = hh.chunk(2, dim=-1)
     ref = a * torch.nn.functional.gelu(gate)
     assert rel(gg_f.float(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("rows,K,C,expect_fused", [(1024, 3840, 1280, True),       # 16 x 16 level, to_q|k|v data gradient: split K
+                                                   (512, 5120, 640, True),         # a feed-forward data gradient at 32 x 32 rows / 8
+                                                   (16384, 320, 320, False)])      # short K: never split -- the request is declined
+def test_layernorm_backward_inside_the_splitk_reduce(rows, K, C, expect_fused):
+    """``adap_conv2d_next_ln_bwd`` (round 5): the LayerNorm backward (attention.py:267-269) that consumes a data-gradient contraction's
+    output, folded into that contraction's split-K reduce pass -- against the contraction followed by ``adap_layernorm_bwd``: the
+    accumulated dx (f32) and its bf16 copy bit for bit; where the contraction does not go out split the request is declined
+    (``adap_conv2d_last_ln_bwd`` = 0) and the outputs are written as usual."""
+    from adaprompt_amd import _lib
+    g16 = rnd(rows, K, seed=1, scale=0.3).to(torch.bfloat16)
+    pk = ops.PackedConv(rnd(C, K, seed=2, scale=K ** -0.5))
+    x = rnd(rows, C, seed=3)
+    gamma = rnd(C, seed=4) * 0.2 + 1.0
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros_like(gamma))
+    base = rnd(rows, C, seed=5)
+    # reference: contraction, then the LayerNorm backward accumulating into a copy of the running gradient
+    dy, _ = ops.linear(g16, pk.fwd, C, out_f32=True)
+    want32 = base.clone()
+    _, want16 = ops.layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=want32, want_bf16=True)
+    # fused: arm the request, run the same contraction
+    got32 = base.clone()
+    got16 = torch.zeros(rows, C, device=dev(), dtype=torch.bfloat16)
+    _lib.call("adap_conv2d_next_ln_bwd", x.data_ptr(), C, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), got32.data_ptr(), C, 1,
+              got16.data_ptr(), C)
+    dy2, _ = ops.linear(g16, pk.fwd, C, out_f32=True)
+    fused = _lib.call_long("adap_conv2d_last_ln_bwd")
+    torch.cuda.synchronize()
+    assert bool(fused) == expect_fused
+    if fused:
+        assert torch.equal(got32, want32) and torch.equal(got16, want16)
+    else:
+        assert torch.equal(dy2, dy) and torch.equal(got32, base)             # declined: nothing of the request was touched
+    # the request is one-shot: the next contraction is an ordinary one
+    dy3, _ = ops.linear(g16, pk.fwd, C, out_f32=True)
+    assert _lib.call_long("adap_conv2d_last_ln_bwd") == 0 and torch.equal(dy3, dy)
