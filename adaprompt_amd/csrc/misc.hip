@@ -941,3 +941,123 @@ extern "C" int adap_mask_hinges_bwd(const float* S, const float* G, long estride
                        dstride);
     return adap_check_launch("mask_hinges_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Key masks of the UNet's levels in ONE launch (attention.py:223-232, :332: the image mask [B,1,h,w], nearest-resized to the
+// level, != 0) and, for the levels whose self-attention runs on the kept keys alone, the stable partition behind it: perm
+// lists a sample's kept keys first (in order), then the masked ones; inv undoes it; count = kept keys (N when none is kept:
+// that sample attends to every key, functional.KeyCompaction).  One workgroup per (level, sample); the partition walks the
+// row in chunks of 256 with a ballot prefix, so the order inside a class is the key order (= torch.argsort(stable=True)).
+// The nearest source index is aten's: min(int(floorf(dst * (float)in / out)), in - 1).
+// ---------------------------------------------------------------------------------------------
+#define KEYMASK_MAX_LEVELS 8
+struct KeyMaskLevels {
+    const float* img;
+    uint8_t* u8;
+    int* i32;
+    int B, h, w, nlev;
+    int H[KEYMASK_MAX_LEVELS], W[KEYMASK_MAX_LEVELS];
+    long mask_off[KEYMASK_MAX_LEVELS], perm_off[KEYMASK_MAX_LEVELS], inv_off[KEYMASK_MAX_LEVELS], count_off[KEYMASK_MAX_LEVELS];
+};
+
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in) {
+    const int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+__global__ __launch_bounds__(256) void key_masks_kernel(KeyMaskLevels p) {
+    __shared__ int wave_kept[4];
+    __shared__ int red[4];
+    const int lev = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = p.H[lev], W = p.W[lev], N = H * W;
+    const float sh = (float)p.h / (float)H, sw = (float)p.w / (float)W;
+    const float* src = p.img + (long)b * p.h * p.w;
+    uint8_t* m = p.u8 + p.mask_off[lev] + (long)b * N;
+    int cnt = 0;
+    for (int i = tid; i < N; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const uint8_t v = src[(long)nearest_src(y, sh, p.h) * p.w + nearest_src(x, sw, p.w)] != 0.f;
+        m[i] = v;
+        cnt += v;
+    }
+    if (p.perm_off[lev] < 0) return;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) red[wv] = cnt;
+    __syncthreads();
+    const int kept = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) p.i32[p.count_off[lev] + b] = kept == 0 ? N : kept;
+    int* perm = p.i32 + p.perm_off[lev] + (long)b * N;
+    int* inv = p.i32 + p.inv_off[lev] + (long)b * N;
+    int base_k = 0, base_m = kept;
+    for (int c0 = 0; c0 < N; c0 += 256) {
+        const int i = c0 + tid;
+        const bool valid = i < N;
+        const bool v = valid && m[i] != 0;          // (this thread's own store above: i = tid mod 256 in both loops)
+        const unsigned long long bal = __ballot(v);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();                            // (the previous chunk's readers of wave_kept are done)
+        if (lane == 0) wave_kept[wv] = __popcll(bal);
+        __syncthreads();
+        int kept_before = before, chunk_kept = 0;
+        for (int q = 0; q < 4; ++q) {
+            if (q < wv) kept_before += wave_kept[q];
+            chunk_kept += wave_kept[q];
+        }
+        if (valid) {
+            const int pos = v ? base_k + kept_before : base_m + (tid - kept_before);
+            perm[pos] = i;
+            inv[i] = pos;
+        }
+        const int chunk_n = N - c0 < 256 ? N - c0 : 256;
+        base_k += chunk_kept;
+        base_m += chunk_n - chunk_kept;
+    }
+}
+
+// img f32 [B][h][w] (the mask's single channel); dims int [2 * nlev] = (H, W) per level; offs long [4 * nlev] = per level the
+// byte offset of its mask [B][H*W] in out_u8 and the int32 offsets of perm [B][H*W], inv [B][H*W], count [B] in out_i32
+// (perm offset < 0: the level gets its mask only).  dims / offs are host arrays.
+extern "C" int adap_key_masks(const float* img, int B, int h, int w, int nlev, const int* dims, const long* offs, void* out_u8,
+                              int* out_i32, void* stream) {
+    ADAP_REQUIRE(img && dims && offs && out_u8 && B > 0 && h > 0 && w > 0, ADAP_ERR_SHAPE, "key_masks: arguments");
+    ADAP_REQUIRE(nlev >= 1 && nlev <= KEYMASK_MAX_LEVELS, ADAP_ERR_UNSUPPORTED, "key_masks: %d levels (1 .. %d)", nlev, KEYMASK_MAX_LEVELS);
+    KeyMaskLevels p = {};
+    p.img = img; p.u8 = (uint8_t*)out_u8; p.i32 = out_i32; p.B = B; p.h = h; p.w = w; p.nlev = nlev;
+    for (int l = 0; l < nlev; ++l) {
+        p.H[l] = dims[2 * l]; p.W[l] = dims[2 * l + 1];
+        p.mask_off[l] = offs[4 * l]; p.perm_off[l] = offs[4 * l + 1]; p.inv_off[l] = offs[4 * l + 2]; p.count_off[l] = offs[4 * l + 3];
+        ADAP_REQUIRE(p.H[l] > 0 && p.W[l] > 0 && (long)p.H[l] * p.W[l] < (1L << 30) && p.mask_off[l] >= 0, ADAP_ERR_SHAPE,
+                     "key_masks: level %d is %d x %d", l, p.H[l], p.W[l]);
+        ADAP_REQUIRE(p.perm_off[l] < 0 || (out_i32 && p.inv_off[l] >= 0 && p.count_off[l] >= 0), ADAP_ERR_SHAPE,
+                     "key_masks: level %d wants its compaction but has no int32 output", l);
+    }
+    hipLaunchKernelGGL(key_masks_kernel, dim3(nlev, B), dim3(256), 0, (hipStream_t)stream, p);
+    return adap_check_launch("key_masks");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pixel classes of the VAE's masked mid-block attention (model.py:196-232): fg / aug masks [B,1,h,w] nearest-resized to H x W;
+// class 1 where fg * aug != 0, 2 where (1 - fg) * aug != 0, else 0 (aug NULL = all ones).  out u8 [B][H*W].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pixel_classes_kernel(const float* __restrict__ fg, const float* __restrict__ aug,
+                                                            uint8_t* __restrict__ out, int B, int h, int w, int ha, int wa,
+                                                            int H, int W) {
+    const long total = (long)B * H * W;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W, sha = (float)ha / (float)H, swa = (float)wa / (float)W;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += 256L * gridDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const long b = i / ((long)W * H);
+        const float f = fg[b * h * w + (long)nearest_src(y, sh, h) * w + nearest_src(x, sw, w)];
+        const float a = aug ? aug[b * ha * wa + (long)nearest_src(y, sha, ha) * wa + nearest_src(x, swa, wa)] : 1.f;
+        out[i] = (f * a != 0.f) ? 1 : (((1.f - f) * a != 0.f) ? 2 : 0);
+    }
+}
+
+extern "C" int adap_pixel_classes(const float* fg, int h, int w, const float* aug, int ha, int wa, void* out, int B, int H, int W,
+                                  void* stream) {
+    ADAP_REQUIRE(fg && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && (!aug || (ha > 0 && wa > 0)), ADAP_ERR_SHAPE,
+                 "pixel_classes: arguments");
+    hipLaunchKernelGGL(pixel_classes_kernel, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, fg, aug,
+                       (uint8_t*)out, B, h, w, ha, wa, H, W);
+    return adap_check_launch("pixel_classes");
+}

@@ -69,36 +69,72 @@ class BasicTransformerBlock(nn.Module):
 
 class KeyMasks:
     """img_mask [B,1,h,w] -> the self-attention key mask [B, H*W] uint8 of a level (attention.py:223-232, :332: nearest
-    resize, != 0), computed once per resolution and forward instead of once per transformer."""
+    resize, != 0) and, from ``functional.COMPACT_KEYS_MIN_N`` keys on, its compaction -- for all of ``sizes`` (the UNet's
+    levels) in ONE launch (``adap_key_masks``) instead of once per transformer; a size outside ``sizes`` gets its own launch
+    when it is first asked for."""
 
-    def __init__(self, img_mask):
-        self.img_mask = img_mask
+    def __init__(self, img_mask, sizes=()):
+        m = img_mask
+        if m.dim() != 4 or m.shape[1] != 1:
+            raise ValueError(f"img_mask must be [B,1,h,w], got {tuple(m.shape)}")
+        if m.device.type != "cuda":
+            raise RuntimeError("KeyMasks (MI355X): the mask must live on the GPU -- there is no CPU path")
+        self.img_mask = m.detach().float().contiguous()
         self._by_res = {}
+        if sizes:
+            self._build(list(dict.fromkeys((int(H), int(W)) for H, W in sizes)))
+
+    def _build(self, sizes):
+        import ctypes
+        m = self.img_mask
+        B, _, h, w = m.shape
+        n = len(sizes)
+        dims, offs = (ctypes.c_int * (2 * n))(), (ctypes.c_long * (4 * n))()
+        nb, ni, compact = 0, 0, []
+        for l, (H, W) in enumerate(sizes):
+            N = H * W
+            dims[2 * l], dims[2 * l + 1] = H, W
+            offs[4 * l] = nb
+            nb += (B * N + 15) // 16 * 16
+            compact.append(N >= HF.COMPACT_KEYS_MIN_N)
+            if compact[-1]:
+                offs[4 * l + 1], offs[4 * l + 2], offs[4 * l + 3] = ni, ni + B * N, ni + 2 * B * N
+                ni += 2 * B * N + (B + 3) // 4 * 4
+            else:
+                offs[4 * l + 1] = offs[4 * l + 2] = offs[4 * l + 3] = -1
+        u8 = torch.empty(nb, device=m.device, dtype=torch.uint8)
+        i32 = torch.empty(max(ni, 1), device=m.device, dtype=torch.int32)
+        ops._lib.call("adap_key_masks", m.data_ptr(), B, h, w, n, dims, offs, u8.data_ptr(), i32.data_ptr(), ops._stream())
+        for l, (H, W) in enumerate(sizes):
+            N = H * W
+            mask = self._by_res[(H, W)] = u8[offs[4 * l]:offs[4 * l] + B * N].view(B, N)
+            if compact[l]:
+                o = offs[4 * l + 1]
+                self._by_res[(H, W, "compaction")] = HF.KeyCompaction(
+                    mask, i32[o:o + B * N].view(B, N), i32[o + B * N:o + 2 * B * N].view(B, N), i32[o + 2 * B * N:o + 2 * B * N + B])
 
     def at(self, H, W):
         m = self._by_res.get((H, W))
         if m is None:
-            m2 = F.interpolate(self.img_mask.float(), size=(H, W), mode="nearest")
-            m = self._by_res[(H, W)] = (m2.reshape(m2.shape[0], H * W) != 0).to(torch.uint8).contiguous()
+            self._build([(H, W)])
+            m = self._by_res[(H, W)]
         return m
 
     def compaction(self, H, W):
         """(perm, inv_perm, count) of a level, all on the device (no host sync): ``perm`` [B,N] int32 lists a sample's kept
         keys first (in order), then the masked ones; ``inv_perm`` undoes it; ``count`` [B] int32 = kept keys.  A masked key's
         softmax weight is exactly 0 (attention.py:223-232 fills its score with -finfo.max), so self-attention over the first
-        ``count`` rows of the permuted K / V is the same arithmetic on fewer key tiles (functional.SpatialTransformerFn)."""
+        ``count`` rows of the permuted K / V is the same arithmetic on fewer key tiles (functional.SpatialTransformerFn).
+        (A sample whose mask keeps NO key -- an image with an empty aug mask, which the data pipeline does not produce --
+        would divide by an empty softmax sum: it attends to all keys instead, count = N; the reference's masked_fill gives
+        it the plain average of V.)"""
         c = self._by_res.get((H, W, "compaction"))
         if c is None:
-            m = self.at(H, W)
-            perm = torch.argsort(m, dim=1, descending=True, stable=True)
-            inv = torch.argsort(perm, dim=1)
-            count = m.sum(dim=1, dtype=torch.int32)
-            # (a sample whose mask keeps NO key -- an image with an empty aug mask, which the data pipeline does not produce --
-            # would divide by an empty softmax sum: it attends to all keys instead; the reference's masked_fill gives it the
-            # plain average of V)
-            count = torch.where(count == 0, torch.full_like(count, H * W), count).contiguous()
-            c = self._by_res[(H, W, "compaction")] = HF.KeyCompaction(m, perm.to(torch.int32).contiguous(),
-                                                                      inv.to(torch.int32).contiguous(), count)
+            if H * W < HF.COMPACT_KEYS_MIN_N:
+                raise ValueError(f"no compaction below {HF.COMPACT_KEYS_MIN_N} keys ({H} x {W})")
+            self._by_res.pop((H, W), None)
+            self._build([(H, W)])
+            c = self._by_res[(H, W, "compaction")]
         return c
 
 

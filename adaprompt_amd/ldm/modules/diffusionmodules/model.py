@@ -114,11 +114,16 @@ class AttnBlock(nn.Module):
         if mask is None or mask.get("fg_mask") is None:
             return None
         B = like.shape[0]
-        fg = F.interpolate(mask["fg_mask"].float(), size=hw, mode="nearest")
+        fg = mask["fg_mask"].detach().float().contiguous()
         aug = mask["aug_mask"]
-        aug = torch.ones_like(fg) if aug is None else F.interpolate(aug.float(), size=hw, mode="nearest")
-        cls = torch.where(fg * aug != 0, 1, torch.where((1 - fg) * aug != 0, 2, 0))
-        return cls.reshape(B, -1).to(torch.uint8).contiguous()
+        aug = None if aug is None else aug.detach().float().contiguous()
+        if fg.dim() != 4 or fg.shape[0] != B or fg.shape[1] != 1 or (aug is not None and aug.shape[:2] != fg.shape[:2]):
+            raise ValueError(f"fg_mask / aug_mask must be [B,1,H,W], got {tuple(fg.shape)}")
+        cls = torch.empty(B, hw[0] * hw[1], device=like.device, dtype=torch.uint8)
+        ops._lib.call("adap_pixel_classes", fg.data_ptr(), fg.shape[2], fg.shape[3], 0 if aug is None else aug.data_ptr(),
+                      0 if aug is None else aug.shape[2], 0 if aug is None else aug.shape[3], cls.data_ptr(), B, hw[0], hw[1],
+                      ops._stream())
+        return cls
 
     def forward(self, x, mask=None):
         B, H, W, C = x.shape

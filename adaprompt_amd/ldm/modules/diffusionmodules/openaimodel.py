@@ -408,7 +408,11 @@ class UNetModel(nn.Module):
                 hoisted = (kvs, HF.ContextKVFn.LAST_SLOTS)
         if img_mask is not None:
             from ..attention import KeyMasks
-            img_mask = KeyMasks(img_mask)
+            # the key masks (and compactions) of every level in one launch: a Downsample (3x3, stride 2, pad 1) halves upwards
+            lv = [(x.shape[2], x.shape[3])]
+            for _ in range(len(self.channel_mult) - 1):
+                lv.append(((lv[-1][0] + 1) // 2, (lv[-1][1] + 1) // 2))
+            img_mask = KeyMasks(img_mask, sizes=lv)
 
         def get_layer_context(layer_idx):
             if layer_idx not in LAYER2CA:

@@ -446,6 +446,20 @@ int adap_upsample2x_bf16(const float* in, long ldi, void* out, int B, int H, int
 /* batched bf16 transpose [R][C] -> [C][R] (V^T of the VAE mid attention, model.py:236-239). */
 int adap_transpose_bf16(const void* in, void* out, int batch, int R, int C, void* stream);
 
+/* The self-attention key masks of up to 8 UNet levels in one launch (reference: attention.py:223-232 and :332 -- img_mask
+ * [B,1,h,w] resized to each level with F.interpolate(mode="nearest") and compared != 0; there once per transformer).
+ * img f32 [B][h][w]; dims (host) int [2*nlev] = (H, W) per level; offs (host) long [4*nlev] = per level the byte offset of
+ * its mask u8 [B][H*W] in out_u8, then the int32 offsets in out_i32 of perm [B][H*W], inv_perm [B][H*W] and count [B] --
+ * the stable partition "kept keys first" that self-attention over the kept keys alone runs on (perm offset < 0: mask
+ * only).  count = kept keys, or H*W for a sample that keeps none (it attends to every key). */
+int adap_key_masks(const float* img, int B, int h, int w, int nlev, const int* dims, const long* offs, void* out_u8,
+                   int* out_i32, void* stream);
+
+/* Pixel classes of the VAE's masked mid-block attention (model.py:196-232): fg [B][h][w] and aug [B][ha][wa] (NULL = ones)
+ * nearest-resized to H x W; out u8 [B][H*W] = 1 where fg*aug != 0, 2 where (1-fg)*aug != 0, else 0. */
+int adap_pixel_classes(const float* fg, int h, int w, const float* aug, int ha, int wa, void* out, int B, int H, int W,
+                       void* stream);
+
 /* VAE mid AttnBlock softmax with the post-softmax hetero-pair zero fill, model.py:190-232.
  * pixel_class [batch][N] bytes: 0 outside aug mask, 1 fg, 2 bg; NULL = no masking. */
 int adap_vae_softmax(const float* S, long lds, void* P, long ldp, const uint8_t* pixel_class, long rows, int N,

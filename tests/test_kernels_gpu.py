@@ -1183,3 +1183,69 @@ def test_layernorm_backward_inside_the_splitk_reduce(rows, K, C, expect_fused):
     # the request is one-shot: the next contraction is an ordinary one
     dy3, _ = ops.linear(g16, pk.fwd, C, out_f32=True)
     assert _lib.call_long("adap_conv2d_last_ln_bwd") == 0 and torch.equal(dy3, dy)
+
+
+# ---------------------------------------------------------------------------------------------
+# key masks of the UNet's levels / pixel classes of the VAE's masked attention: one launch each, bit-exact against the
+# reference's torch expressions (attention.py:223-232, :332; model.py:196-232)
+# ---------------------------------------------------------------------------------------------
+def _mask_images(B, h, w, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    m = (torch.rand(B, 1, h, w, generator=g) > 0.35).float()
+    m[:, :, : h // 5] = 0                      # a border band, as the augmentation masks have
+    m[:, :, :, -(w // 7):] = 0
+    if B > 1:
+        m[1] = 0                               # a sample that keeps no key: count = N, perm = identity
+    if B > 2:
+        m[2] = 1                               # ... and one that keeps all of them
+    return m.to(dev())
+
+
+@pytest.mark.parametrize("B,h,w,sizes", [
+    (4, 512, 512, [(64, 64), (32, 32), (16, 16), (8, 8)]),      # the shipped levels (bs 4)
+    (3, 500, 380, [(63, 48), (32, 24), (16, 12), (8, 6)]),       # non-integer resize ratios, ragged last chunk
+    (2, 64, 64, [(96, 96), (48, 48)]),                           # more than 4096 keys per sample; an upscaled mask
+    (1, 37, 53, [(40, 40)]),
+])
+def test_key_masks_one_launch_equals_the_torch_expressions(B, h, w, sizes):
+    from adaprompt_amd import functional as HF
+    from adaprompt_amd.ldm.modules.attention import KeyMasks
+    img = _mask_images(B, h, w, seed=h + w)
+    km = KeyMasks(img, sizes=sizes)
+    for H, W in sizes:
+        m2 = F.interpolate(img.float(), size=(H, W), mode="nearest")
+        want = (m2.reshape(B, H * W) != 0).to(torch.uint8)
+        assert torch.equal(km.at(H, W), want), (H, W)
+        if H * W >= HF.COMPACT_KEYS_MIN_N:
+            c = km.compaction(H, W)
+            perm = torch.argsort(want, dim=1, descending=True, stable=True)
+            inv = torch.argsort(perm, dim=1)
+            count = want.sum(dim=1, dtype=torch.int32)
+            count = torch.where(count == 0, torch.full_like(count, H * W), count)
+            assert c.perm.dtype == torch.int32 and c.inv_perm.dtype == torch.int32 and c.count.dtype == torch.int32
+            assert torch.equal(c.perm.long(), perm) and torch.equal(c.inv_perm.long(), inv) and torch.equal(c.count, count)
+            assert c.mask.data_ptr() == km.at(H, W).data_ptr()
+        else:
+            with pytest.raises(ValueError):
+                km.compaction(H, W)
+    # a size that was not announced gets its own launch
+    H, W = sizes[0][0] // 2 + 3, sizes[0][1] // 2 + 1
+    want = (F.interpolate(img.float(), size=(H, W), mode="nearest").reshape(B, H * W) != 0).to(torch.uint8)
+    assert torch.equal(km.at(H, W), want)
+    with pytest.raises(ValueError):
+        KeyMasks(img[:, 0])
+
+
+@pytest.mark.parametrize("with_aug", [True, False])
+def test_pixel_classes_one_launch_equals_the_torch_expression(with_aug):
+    from adaprompt_amd.ldm.modules.diffusionmodules.model import AttnBlock
+    B, h, w, hw = 3, 512, 384, (64, 48)
+    fg = _mask_images(B, h, w, seed=5)
+    fg[0, :, 100:200, 50:90] = 0.5                   # (a soft value: fg and 1 - fg both non-zero -> class 1 wins)
+    aug = _mask_images(B, h // 2, w // 2, seed=6) if with_aug else None
+    got = AttnBlock.pixel_classes({"fg_mask": fg, "aug_mask": aug}, hw, fg)
+    f = F.interpolate(fg, size=hw, mode="nearest")
+    a = torch.ones_like(f) if aug is None else F.interpolate(aug, size=hw, mode="nearest")
+    want = torch.where(f * a != 0, 1, torch.where((1 - f) * a != 0, 2, 0)).reshape(B, -1).to(torch.uint8)
+    assert got.dtype == torch.uint8 and torch.equal(got, want)
+    assert AttnBlock.pixel_classes(None, hw, fg) is None and AttnBlock.pixel_classes({"fg_mask": None}, hw, fg) is None
