@@ -12,6 +12,10 @@ OUT = os.path.join(HERE, "libadaprompt_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "adaprompt_hip.h")
 SOURCES = ["capi.hip", "conv_gemm.hip", "norms.hip", "attention.hip", "misc.hip", "optim.hip", "wgrad.hip", "vae.hip", "comm.hip", "regloss.hip", "blocks.hip", "stage2loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
+# per-source additions.  attention.hip: the SLP vectoriser packs the softmax's independent f32 multiplies into v_pk_mul_f32 and the
+# bf16 conversions into shuffles -- 28 v_mov + 12 v_alignbit + 4 v_perm of register re-alignment per dK/dV tile step beside the
+# MFMAs (the guide's "packed f32 VALU is an anti-lever beside MFMAs"); without it the loops are exp / mul / cvt only
+FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _stamp():
@@ -26,6 +30,7 @@ def _stamp():
         h.update(b"adaprompt_hip.h")
         h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -64,7 +69,7 @@ def _build_locked(stamp_file, verbose, tempfile, shutil):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

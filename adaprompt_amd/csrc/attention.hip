@@ -23,6 +23,7 @@
 // as the forward), dK/dV are key-stationary (a wave owns 32 keys and sweeps the queries); P is
 // recomputed from the saved LSE.
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include <float.h>
 
@@ -51,6 +52,20 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sh) {
     for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * sh + j];
     return r;
 }
+
+// A per-query (per-row) f32 addend of the scores that rides through the matrix core instead of the vector unit: with a spare
+// K-dimension chunk (dim_head = 40 pads to 48) the key side carries 1.0 in the chunk's first columns and the query side the
+// addend, split into bf16 terms -- hi + mid + lo reproduce an f32 to 2^-24 of its size, and the products 1.0 * term are exact.
+// (The accumulator then starts from the inline constant 0: no 16-register copy of the addend per score tile.)
+__device__ __forceinline__ uint2 bf16_split3(float x) {
+    const float hi = bf16_to_f32(f32_to_bf16(x));
+    const float r1 = x - hi;
+    const float mid = bf16_to_f32(f32_to_bf16(r1));
+    const float lo = r1 - mid;
+    return make_uint2((uint32_t)f32_to_bf16(hi) | ((uint32_t)f32_to_bf16(mid) << 16), (uint32_t)f32_to_bf16(lo));
+}
+#define BF16_ONES3_X 0x3F803F80u      // (1.0, 1.0) and
+#define BF16_ONES3_Y 0x00003F80u      // (1.0, 0): the key side of a three-term addend
 
 #define TOK_MAXG 4
 struct AttnParams {
@@ -164,7 +179,8 @@ struct TileMap {
     int goff[CPT];      // element offset in the global tile
     int loff[CPT];      // byte offset in the LDS image, or -1
     bool one[CPT];      // this chunk starts at the "ones" column (V tile: its first element is bf16 1.0, the rest 0)
-    __device__ __forceinline__ void init(long ld, int stride, int d, int tid, int ones_chunk = -1) {
+    // skip_chunk: this chunk of every row is written by somebody else (the dK/dV kernel's per-row addends), not by the tile's store
+    __device__ __forceinline__ void init(long ld, int stride, int d, int tid, int ones_chunk = -1, int skip_chunk = -1) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             int idx = tid + NT * i;
@@ -172,7 +188,7 @@ struct TileMap {
             bool in = idx < 64 * NCH;
             row[i] = (in && ch * 8 < d) ? r : 64;
             goff[i] = (int)(r * ld) + ch * 8;
-            loff[i] = in ? r * stride + ch * 16 : -1;
+            loff[i] = (in && ch != skip_chunk) ? r * stride + ch * 16 : -1;
             one[i] = in && ch == ones_chunk;
         }
     }
@@ -280,8 +296,13 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
     const int ntiles = (Mb + 63) / 64;
     TileRegs<G::NCH> rK, rV;
     TileMap<G::NCH> mapK, mapV;
-    mapK.init(p.ldk, KSTRIDE, d, tid);
+    // pre-scaled queries with a spare K chunk: the reference point -m rides in through that chunk (the K tile carries 1.0 in
+    // column d, the query fragment -m there) -- m is kept bf16-representable for it, which is as good a reference point as any
+    const bool padm = pre && (d >> 3) < G::NCH && !(p.xcd & 16);
+    mapK.init(p.ldk, KSTRIDE, d, tid, padm ? (d >> 3) : -1);
     mapV.init(p.ldv, VSTRIDE, d, tid, ones_col ? (d >> 3) : -1);
+    const int pad_s = d >> 4;                 // the spare chunk is chunk d/8: fragment slice (d/8)/2 of the lanes h == (d/8)&1
+    const bool pad_lane = padm && h == ((d >> 3) & 1);
     // per-key additive bias of a tile (ragged last tile: -inf, masked keys: -FLT_MAX) and whether the tile has any
     auto key_bias = [&](int key0, float* sBias) {
         if (tid < 64) {
@@ -300,129 +321,151 @@ __global__ __launch_bounds__(256, (QB == 1 && KS <= 6) || (QB == 2 && KS <= 4) ?
     tile_store(rV, mapV, sKV + 64 * KSTRIDE);
     key_bias(0, sBiasAll);
     __syncthreads();
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const bool more = kt + 1 < ntiles;
-        const char* sK = sKV + (kt & 1) * TILE;
-        const char* sV = sK + 64 * KSTRIDE;
-        const float* sBias = sBiasAll + (kt & 1) * 68;
-        if (more) {
-            const int key1 = (kt + 1) * 64;
-            tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, Mb - key1));
-            tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, Mb - key1));
-        }
-        f32x16 S[QB][2];
-        float sinit[QB];
+    // the tile loop in two compiled forms: PADM = the reference point rides in through the spare K chunk (the score tiles then
+    // start from the inline constant 0; with a run-time flag in one loop body they start from a register, 16 copies per tile)
+    auto tiles = [&](auto padc) {
+        constexpr bool PADM = decltype(padc)::value;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const bool more = kt + 1 < ntiles;
+            const char* sK = sKV + (kt & 1) * TILE;
+            const char* sV = sK + 64 * KSTRIDE;
+            const float* sBias = sBiasAll + (kt & 1) * 68;
+            if (more) {
+                const int key1 = (kt + 1) * 64;
+                tile_load(rK, mapK, kb + (size_t)key1 * p.ldk, min(64, Mb - key1));
+                tile_load(rV, mapV, vb + (size_t)key1 * p.ldv, min(64, Mb - key1));
+            }
+            f32x16 S[QB][2];
+            float sinit[QB];
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) sinit[qb] = (pre && m[qb] != -INFINITY) ? -m[qb] : 0.f;
+            for (int qb = 0; qb < QB; ++qb) sinit[qb] = (pre && !PADM && m[qb] != -INFINITY) ? -m[qb] : 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[qb][t][r] = sinit[qb];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
-                    S[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][s], S[qb][t], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[qb][t][r] = sinit[qb];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    bf16x8 kf = *(const bf16x8*)(sK + (32 * t + c) * KSTRIDE + (2 * s + h) * 16);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        S[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][s], S[qb][t], 0, 0, 0);
+                }
             }
-        }
-        // wave-uniform: ragged / masked tile (not even looked at when there is no key mask and the tile is not the ragged last one)
-        const bool biased = (p.kmask != nullptr || (!more && (Mb & 63) != 0)) && sBias[64] != 0.f;
+            // wave-uniform: ragged / masked tile (not even looked at when there is no key mask and the tile is not the ragged last one)
+            const bool biased = (p.kmask != nullptr || (!more && (Mb & 63) != 0)) && sBias[64] != 0.f;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            if (biased) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
-                        S[qb][t][4 * g] += bv.x; S[qb][t][4 * g + 1] += bv.y;
-                        S[qb][t][4 * g + 2] += bv.z; S[qb][t][4 * g + 3] += bv.w;
-                    }
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][t][r]);
-            mx = xor32_max(mx);
-            // running reference point in the exp2 domain (cs > 0): raised only when a row's max outgrows it by more than
-            // 2^MAX_SLACK (or it is still -inf) -- p <= 2^MAX_SLACK keeps its full f32 / bf16 relative precision, and the O
-            // rescale below (64 multiplies) then runs on a handful of tiles instead of on every second one
-            if constexpr (pre) {
-                // S is already in the exp2 domain and relative to the reference point m (absolute while m is still -inf)
-                const bool first = m[qb] == -INFINITY;
-                const bool grow = first ? (mx > -INFINITY) : (mx > MAX_SLACK);
-                if (__any(grow)) {                      // wave-uniform, rare: the reference moves up by `shift`
-                    const float shift = grow ? mx : 0.f;
-                    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-shift);
-#pragma unroll
-                    for (int vt = 0; vt < VT; ++vt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
-                    l[qb] *= alpha;
-                    if (grow) m[qb] = first ? mx : m[qb] + shift;
+            for (int qb = 0; qb < QB; ++qb) {
+                if (biased) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) S[qb][t][r] -= shift;
+                        for (int g = 0; g < 4; ++g) {
+                            float4 bv = *(const float4*)(sBias + 32 * t + 8 * g + 4 * h);
+                            S[qb][t][4 * g] += bv.x; S[qb][t][4 * g + 1] += bv.y;
+                            S[qb][t][4 * g + 2] += bv.z; S[qb][t][4 * g + 3] += bv.w;
+                        }
                 }
+                float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(S[qb][t][r]);
-            } else {
-                const float mcand = mx * cs;
-                const bool grow = mcand > m[qb] + MAX_SLACK;
-                if (__any(grow)) {                          // wave-uniform
-                    const float mnew = grow ? mcand : m[qb];
-                    const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);      // 1 for the rows that keep their reference
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][t][r]);
+                mx = xor32_max(mx);
+                // running reference point in the exp2 domain (cs > 0): raised only when a row's max outgrows it by more than
+                // 2^MAX_SLACK (or it is still -inf) -- p <= 2^MAX_SLACK keeps its full f32 / bf16 relative precision, and the O
+                // rescale below (64 multiplies) then runs on a handful of tiles instead of on every second one
+                if constexpr (pre) {
+                    // S is already in the exp2 domain and relative to the reference point m (absolute while m is still -inf)
+                    const bool first = m[qb] == -INFINITY;
+                    const bool grow = first ? (mx > -INFINITY) : (mx > MAX_SLACK);
+                    if (__any(grow)) {                      // wave-uniform, rare: the reference moves up by `shift`
+                        float mnew = first ? mx : m[qb] + mx;
+                        if (PADM) mnew = bf16_to_f32(f32_to_bf16(mnew));   // (it travels in a Q fragment: a bf16 value)
+                        const float shift = !grow ? 0.f : (first ? mnew : mnew - m[qb]);
+                        if (PADM && grow) {
 #pragma unroll
-                    for (int vt = 0; vt < VT; ++vt)
+                            for (int s2 = 0; s2 < KS; ++s2)
+                                if (s2 == pad_s && pad_lane) {
+                                    uint4 qv = __builtin_bit_cast(uint4, qf[qb][s2]);
+                                    qv.x = (uint32_t)f32_to_bf16(-mnew);
+                                    qf[qb][s2] = __builtin_bit_cast(bf16x8, qv);
+                                }
+                        }
+                        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
-                    l[qb] *= alpha;
-                    m[qb] = mnew;
+                        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
+                        l[qb] *= alpha;
+                        if (grow) m[qb] = mnew;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) S[qb][t][r] -= shift;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(S[qb][t][r]);
+                } else {
+                    const float mcand = mx * cs;
+                    const bool grow = mcand > m[qb] + MAX_SLACK;
+                    if (__any(grow)) {                          // wave-uniform
+                        const float mnew = grow ? mcand : m[qb];
+                        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);      // 1 for the rows that keep their reference
+#pragma unroll
+                        for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) O[qb][vt][r] *= alpha;
+                        l[qb] *= alpha;
+                        m[qb] = mnew;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(fmaf(S[qb][t][r], cs, -m[qb]));
                 }
+                if (!ones_col) {
+                    float psum = 0.f;
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) S[qb][t][r] = __builtin_amdgcn_exp2f(fmaf(S[qb][t][r], cs, -m[qb]));
+                        for (int r = 0; r < 16; ++r) psum += S[qb][t][r];
+                    l[qb] += psum;
+                }
             }
-            if (!ones_col) {
-                float psum = 0.f;
+            // O^T += V^T P^T
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) psum += S[qb][t][r];
-                l[qb] += psum;
+                for (int sh = 0; sh < 2; ++sh) {
+                    bf16x8 pf[QB];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) pf[qb] = acc_to_frag(S[qb][t], sh);
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) {
+                        bf16x8 vf = lds_tr_frag(sV, VSTRIDE, 32 * t + 16 * sh, 32 * vt, lane);
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], O[qb][vt], 0, 0, 0);
+                    }
+                }
+            if (more) {                                     // the other buffer: its last readers passed the previous barrier
+                char* nK = sKV + ((kt + 1) & 1) * TILE;
+                tile_store(rK, mapK, nK);
+                tile_store(rV, mapV, nK + 64 * KSTRIDE);
+                key_bias((kt + 1) * 64, sBiasAll + ((kt + 1) & 1) * 68);
             }
+            __syncthreads();
         }
-        // O^T += V^T P^T
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                bf16x8 pf[QB];
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) pf[qb] = acc_to_frag(S[qb][t], sh);
-#pragma unroll
-                for (int vt = 0; vt < VT; ++vt) {
-                    bf16x8 vf = lds_tr_frag(sV, VSTRIDE, 32 * t + 16 * sh, 32 * vt, lane);
-#pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
-                        O[qb][vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], O[qb][vt], 0, 0, 0);
-                }
-            }
-        if (more) {                                     // the other buffer: its last readers passed the previous barrier
-            char* nK = sKV + ((kt + 1) & 1) * TILE;
-            tile_store(rK, mapK, nK);
-            tile_store(rV, mapV, nK + 64 * KSTRIDE);
-            key_bias((kt + 1) * 64, sBiasAll + ((kt + 1) & 1) * 68);
-        }
-        __syncthreads();
+    };
+    if constexpr (pre) {
+        if (padm) tiles(std::true_type{});
+        else tiles(std::false_type{});
+    } else {
+        tiles(std::false_type{});
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -1246,7 +1289,10 @@ __global__ __launch_bounds__(256, (KS <= 6 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 // =============================================================================================
 // backward, part 2: dK, dV (key-stationary: a wave owns 32 keys, the workgroup 128 keys)
 // =============================================================================================
-template <int KS, int VT, bool PRE>
+// MASKED = false (no key mask; a key count at most): a key's column of S / P / dS feeds only that key's own dK / dV column, so
+// the rows beyond the count are not biased inside the loop at all -- their columns (whatever they hold) are zeroed at the end.
+// (The compiler turns the wave-uniform `if (biased) S += bias` into 32 adds + 32 selects per tile step on every path.)
+template <int KS, int VT, bool PRE, bool MASKED>
 __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnParams p) {
     using G = TileGeom<KS>;
     constexpr int QSTRIDE = G::RSTRIDE;
@@ -1271,6 +1317,11 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     constexpr bool pre = PRE;             // (a template parameter: see attn_fwd_kernel)
     const int Mb = attn_key_count(p, b);          // this sample's key count (rows beyond it get zeros)
 
+    // pre-scaled queries with a spare K chunk (dim_head 40): -lse and -delta of a query row ride in through that chunk
+    // (bf16_split3): the Q / dO tiles carry their three terms in it, K / V fragments 1.0 -- instead of 16 LDS reads of 16 bytes
+    // per lane and tile step that load them as the accumulators' initial values
+    const bool padstat = pre && (d >> 3) < G::NCH && !(p.xcd & 32);
+    const int pad_ch = padstat ? (d >> 3) : -1;
     // this wave's 32 keys as B operands
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -1281,13 +1332,14 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
             a = *(const uint4*)(p.k + ((size_t)b * p.M + key) * p.ldk + head * d + ch * 8);
             g = *(const uint4*)(p.v + ((size_t)b * p.M + key) * p.ldv + head * d + ch * 8);
         }
+        if (ch == pad_ch) a = g = make_uint4(BF16_ONES3_X, BF16_ONES3_Y, 0, 0);
         kf[s] = __builtin_bit_cast(bf16x8, a);
         vf[s] = __builtin_bit_cast(bf16x8, g);
     }
     float bias = 0.f;
     if (key >= Mb) bias = -INFINITY;
     else if (p.kmask && !p.kmask[(size_t)b * p.M + key]) bias = -FLT_MAX;
-    const bool biased = __any(bias != 0.f);              // wave-uniform
+    const bool biased = MASKED && __any(bias != 0.f);    // wave-uniform
 
     f32x16 dK[VT], dV[VT];
 #pragma unroll
@@ -1302,8 +1354,8 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     const int ntiles = (p.N + 63) / 64;
     TileRegs<G::NCH> rQ, rDO;
     TileMap<G::NCH> mapQ, mapDO;
-    mapQ.init(p.ldq, QSTRIDE, d, tid);
-    mapDO.init(p.lddo, QSTRIDE, d, tid);
+    mapQ.init(p.ldq, QSTRIDE, d, tid, -1, pad_ch);
+    mapDO.init(p.lddo, QSTRIDE, d, tid, -1, pad_ch);
     float rl = 0.f, rd = 0.f;
     auto row_stats_load = [&](int q0) {        // stored negated: -lse2 is the fma addend, -delta the dP accumulator's initial value
         if (tid < 64) {
@@ -1320,85 +1372,123 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     tile_load(rQ, mapQ, qb + (size_t)qt0 * 64 * p.ldq, min(64, p.N - qt0 * 64));
     tile_load(rDO, mapDO, dob + (size_t)qt0 * 64 * p.lddo, min(64, p.N - qt0 * 64));
     row_stats_load(qt0 * 64);
+    auto row_stats_store = [&]() {
+        if (tid < 64) {
+            if (padstat) {
+                const uint2 sl = bf16_split3(rl), sd = bf16_split3(rd);
+                *(uint4*)(sQ + tid * QSTRIDE + pad_ch * 16) = make_uint4(sl.x, sl.y, 0, 0);
+                *(uint4*)(sDO + tid * QSTRIDE + pad_ch * 16) = make_uint4(sd.x, sd.y, 0, 0);
+            } else {
+                sLse[tid] = rl;
+                sDl[tid] = rd;
+            }
+        }
+    };
     tile_store(rQ, mapQ, sQ);
     tile_store(rDO, mapDO, sDO);
-    if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
+    row_stats_store();
     __syncthreads();
-    for (int qt = qt0; qt < qt1; ++qt) {
-        const bool more = qt + 1 < qt1;
-        if (more) {
-            const int q1 = (qt + 1) * 64;
-            tile_load(rQ, mapQ, qb + (size_t)q1 * p.ldq, min(64, p.N - q1));
-            tile_load(rDO, mapDO, dob + (size_t)q1 * p.lddo, min(64, p.N - q1));
-            row_stats_load(q1);
-        }
-        // Three passes over the tile's two 32-query halves -- all S / dP products, then both halves' exponent / dS chains, then
-        // all dV / dK products -- instead of one half after the other: the matrix pipe gets 12 and 16 back-to-back MFMAs and the
-        // vector unit two independent chains at a time (the two waves of a SIMD then overlap phases of different kinds more often)
-        f32x16 S[2], dP[2], nl[2];
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            // rows of S / dP are queries 32qi + 8g + 4h + e, the column (lane) is this wave's key
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
-                float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
-                nl[qi][4 * g] = lv.x; nl[qi][4 * g + 1] = lv.y; nl[qi][4 * g + 2] = lv.z; nl[qi][4 * g + 3] = lv.w;
-                if (pre) { S[qi][4 * g] = lv.x; S[qi][4 * g + 1] = lv.y; S[qi][4 * g + 2] = lv.z; S[qi][4 * g + 3] = lv.w; }
-                else { S[qi][4 * g] = 0.f; S[qi][4 * g + 1] = 0.f; S[qi][4 * g + 2] = 0.f; S[qi][4 * g + 3] = 0.f; }
-                dP[qi][4 * g] = dv.x; dP[qi][4 * g + 1] = dv.y; dP[qi][4 * g + 2] = dv.z; dP[qi][4 * g + 3] = dv.w;
+    // the query-tile loop in two compiled forms (PADSTAT: the score tiles start from the inline constant 0 -- as a run-time flag in
+    // one loop body the zero start is 64 register writes per step)
+    auto qtiles = [&](auto padc) {
+        constexpr bool PADSTAT = decltype(padc)::value;
+        for (int qt = qt0; qt < qt1; ++qt) {
+            const bool more = qt + 1 < qt1;
+            if (more) {
+                const int q1 = (qt + 1) * 64;
+                tile_load(rQ, mapQ, qb + (size_t)q1 * p.ldq, min(64, p.N - q1));
+                tile_load(rDO, mapDO, dob + (size_t)q1 * p.lddo, min(64, p.N - q1));
+                row_stats_load(q1);
             }
+            // Three passes over the tile's two 32-query halves -- all S / dP products, then both halves' exponent / dS chains, then
+            // all dV / dK products -- instead of one half after the other: the matrix pipe gets 12 and 16 back-to-back MFMAs and the
+            // vector unit two independent chains at a time (the two waves of a SIMD then overlap phases of different kinds more often)
+            f32x16 S[2], dP[2], nl[2];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                bf16x8 qrow = *(const bf16x8*)(sQ + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
-                S[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow, kf[s], S[qi], 0, 0, 0);
-                bf16x8 drow = *(const bf16x8*)(sDO + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
-                dP[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP[qi], 0, 0, 0);
-            }
-        }
+            for (int qi = 0; qi < 2; ++qi) {
+                // rows of S / dP are queries 32qi + 8g + 4h + e, the column (lane) is this wave's key
+                if constexpr (PADSTAT) {
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            if (biased) {
+                    for (int r = 0; r < 16; ++r) { S[qi][r] = 0.f; dP[qi][r] = 0.f; nl[qi][r] = 0.f; }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[qi][r] += bias;
-            }
-            if (pre) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(S[qi][r]);
-                    S[qi][r] = pv;                 // P
-                    dP[qi][r] = pv * dP[qi][r];    // dS
+                    for (int g = 0; g < 4; ++g) {
+                        float4 lv = *(const float4*)(sLse + 32 * qi + 8 * g + 4 * h);
+                        float4 dv = *(const float4*)(sDl + 32 * qi + 8 * g + 4 * h);
+                        nl[qi][4 * g] = lv.x; nl[qi][4 * g + 1] = lv.y; nl[qi][4 * g + 2] = lv.z; nl[qi][4 * g + 3] = lv.w;
+                        if (pre) { S[qi][4 * g] = lv.x; S[qi][4 * g + 1] = lv.y; S[qi][4 * g + 2] = lv.z; S[qi][4 * g + 3] = lv.w; }
+                        else { S[qi][4 * g] = 0.f; S[qi][4 * g + 1] = 0.f; S[qi][4 * g + 2] = 0.f; S[qi][4 * g + 3] = 0.f; }
+                        dP[qi][4 * g] = dv.x; dP[qi][4 * g + 1] = dv.y; dP[qi][4 * g + 2] = dv.z; dP[qi][4 * g + 3] = dv.w;
+                    }
                 }
-            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(S[qi][r], cs, nl[qi][r]));
-                    S[qi][r] = pv;                 // P
-                    dP[qi][r] = pv * dP[qi][r];    // dS
+                for (int s = 0; s < KS; ++s) {
+                    bf16x8 qrow = *(const bf16x8*)(sQ + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
+                    S[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qrow, kf[s], S[qi], 0, 0, 0);
+                    bf16x8 drow = *(const bf16x8*)(sDO + (32 * qi + c) * QSTRIDE + (2 * s + h) * 16);
+                    dP[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP[qi], 0, 0, 0);
                 }
             }
-        }
 #pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
+            for (int qi = 0; qi < 2; ++qi) {
+                if constexpr (MASKED) {
+                    if (biased) {
 #pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-                bf16x8 pf = acc_to_frag(S[qi], sh);
-                bf16x8 dsf = acc_to_frag(dP[qi], sh);
+                        for (int r = 0; r < 16; ++r) S[qi][r] += bias;
+                    }
+                }
+                if (pre) {
 #pragma unroll
-                for (int vt = 0; vt < VT; ++vt) {
-                    bf16x8 dotr = lds_tr_frag(sDO, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
-                    dV[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotr, pf, dV[vt], 0, 0, 0);
-                    bf16x8 qtr = lds_tr_frag(sQ, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
-                    dK[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr, dsf, dK[vt], 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(S[qi][r]);
+                        S[qi][r] = pv;                 // P
+                        dP[qi][r] = pv * dP[qi][r];    // dS
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(fmaf(S[qi][r], cs, nl[qi][r]));
+                        S[qi][r] = pv;                 // P
+                        dP[qi][r] = pv * dP[qi][r];    // dS
+                    }
                 }
             }
-        }
-        __syncthreads();
-        if (more) {
-            tile_store(rQ, mapQ, sQ);
-            tile_store(rDO, mapDO, sDO);
-            if (tid < 64) { sLse[tid] = rl; sDl[tid] = rd; }
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    bf16x8 pf = acc_to_frag(S[qi], sh);
+                    bf16x8 dsf = acc_to_frag(dP[qi], sh);
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) {
+                        bf16x8 dotr = lds_tr_frag(sDO, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
+                        dV[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotr, pf, dV[vt], 0, 0, 0);
+                        bf16x8 qtr = lds_tr_frag(sQ, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
+                        dK[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr, dsf, dK[vt], 0, 0, 0);
+                    }
+                }
+            }
             __syncthreads();
+            if (more) {
+                tile_store(rQ, mapQ, sQ);
+                tile_store(rDO, mapDO, sDO);
+                row_stats_store();
+                __syncthreads();
+            }
+        }
+    };
+    if constexpr (pre) {
+        if (padstat) qtiles(std::true_type{});
+        else qtiles(std::false_type{});
+    } else {
+        qtiles(std::false_type{});
+    }
+    if constexpr (!MASKED) {
+        if (bias != 0.f) {              // a key beyond the sample's count: softmax weight exactly 0 (bias = -inf)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dK[vt][r] = 0.f; dV[vt][r] = 0.f; }
         }
     }
     if (key < p.M) {
@@ -1506,7 +1596,8 @@ struct AttnDebug {
     int pp_prio;      // ping-pong kernel: phase at raised priority, 1 = matrix (default), 2 = vector, 0 = neither
     int qb1;          // 1 = one query block per wave even at the 64 x 64 level
     int dkv_qsplit;   // 0 = heuristic, else the dK/dV kernel's query-split factor
-    int xcd;          // AttnParams::xcd bits (ADAP_ATTN_XCD=0: the plain blockIdx map everywhere, for A/B runs)
+    int xcd;          // AttnParams::xcd bits (ADAP_ATTN_XCD=0: the plain blockIdx map everywhere, for A/B runs; +16 / +32: the
+                      // forward's reference point / the dK/dV kernel's row statistics NOT through the spare K chunk)
 };
 static AttnDebug& attn_debug() {
     static AttnDebug d = [] {
@@ -1650,8 +1741,13 @@ static int launch_bwd(const AttnParams& p_in, hipStream_t s) {
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT, false>), g1, dim3(256), lds1, s, p);
     size_t lds2 = 2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4;
     dim3 g2((p.M + 127) / 128, p.B * p.H, p.qsplit);
-    if (p.pre) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, true>), g2, dim3(256), lds2, s, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, false>), g2, dim3(256), lds2, s, p);
+    if (p.kmask) {
+        if (p.pre) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, true, true>), g2, dim3(256), lds2, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, false, true>), g2, dim3(256), lds2, s, p);
+    } else {
+        if (p.pre) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, true, false>), g2, dim3(256), lds2, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, false, false>), g2, dim3(256), lds2, s, p);
+    }
     if (p.qsplit > 1) {
         long tot = (long)p.B * p.M * (p.H * p.d / 4);
         long nb = (tot + 255) / 256;

@@ -8,7 +8,9 @@ C = H * d
 qkv = torch.randn(B, N, 3 * C, device=dev).to(torch.bfloat16)
 q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
 do = torch.randn(B, N, C, device=dev).to(torch.bfloat16)
-def timed(fn, it=200):
+IT = int(os.environ.get('ADAP_PROBE_ITERS', '200'))
+def timed(fn, it=None):
+    it = it or IT
     for _ in range(it): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
