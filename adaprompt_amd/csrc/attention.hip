@@ -1297,10 +1297,13 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     using G = TileGeom<KS>;
     constexpr int QSTRIDE = G::RSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;                        // [64][QSTRIDE]
-    char* sDO = sQ + 64 * QSTRIDE;          // [64][QSTRIDE]
-    float* sLse = (float*)(sDO + 64 * QSTRIDE);   // [64] (log2 domain)
-    float* sDl = sLse + 64;                       // [64]
+    // two sets of [ Q [64][QSTRIDE] | dO [64][QSTRIDE] | lse [64] (log2 domain) | delta [64] ]: tile qt+1 is written (from the
+    // registers its global loads landed in) while other waves may still be multiplying tile qt -- ONE barrier per tile step
+    constexpr int SET = 2 * 64 * QSTRIDE + 128 * 4;
+    char* sQ = smem;
+    char* sDO = sQ + 64 * QSTRIDE;
+    float* sLse = (float*)(sDO + 64 * QSTRIDE);
+    float* sDl = sLse + 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -1372,21 +1375,21 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
     tile_load(rQ, mapQ, qb + (size_t)qt0 * 64 * p.ldq, min(64, p.N - qt0 * 64));
     tile_load(rDO, mapDO, dob + (size_t)qt0 * 64 * p.lddo, min(64, p.N - qt0 * 64));
     row_stats_load(qt0 * 64);
-    auto row_stats_store = [&]() {
+    auto row_stats_store = [&](int off) {         // off: byte offset of the buffer set
         if (tid < 64) {
             if (padstat) {
                 const uint2 sl = bf16_split3(rl), sd = bf16_split3(rd);
-                *(uint4*)(sQ + tid * QSTRIDE + pad_ch * 16) = make_uint4(sl.x, sl.y, 0, 0);
-                *(uint4*)(sDO + tid * QSTRIDE + pad_ch * 16) = make_uint4(sd.x, sd.y, 0, 0);
+                *(uint4*)(sQ + off + tid * QSTRIDE + pad_ch * 16) = make_uint4(sl.x, sl.y, 0, 0);
+                *(uint4*)(sDO + off + tid * QSTRIDE + pad_ch * 16) = make_uint4(sd.x, sd.y, 0, 0);
             } else {
-                sLse[tid] = rl;
-                sDl[tid] = rd;
+                *(float*)((char*)sLse + off + tid * 4) = rl;
+                *(float*)((char*)sDl + off + tid * 4) = rd;
             }
         }
     };
     tile_store(rQ, mapQ, sQ);
     tile_store(rDO, mapDO, sDO);
-    row_stats_store();
+    row_stats_store(0);
     __syncthreads();
     // the query-tile loop in two compiled forms (PADSTAT: the score tiles start from the inline constant 0 -- as a run-time flag in
     // one loop body the zero start is 64 register writes per step)
@@ -1394,6 +1397,11 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
         constexpr bool PADSTAT = decltype(padc)::value;
         for (int qt = qt0; qt < qt1; ++qt) {
             const bool more = qt + 1 < qt1;
+            const int cur = ((qt - qt0) & 1) * SET;        // this step's buffer set (byte offset)
+            const char* sQ = smem + cur;
+            const char* sDO = sQ + 64 * QSTRIDE;
+            const float* sLse = (const float*)(sDO + 64 * QSTRIDE);
+            const float* sDl = sLse + 64;
             if (more) {
                 const int q1 = (qt + 1) * 64;
                 tile_load(rQ, mapQ, qb + (size_t)q1 * p.ldq, min(64, p.N - q1));
@@ -1468,13 +1476,13 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
                     }
                 }
             }
-            __syncthreads();
-            if (more) {
-                tile_store(rQ, mapQ, sQ);
-                tile_store(rDO, mapDO, sDO);
-                row_stats_store();
-                __syncthreads();
+            if (more) {                                    // the other set: its last readers passed the previous barrier
+                char* nQ = smem + (SET - cur);
+                tile_store(rQ, mapQ, nQ);
+                tile_store(rDO, mapDO, nQ + 64 * QSTRIDE);
+                row_stats_store(SET - cur);
             }
+            __syncthreads();
         }
     };
     if constexpr (pre) {
@@ -1726,6 +1734,16 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
     return launch_fwd_q<KS, VT, 1>(p, s);
 }
 
+template <int KS, int VT, bool PRE, bool MASKED>
+static void launch_dkv(dim3 grid, size_t lds, hipStream_t s, const AttnParams& p) {
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KS, VT, PRE, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, PRE, MASKED>), grid, dim3(256), lds, s, p);
+}
+
 template <int KS, int VT>
 static int launch_bwd(const AttnParams& p_in, hipStream_t s) {
     // The XCD-aware workgroup map (attn_wg_coords) for the two backward kernels only where a (batch, head) row has few blocks:
@@ -1739,14 +1757,14 @@ static int launch_bwd(const AttnParams& p_in, hipStream_t s) {
     dim3 g1((p.N + 127) / 128, p.B * p.H);
     if (p.pre) hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT, true>), g1, dim3(256), lds1, s, p);
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, VT, false>), g1, dim3(256), lds1, s, p);
-    size_t lds2 = 2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4;
+    size_t lds2 = 2 * (2 * 64 * TileGeom<KS>::RSTRIDE + 128 * 4);          // two buffer sets
     dim3 g2((p.M + 127) / 128, p.B * p.H, p.qsplit);
     if (p.kmask) {
-        if (p.pre) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, true, true>), g2, dim3(256), lds2, s, p);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, false, true>), g2, dim3(256), lds2, s, p);
+        if (p.pre) launch_dkv<KS, VT, true, true>(g2, lds2, s, p);
+        else launch_dkv<KS, VT, false, true>(g2, lds2, s, p);
     } else {
-        if (p.pre) hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, true, false>), g2, dim3(256), lds2, s, p);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<KS, VT, false, false>), g2, dim3(256), lds2, s, p);
+        if (p.pre) launch_dkv<KS, VT, true, false>(g2, lds2, s, p);
+        else launch_dkv<KS, VT, false, false>(g2, lds2, s, p);
     }
     if (p.qsplit > 1) {
         long tot = (long)p.B * p.M * (p.H * p.d / 4);
