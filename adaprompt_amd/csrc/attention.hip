@@ -1437,6 +1437,12 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
                     dP[qi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(drow, vf[s], dP[qi], 0, 0, 0);
                 }
             }
+            bf16x8 cdo[VT], cq[VT];
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) {
+                cdo[vt] = lds_tr_frag(sDO, QSTRIDE, 0, 32 * vt, lane);
+                cq[vt] = lds_tr_frag(sQ, QSTRIDE, 0, 32 * vt, lane);
+            }
 #pragma unroll
             for (int qi = 0; qi < 2; ++qi) {
                 if constexpr (MASKED) {
@@ -1461,19 +1467,29 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void attn_bwd_dkv_kernel(At
                     }
                 }
             }
+            // dV / dK products, the transposed dO / Q fragments of 16-query slice i + 1 read while slice i multiplies (slice 0's
+            // were read in front of the exponent phase above)
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-#pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    bf16x8 pf = acc_to_frag(S[qi], sh);
-                    bf16x8 dsf = acc_to_frag(dP[qi], sh);
+            for (int i = 0; i < 4; ++i) {
+                const int qi = i >> 1, sh = i & 1;
+                bf16x8 ndo[VT], nq[VT];
+                if (i < 3) {
 #pragma unroll
                     for (int vt = 0; vt < VT; ++vt) {
-                        bf16x8 dotr = lds_tr_frag(sDO, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
-                        dV[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotr, pf, dV[vt], 0, 0, 0);
-                        bf16x8 qtr = lds_tr_frag(sQ, QSTRIDE, 32 * qi + 16 * sh, 32 * vt, lane);
-                        dK[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtr, dsf, dK[vt], 0, 0, 0);
+                        ndo[vt] = lds_tr_frag(sDO, QSTRIDE, 16 * (i + 1), 32 * vt, lane);
+                        nq[vt] = lds_tr_frag(sQ, QSTRIDE, 16 * (i + 1), 32 * vt, lane);
                     }
+                }
+                bf16x8 pf = acc_to_frag(S[qi], sh);
+                bf16x8 dsf = acc_to_frag(dP[qi], sh);
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) {
+                    dV[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cdo[vt], pf, dV[vt], 0, 0, 0);
+                    dK[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq[vt], dsf, dK[vt], 0, 0, 0);
+                }
+                if (i < 3) {
+#pragma unroll
+                    for (int vt = 0; vt < VT; ++vt) { cdo[vt] = ndo[vt]; cq[vt] = nq[vt]; }
                 }
             }
             if (more) {                                    // the other set: its last readers passed the previous barrier
