@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Self-attention kernels in isolation on the UNet's shapes (tuning aid, GPU only)."""
+"""Self-attention kernels in isolation on the UNet's shapes (tuning aid, GPU only).  Self-attention shapes (N == M) run in the form
+the training step calls: pre-scaled queries, scale = 0 (functional.PRESCALE_Q); the cross-attention shape with the kernel's own scale."""
 import os
 import sys
 
@@ -15,17 +16,18 @@ for (B, H, N, M, d) in [(4, 8, 4096, 4096, 40), (4, 8, 1024, 1024, 80), (4, 8, 2
     k = torch.randn(B, M, C, device=dev).to(torch.bfloat16)
     v = torch.randn(B, M, C, device=dev).to(torch.bfloat16)
     do = torch.randn(B, N, C, device=dev).to(torch.bfloat16)
+    sc = 0.0 if N == M else None
     for _ in range(2):
-        o, lse = ops.attention_fwd(q, k, v, H)
-        ops.attention_bwd(q, k, v, o, do, lse, H)
+        o, lse = ops.attention_fwd(q, k, v, H, scale=sc)
+        ops.attention_bwd(q, k, v, o, do, lse, H, scale=sc)
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record()
     for _ in range(5):
-        o, lse = ops.attention_fwd(q, k, v, H)
+        o, lse = ops.attention_fwd(q, k, v, H, scale=sc)
     e[1].record()
     for _ in range(5):
-        ops.attention_bwd(q, k, v, o, do, lse, H)
+        ops.attention_bwd(q, k, v, o, do, lse, H, scale=sc)
     e[2].record()
     torch.cuda.synchronize()
     f = 4.0 * B * H * N * M * d
