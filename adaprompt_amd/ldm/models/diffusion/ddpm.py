@@ -1967,6 +1967,8 @@ class MicroBatchLanes:
         self.reducer = reducer
         self._prev_done = None
         self._gated, self._gate_ev = set(), None
+        ops.multi_stream(+1)             # cached device data built from now on is complete before another lane can read it
+        self._announced = True
         # Every stream this process will use takes its hardware queue NOW, in a fixed order -- the lanes, then each lane's block
         # side lane (functional.side_lane; suspended while the lanes run, used by every other leg of a process).  Which streams
         # end up sharing a queue depends on the order of their first use, and the order "lanes first, side lanes whenever a later
@@ -2068,6 +2070,9 @@ class MicroBatchLanes:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._announced:
+            ops.multi_stream(-1)
+            self._announced = False
         if self._warn_set is not None:
             self._warn_set(True)
             self._warn_set = None

@@ -328,6 +328,7 @@ class UNetModel(nn.Module):
                         runs.append((i, j - i, C, wf, wb))
                         i = j
         self.__dict__["_kv_runs_cache"] = (key, runs)
+        ops.note_cache_fill()
         return runs
 
     def _attn2_modules(self):
@@ -357,6 +358,7 @@ class UNetModel(nn.Module):
                 w = torch.cat([b.emb_layers[1].weight.detach().float() for b in blocks], dim=0).contiguous()
                 bias = torch.cat([b.emb_layers[1].bias.detach().float() for b in blocks], dim=0).contiguous()
             self._emb_cat = (stamp, w, bias)
+            ops.note_cache_fill()
         _, w, bias = self._emb_cat
         allp = ops.linear_small(emb, w, bias, pre_silu=True)          # [B, sum Cout]
         outs, off = {}, 0

@@ -298,6 +298,8 @@ def token_weight_matrix(index_groups, batch, ntok):
     for g, (bi, ti) in enumerate(index_groups):
         w[:, :, g].index_put_((bi, ti), torch.ones(bi.numel(), device=dev), accumulate=True)
     _TOKEN_WEIGHTS[key] = (w, [t for pair in index_groups for t in pair])
+    from .. import ops
+    ops.note_cache_fill()            # (cached: the other micro-batch lane reads it too, ops.note_cache_fill)
     return w
 
 

@@ -99,6 +99,30 @@ def _ceil(a, m):
     return (a + m - 1) // m * m
 
 
+# Device data that is built once and then CACHED (weight packs, stacked packs, concatenated weights) is built by kernels on
+# whatever stream is current at its first use -- and read afterwards from every stream without further ordering.  On one stream
+# that is stream order; with several streams of whole passes in flight (MicroBatchLanes: micro-batch 1's forward starts while
+# micro-batch 0's is still running) the second stream's first kernels could read a pack the first stream's pack kernel has not
+# written yet (seen as a NaN loss in two processes sharing one card, where the lanes drift further apart).  So while such a
+# mode is announced (multi_stream(+1)), a cache fill drains the stream that built it before anybody gets to see the result;
+# fills happen in the first window only (frozen weights), or never on the multi-stream paths (unfreeze_model runs one stream).
+CACHE_FILLS = 0
+_MULTI_STREAM = 0
+
+
+def multi_stream(delta):
+    global _MULTI_STREAM
+    _MULTI_STREAM = max(0, _MULTI_STREAM + int(delta))
+
+
+def note_cache_fill():
+    """call AFTER the kernels that build a cached device tensor have been issued."""
+    global CACHE_FILLS
+    CACHE_FILLS += 1
+    if _MULTI_STREAM > 0 and torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
 class PackedConv:
     """bf16 weight packs of one nn.Conv2d / nn.Linear: forward [taps][O][I8] and (lazily) the
     data-gradient pack [taps][I4..][O8] (taps flipped, roles swapped).  I is zero-padded to a
@@ -122,6 +146,7 @@ class PackedConv:
         _lib.call("adap_pack_conv_weight", self.w_f32.data_ptr(), self.fwd.data_ptr(), self.O, self.I, self.KH,
                   self.KW, 0, self.O4, self.I8, _stream())
         self._bwd = None
+        note_cache_fill()
 
     @property
     def bwd(self):
@@ -130,6 +155,7 @@ class PackedConv:
             self._bwd = torch.empty(self.KH * self.KW, rows, cols, device=self.fwd.device, dtype=BF16)
             _lib.call("adap_pack_conv_weight", self.w_f32.data_ptr(), self._bwd.data_ptr(), self.O, self.I, self.KH,
                       self.KW, 1, rows, cols, _stream())
+            note_cache_fill()
         return self._bwd
 
     def drop_f32(self):

@@ -145,6 +145,8 @@ class GradReducer:
     # ---- one chunk's collective ----------------------------------------------------------------------------------------
     def _issue(self, ci):
         c = self.chunks[ci]
+        if os.environ.get("ADAP_DIAG_NO_EXCHANGE") == "1":           # DIAGNOSTIC (tools/lanes_two_process_soak.sh): the ranks stop
+            return                                                   # talking -- two processes share a card at full speed
         if self._cabi is not None:
             # the chunk's gradients were written on the current (compute) stream: the exchange stream waits for exactly that
             ev = torch.cuda.Event()

@@ -271,6 +271,13 @@ def main():
     B = args.batch
     batches = [synthetic_batch(B, device, 1234 + rank * 100 + i) for i in range(2)]
     gen = torch.Generator(device=device).manual_seed(99 + rank)
+    # the host RNG the step draws from (timestep annealing: one random.random() + np.random.randint per element, util.py:372-395):
+    # seeded, so that a run's losses are a function of the command line alone (tools/determinism_check.sh repeats them digit for digit)
+    import random as _py_random
+    import numpy as _np
+    _py_random.seed(4321 + rank)
+    _np.random.seed(4321 + rank)
+    torch.manual_seed(777 + rank)
 
     # ---- hipGraph capture of the launch-bound part (~1400 kernel launches per micro-batch): forward and backward
     # are two graphs, so the previous micro-batch's gradient all-reduce can be awaited between them.  Inputs live in

@@ -233,3 +233,44 @@ def test_trainer_fit_runs_windows_through_the_per_batch_entry():
     assert tr.lanes is None and not ld._win_entry["buf"] and not ld._win_entry["pf"]._queue
     assert all(not p._backward_hooks for p in params)
     assert not ops.gn_sync_poisoned()
+
+
+def test_cached_device_data_is_complete_before_another_lane_can_read_it():
+    """Weight packs (and the other cached device tensors) are built by kernels on whatever stream first needs them and read
+    afterwards from every stream.  While micro-batch lanes exist a fill drains its stream before the object is handed out --
+    found as a NaN loss in two processes sharing one card (lane 1's first convolutions read packs lane 0's pack kernels had not
+    written yet).  Outside that mode nothing is drained (``unfreeze_model`` rebuilds 686 packs per step on one stream)."""
+    from adaprompt_amd import _lib, ops
+    dev = torch.device("cuda:0")
+    w = torch.randn(320, 320, 3, 3, device=dev)
+    sink = torch.zeros(1, device=dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    fills = ops.CACHE_FILLS
+    ops.multi_stream(+1)
+    try:
+        with torch.cuda.stream(side):
+            _lib.call("adap_debug_occupy", 64, 512, 20000, sink.data_ptr(), _lib.current_stream())     # 20 ms ahead of the pack kernel
+            pk = ops.PackedConv(w)
+            assert side.query(), "the pack kernel is still queued behind the resident kernel: another stream could read garbage"
+            _lib.call("adap_debug_occupy", 64, 512, 20000, sink.data_ptr(), _lib.current_stream())
+            _ = pk.bwd
+            assert side.query()
+    finally:
+        ops.multi_stream(-1)
+    assert ops.CACHE_FILLS == fills + 2
+    with torch.cuda.stream(side):
+        _lib.call("adap_debug_occupy", 64, 512, 20000, sink.data_ptr(), _lib.current_stream())
+        pk2 = ops.PackedConv(w)
+        assert not side.query(), "a cache fill must not drain its stream outside the multi-stream mode"
+    torch.cuda.synchronize()
+    assert torch.equal(pk.fwd, pk2.fwd)
+    # the lanes announce the mode for their lifetime
+    from adaprompt_amd.ldm.models.diffusion.ddpm import MicroBatchLanes
+    p = torch.nn.Parameter(torch.zeros(4, device=dev))
+    before = ops._MULTI_STREAM
+    lanes = MicroBatchLanes([p], n=2)
+    assert ops._MULTI_STREAM == before + 1
+    lanes.remove()
+    lanes.remove()
+    assert ops._MULTI_STREAM == before
