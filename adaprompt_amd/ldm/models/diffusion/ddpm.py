@@ -1688,6 +1688,10 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         side_lane_was, ksplit_was, gn_owner_was = HF.SIDE_LANE, None, None
         if lanes is not None:
             lanes.window_start()       # the weights (and whatever else lane 0 has queued so far) as the side lanes' starting point
+            # inside a window on lanes, cached device data (weight packs ...) is complete before the other lane can read it
+            # (ops.note_cache_fill).  Scoped to the window: outside it lane 0 orders everything (window_start), and the
+            # one-stream paths of the same process (unfreeze_model rebuilds 686 packs per step) must not pay a drain per pack
+            ops.multi_stream(+1)
             # a block's side lane (functional.side_lane: work off its dependency chain on a second stream) fills CUs the chain
             # leaves idle -- which the other micro-batch's lane does here; with two lanes, their two side lanes and the prefetch
             # stream the five streams outnumber the hardware queues, and the blocks' fork / join events then cost more than the
@@ -1705,6 +1709,8 @@ class LatentDiffusion(ConditioningMixin, DDPM):
             return self._training_window(batches, optimizer, reducer, scheduler, lanes, auto_iteration, step_kwargs, after_forward,
                                          contextlib, after_backward, pre_kws)
         finally:
+            if lanes is not None:
+                ops.multi_stream(-1)
             HF.SIDE_LANE = side_lane_was
             if ksplit_was is not None:
                 ops._lib.call_long("adap_conv_ksplit_scale", ksplit_was)
@@ -1967,8 +1973,6 @@ class MicroBatchLanes:
         self.reducer = reducer
         self._prev_done = None
         self._gated, self._gate_ev = set(), None
-        ops.multi_stream(+1)             # cached device data built from now on is complete before another lane can read it
-        self._announced = True
         # Every stream this process will use takes its hardware queue NOW, in a fixed order -- the lanes, then each lane's block
         # side lane (functional.side_lane; suspended while the lanes run, used by every other leg of a process).  Which streams
         # end up sharing a queue depends on the order of their first use, and the order "lanes first, side lanes whenever a later
@@ -2070,9 +2074,6 @@ class MicroBatchLanes:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self._announced:
-            ops.multi_stream(-1)
-            self._announced = False
         if self._warn_set is not None:
             self._warn_set(True)
             self._warn_set = None

@@ -104,8 +104,8 @@ def _ceil(a, m):
 # that is stream order; with several streams of whole passes in flight (MicroBatchLanes: micro-batch 1's forward starts while
 # micro-batch 0's is still running) the second stream's first kernels could read a pack the first stream's pack kernel has not
 # written yet (seen as a NaN loss in two processes sharing one card, where the lanes drift further apart).  So while such a
-# mode is announced (multi_stream(+1)), a cache fill drains the stream that built it before anybody gets to see the result;
-# fills happen in the first window only (frozen weights), or never on the multi-stream paths (unfreeze_model runs one stream).
+# mode is announced (multi_stream(+1): LatentDiffusion.training_window for the duration of a window on lanes), a cache fill drains
+# the stream that built it before anybody gets to see the result; fills happen in the first window only (frozen weights).
 CACHE_FILLS = 0
 _MULTI_STREAM = 0
 

@@ -673,11 +673,15 @@ def test_training_window_on_two_lanes_equals_sequential_training_steps():
                     losses.append(ld.training_step(batch, optimizer=opt, reducer=red, scheduler=sched, **kw)[0])
             else:
                 lanes = MicroBatchLanes(params, n=2)
+                mode_seen = []
                 for w in range(2):
                     out = ld.training_window([mbs[2 * w][0], mbs[2 * w + 1][0]], opt, red, sched, lanes,
-                                             step_kwargs=[mbs[2 * w][1], mbs[2 * w + 1][1]], fuse=(mode == "fused"))
+                                             step_kwargs=[mbs[2 * w][1], mbs[2 * w + 1][1]], fuse=(mode == "fused"),
+                                             after_forward=lambda k: mode_seen.append(ops._MULTI_STREAM))
                     losses += [o[0] for o in out]
                 lanes.remove()
+                # a window on lanes runs with cache fills draining their stream (ops.note_cache_fill), and only the window
+                assert ops._MULTI_STREAM == 0 and (mode == "fused" or mode_seen == [1] * 4), (mode, mode_seen)
             torch.cuda.synchronize()
         finally:
             ops.gn_two_pass(False)

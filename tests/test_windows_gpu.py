@@ -265,12 +265,4 @@ def test_cached_device_data_is_complete_before_another_lane_can_read_it():
         assert not side.query(), "a cache fill must not drain its stream outside the multi-stream mode"
     torch.cuda.synchronize()
     assert torch.equal(pk.fwd, pk2.fwd)
-    # the lanes announce the mode for their lifetime
-    from adaprompt_amd.ldm.models.diffusion.ddpm import MicroBatchLanes
-    p = torch.nn.Parameter(torch.zeros(4, device=dev))
-    before = ops._MULTI_STREAM
-    lanes = MicroBatchLanes([p], n=2)
-    assert ops._MULTI_STREAM == before + 1
-    lanes.remove()
-    lanes.remove()
-    assert ops._MULTI_STREAM == before
+    assert ops._MULTI_STREAM == 0           # (training_window announces the mode for the duration of a window on lanes only)
