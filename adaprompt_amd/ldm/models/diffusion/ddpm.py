@@ -1947,6 +1947,11 @@ class LatentDiffusion(ConditioningMixin, DDPM):
         return [(f[0], f[3]) for f in fronts]
 
 
+_LANE_DELAY = None
+if os.environ.get("ADAP_DIAG_LANE_DELAY"):                 # "lane,microseconds"
+    _LANE_DELAY = tuple(int(v) for v in os.environ["ADAP_DIAG_LANE_DELAY"].split(","))
+
+
 class MicroBatchLanes:
     """One HIP stream per micro-batch of an accumulation window (``LatentDiffusion.training_window``).
 
@@ -2038,6 +2043,10 @@ class MicroBatchLanes:
                 if k == 0:
                     self._prev_done = None             # (the optimiser step on lane 0 ordered everything before this window)
             with torch.cuda.stream(s):
+                if _LANE_DELAY is not None and (k if lane is None else lane) % len(self.streams) == _LANE_DELAY[0]:
+                    # DIAGNOSTIC (tools/lane_skew_soak.sh): one idle workgroup holds this lane back, so that the lanes drift apart
+                    # by far more than they ever do alone -- a missing dependency between them then shows as a changed loss
+                    ops._lib.call("adap_debug_occupy", 1, 64, _LANE_DELAY[1], 0, ops._stream())
                 yield s
                 if closing:
                     ev = torch.cuda.Event()

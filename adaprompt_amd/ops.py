@@ -5,6 +5,7 @@ passes raw pointers to the C ABI (include/adaprompt_hip.h) on torch's current st
 torch tensors.  Activations are pixel-major: [B, H, W, C] / [B, N, C] with the channel dim
 contiguous and an arbitrary leading dimension (stride of dim -2)."""
 import ctypes
+import os
 
 import torch
 
@@ -119,7 +120,7 @@ def note_cache_fill():
     """call AFTER the kernels that build a cached device tensor have been issued."""
     global CACHE_FILLS
     CACHE_FILLS += 1
-    if _MULTI_STREAM > 0 and torch.cuda.is_available():
+    if _MULTI_STREAM > 0 and torch.cuda.is_available() and os.environ.get("ADAP_DIAG_NO_FILL_DRAIN") != "1":
         torch.cuda.current_stream().synchronize()
 
 
