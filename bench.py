@@ -490,6 +490,12 @@ def main():
         def run_steps(first, n):                            # noqa: F811 -- the timed loop through the per-batch entry
             return _run_l(n)
 
+    if os.environ.get("ADAP_DIAG_WARM_ONE_STREAM") == "1" and lanes is not None:
+        # DIAGNOSTIC (tools/lanes_two_process_soak.sh): one accumulation window on ONE stream first, so that every lazily built
+        # cache is filled and complete before the lanes start -- separates first-use races from steady-state ones
+        for i_ in range(2):
+            step_prefetch(i_)
+        torch.cuda.synchronize()
     run_steps(0, args.warmup)
     if lanes is not None and ld.batch_idx % 2 == 1:
         # an odd warm-up ends in the middle of an accumulation window: close it here, untimed (clip + optimiser step on the one
